@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs (bit-exact: all integer work)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from synth import noise_frame, synth
+from vc2lib import KERNELS, make_params
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_digests.json")))
+
+
+def _planes(oracle, raw, w, h, cf, bits, word_bytes=2):
+    cw = w if cf == "444" else w // 2
+    ch = h // 2 if cf == "420" else h
+    n0 = w * h * word_bytes
+    n1 = cw * ch * word_bytes
+    y = oracle.ingest(raw[:n0], word_bytes, bits, (h, w))
+    u = oracle.ingest(raw[n0:n0 + n1], word_bytes, bits, (ch, cw))
+    v = oracle.ingest(raw[n0 + n1:n0 + 2 * n1], word_bytes, bits, (ch, cw))
+    return y, u, v
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+@pytest.mark.parametrize("shape,depth", [((48, 80), 3), ((44, 70), 2), ((270, 130), 1), ((64, 96), 4)])
+def test_dwt_forward_matches_oracle(hip, oracle, kernel, shape, depth):
+    rng = np.random.default_rng(11)
+    plane = rng.integers(-512, 512, size=shape).astype(np.int32)
+    want = oracle.dwt_forward(plane, KERNELS[kernel], depth)
+    got = hip.dwt_forward(plane, KERNELS[kernel], depth)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+@pytest.mark.parametrize("shape,depth", [((48, 80), 3), ((44, 70), 2), ((64, 96), 4)])
+def test_dwt_inverse_matches_oracle(hip, oracle, kernel, shape, depth):
+    rng = np.random.default_rng(12)
+    ph, pw = oracle.padded_size(shape[0], depth), oracle.padded_size(shape[1], depth)
+    coef = rng.integers(-3000, 3000, size=(ph, pw)).astype(np.int32)
+    want = oracle.dwt_inverse(coef, KERNELS[kernel], depth, shape)
+    got = hip.dwt_inverse(coef, KERNELS[kernel], depth, shape)
+    assert np.array_equal(got, want)
+
+
+def test_dwt_large_plane_all_tiles(hip, oracle):
+    # bigger than one tile in both directions, ragged tile edges, extreme values (12-bit range)
+    rng = np.random.default_rng(13)
+    plane = (rng.integers(0, 2, size=(400, 720)) * 4095 - 2048).astype(np.int32)
+    for name in ("DD97", "Fidelity", "LeGall"):
+        c = oracle.dwt_forward(plane, KERNELS[name], 4)
+        assert np.array_equal(hip.dwt_forward(plane, KERNELS[name], 4), c), name
+        assert np.array_equal(hip.dwt_inverse(c, KERNELS[name], 4, plane.shape), plane), name
+
+
+def test_quantise_dequantise_match_oracle(hip, oracle):
+    rng = np.random.default_rng(14)
+    depth, ys, xs = 3, 4, 5
+    coef = rng.integers(-20000, 20000, size=(ys * 16, xs * 8)).astype(np.int32)
+    qidx = rng.integers(0, 60, size=(ys, xs)).astype(np.int32)
+    for name in ("DD97", "Fidelity", "Haar0"):
+        qm = oracle.quant_matrix(KERNELS[name], depth)
+        q_want = oracle.quantise_np(coef, depth, qidx, qm)
+        q_got = hip.quantise_np(coef, depth, qidx, qm)
+        assert np.array_equal(q_got, q_want)
+        assert np.array_equal(hip.dequantise_np(q_want, depth, qidx, qm),
+                              oracle.dequantise_np(q_want, depth, qidx, qm))
+        assert np.array_equal(hip.dequantise_ld(q_want, depth, qidx, qm),
+                              oracle.dequantise_ld(q_want, depth, qidx, qm))
+
+
+def test_quantiser_index_limit_error(hip, oracle):
+    from vc2hip_py import Vc2HipError
+    coef = np.ones((16, 16), np.int32)
+    qm = np.zeros(7, np.int32)
+    with pytest.raises(Vc2HipError, match="quantization index exceeds maximum implemented value."):
+        hip.quantise_np(coef, 2, np.full((1, 1), 125, np.int32), qm)
+    hip.quantise_np(coef, 2, np.full((1, 1), 119, np.int32), qm)
+
+
+def _quantised_planes(oracle, seed, lshape, cshape, depth, ys, xs, kernel, q, spread=400):
+    rng = np.random.default_rng(seed)
+    qm = oracle.quant_matrix(KERNELS[kernel], depth)
+    qidx = np.full((ys, xs), q, np.int32)
+    out = []
+    for shape in (lshape, cshape, cshape):
+        c = (rng.standard_normal(shape) * spread).astype(np.int32)
+        c[rng.random(shape) < 0.4] = 0
+        out.append(oracle.quantise_np(c, depth, qidx, qm))
+    return out, qidx, qm
+
+
+@pytest.mark.parametrize("prefix,scalar", [(0, 1), (2, 3)])
+def test_hq_pack_vbr_matches_oracle(hip, oracle, prefix, scalar):
+    depth, ys, xs = 3, 6, 5
+    (y, u, v), qidx, _ = _quantised_planes(oracle, 21, (ys * 8, xs * 16), (ys * 8, xs * 8), depth, ys, xs, "DD97", 8)
+    qidx[1, 2] = 33
+    want = oracle.hq_pack(y, u, v, depth, qidx, prefix, scalar)
+    got = hip.hq_pack(y, u, v, depth, qidx, prefix, scalar)
+    assert bytes(got) == bytes(want)
+
+
+def test_hq_pack_empty_and_dense_slices(hip, oracle):
+    depth, ys, xs = 2, 3, 4
+    rng = np.random.default_rng(22)
+    y = np.zeros((ys * 8, xs * 8), np.int32)
+    u = np.zeros((ys * 8, xs * 4), np.int32)
+    v = np.zeros((ys * 8, xs * 4), np.int32)
+    y[8:16, 8:16] = rng.integers(-65534, 65535, size=(8, 8))   # maximum-length codes
+    v[0, 0] = -1
+    u[16:24, 4:8] = rng.integers(-3, 4, size=(8, 4))
+    qidx = np.zeros((ys, xs), np.int32)
+    want = oracle.hq_pack(y, u, v, depth, qidx, 0, 2)
+    got = hip.hq_pack(y, u, v, depth, qidx, 0, 2)
+    assert bytes(got) == bytes(want)
+
+
+def test_hq_pack_scalar_too_small_error(hip, oracle):
+    from vc2hip_py import Vc2HipError
+    depth, ys, xs = 2, 1, 1
+    y = np.full((16, 16), 30000, np.int32)
+    u = np.zeros((16, 8), np.int32)
+    with pytest.raises(Vc2HipError, match="Slice scalar is too small"):
+        hip.hq_pack(y, u, u, depth, np.zeros((1, 1), np.int32), 0, 1)
+
+
+def test_hq_pack_cbr_matches_oracle(hip, oracle):
+    depth, ys, xs = 3, 4, 4
+    (y, u, v), qidx, _ = _quantised_planes(oracle, 23, (ys * 8, xs * 16), (ys * 8, xs * 8), depth, ys, xs, "DD97", 20, 200)
+    sb = oracle.slice_bytes(ys, xs, 16 * 330, 2)
+    want = oracle.hq_pack(y, u, v, depth, qidx, 1, 2, cbr=sb)
+    got = hip.hq_pack(y, u, v, depth, qidx, 1, 2, cbr=sb)
+    assert bytes(got) == bytes(want)
+
+
+@pytest.mark.parametrize("prefix,scalar", [(0, 1), (3, 2)])
+def test_hq_unpack_matches_oracle(hip, oracle, prefix, scalar):
+    depth, ys, xs = 3, 6, 5
+    lshape, cshape = (ys * 8, xs * 16), (ys * 8, xs * 8)
+    (y, u, v), qidx, _ = _quantised_planes(oracle, 24, lshape, cshape, depth, ys, xs, "LeGall", 6)
+    qidx[2, 3] = 17
+    payload = oracle.hq_pack(y, u, v, depth, qidx, prefix, scalar)
+    y2, u2, v2, q2, used = hip.hq_unpack(payload, lshape, cshape, depth, ys, xs, prefix, scalar)
+    assert np.array_equal(y2, y) and np.array_equal(u2, u) and np.array_equal(v2, v)
+    assert np.array_equal(q2, qidx) and used == payload.size
+
+
+def test_hq_unpack_arbitrary_bytes_matches_oracle(hip, oracle):
+    # third-party / corrupt streams: any byte string parses; bits past a bound read as 1
+    depth, ys, xs = 2, 2, 3
+    lshape, cshape = (ys * 4, xs * 8), (ys * 4, xs * 4)
+    rng = np.random.default_rng(25)
+    for trial in range(5):
+        blob = rng.integers(0, 256, size=4096).astype(np.uint8)
+        blob[rng.random(4096) < 0.3] = 0xFF       # plenty of zero-runs
+        want = oracle.hq_unpack(blob, lshape, cshape, depth, ys, xs, 0, 1)
+        got = hip.hq_unpack(blob, lshape, cshape, depth, ys, xs, 0, 1)
+        for a, b in zip(got[:4], want[:4]):
+            assert np.array_equal(a, b)
+
+
+def test_cbr_qindices_match_oracle(hip, oracle):
+    w, h, depth = 256, 128, 3
+    raw = synth(w, h, "422", 10, 31)
+    y, u, v = _planes(oracle, raw, w, h, "422", 10)
+    k = KERNELS["DD97"]
+    ty, tu, tv = (oracle.dwt_forward(p, k, depth) for p in (y, u, v))
+    qm = oracle.quant_matrix(k, depth)
+    ys, xs = 16, 8
+    sb = oracle.slice_bytes(ys, xs, 24000, 1)
+    want = oracle.cbr_qindices(ty, tu, tv, depth, qm, sb, 1)
+    got = hip.cbr_qindices(ty, tu, tv, depth, qm, sb, 1)
+    assert np.array_equal(got, want)
+    assert len(set(want.flatten().tolist())) > 1
+
+
+def _fmt_cp(hip, w, h, cf, bits, kernel, depth, u, a, **kw):
+    import vc2hip_py
+    word_bytes = kw.pop("word_bytes", 2)
+    fmt = vc2hip_py.picture_format(w, h, cf, bits, word_bytes)
+    cp = vc2hip_py.coding_params(hip.lib, fmt, kernel, depth, u, a, **kw)
+    return fmt, cp
+
+
+def _oracle_payload(oracle, p, raw):
+    """slice payload + decoded picture from the oracle's whole-stream drivers"""
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, n = oracle.decode_stream(p, stream, 1)
+    assert n == 1
+    return stream, dec
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_encode_picture_constq_all_kernels(hip, oracle, kernel):
+    w, h, depth = 208, 120, 3        # pads 120 -> 120 (u=1 -> 15 slices), chroma 104 wide
+    raw = noise_frame(w, h, "422", 10, seed=41)
+    p = make_params(w, h, "422", 10, kernel, depth, 1, 2, q=9, scalar=3)
+    stream, dec = _oracle_payload(oracle, p, raw)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, kernel, depth, 1, 2, q=9, scalar=3)
+    payload, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]      # slices sit right before end-of-sequence
+    assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+@pytest.mark.parametrize("cf,bits,word_bytes", [("444", 12, 2), ("420", 8, 1), ("422", 16, 2), ("420", 10, 2)])
+def test_encode_decode_formats_and_padding(hip, oracle, cf, bits, word_bytes):
+    w, h, depth = 176, 100, 2        # 100 is not a multiple of 4*... -> padded planes
+    raw = synth(w, h, cf, bits, 43, word_bytes=word_bytes)
+    p = make_params(w, h, cf, bits, "DD97", depth, 2, 2, q=5, scalar=4, word_bytes=word_bytes)
+    stream, dec = _oracle_payload(oracle, p, raw)
+    fmt, cp = _fmt_cp(hip, w, h, cf, bits, "DD97", depth, 2, 2, q=5, scalar=4, word_bytes=word_bytes)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+def test_encode_picture_cbr(hip, oracle):
+    w, h, depth = 256, 128, 3
+    raw = synth(w, h, "422", 10, 44)
+    p = make_params(w, h, "422", 10, "DD97", depth, 1, 2, mode="HQ_CBR", s=24000, scalar=1)
+    stream, dec = _oracle_payload(oracle, p, raw)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", depth, 1, 2, mode="HQ_CBR", s=24000, scalar=1)
+    payload, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+def test_q0_lossless_roundtrip_on_gpu(hip):
+    w, h = 320, 176
+    raw = noise_frame(w, h, "422", 10, seed=45)
+    for kernel in KERNELS:
+        fmt, cp = _fmt_cp(hip, w, h, "422", 10, kernel, 4, 1, 2, q=0, scalar=8)
+        payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+        assert hip.decode_picture(payload, fmt, cp) == raw, kernel
+
+
+def test_ld_decode_matches_oracle(hip, oracle):
+    # cfg 5 shape in miniature: LD stream made by the oracle, decoded by the GPU
+    w, h, depth = 256, 120, 3
+    raw = synth(w, h, "422", 8, 46, word_bytes=1)
+    p = make_params(w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=12000, word_bytes=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, n = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=12000, word_bytes=1)
+    ns = cp.y_slices * cp.x_slices
+    sb = oracle.slice_bytes(cp.y_slices, cp.x_slices, 12000, 1)
+    payload = stream[-13 - int(sb.sum()):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+    # fine-grained LD unpack
+    ph, pw = oracle.padded_size(h, depth), oracle.padded_size(w, depth)
+    want = oracle.ld_unpack(np.frombuffer(payload, np.uint8), (ph, pw), (ph, pw // 2), depth, sb)
+    got = hip.ld_unpack(np.frombuffer(payload, np.uint8), (ph, pw), (ph, pw // 2), depth, sb)
+    for a, b in zip(got[:4], want[:4]):
+        assert np.array_equal(a, b)
+
+
+def test_cfg1_reference_digest_on_gpu(hip, oracle):
+    """BASELINE config 1 at full size: GPU payload + oracle stream headers == the reference's stream."""
+    g = GOLD["cfg1"]
+    raw = synth(1920, 1080, "422", 10, 1234)
+    fmt, cp = _fmt_cp(hip, 1920, 1080, "422", 10, "LeGall", 2, 2, 4, q=12, scalar=1)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    p = make_params(1920, 1080, "422", 10, "LeGall", 2, 2, 4, q=12)
+    stream = oracle.encode_stream(p, raw, 1)
+    assert hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"]
+    assert payload == stream[-13 - len(payload):-13]
+    dec = hip.decode_picture(payload, fmt, cp)
+    assert hashlib.sha256(dec).hexdigest() == g["decoded"]["sha256"]
+
+
+def test_cfg2_uhd_batch_device_resident(hip, oracle):
+    """BASELINE config 2 (UHD-1 4:2:2 10-bit DD97 d4 q16 S2), 2 frames through the device-resident
+    batch path; digests of reference output from SURVEY Appendix B."""
+    import torch
+    import vc2hip_py
+    g = GOLD["cfg2"]
+    raw = synth(3840, 2160, "422", 10, 1234, frames=2)
+    fmt, cp = _fmt_cp(hip, 3840, 2160, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    n = 2
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    lens = d_len.cpu().tolist()
+    pay = d_pay.cpu().numpy()
+    # rebuild the reference stream: oracle headers around the GPU payloads
+    p = make_params(3840, 2160, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    stream = oracle.encode_stream(p, raw, n)
+    assert hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"]
+    pos = len(stream) - 13
+    for k in reversed(range(n)):
+        body = bytes(pay[k * stride:k * stride + lens[k]])
+        assert stream[pos - lens[k]:pos] == body, f"frame {k}"
+        pos -= lens[k]
+        pos = stream.rfind(b"BBCD", 0, pos)
+    assert hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest() == g["decoded"]["sha256"]

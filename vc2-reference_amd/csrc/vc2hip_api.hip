@@ -1,0 +1,1008 @@
+// libvc2hip C-ABI (include/vc2hip.h): context, workspace, launch sequencing, error mapping.
+// No torch types, no CPU fallback: every entry point either runs the HIP kernels or fails.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "vc2hip_internal.h"
+
+void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s);
+int vc2_halo_x(int kernel);
+int vc2_halo_y(int kernel);
+void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s);
+void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// profiling hook: optional hipEvent pair around every launch
+// ------------------------------------------------------------------------------------------
+struct ProfEntry {
+  std::string name;
+  int launches = 0;
+  double ms = 0;
+};
+struct Launcher {
+  bool on = false;
+  std::vector<ProfEntry> entries;
+  struct Pending { int entry; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  int cur = -1;
+  hipEvent_t ev() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void collect() {
+    for (auto &p : pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { entries[p.entry].ms += ms; entries[p.entry].launches++; }
+      pool.push_back(p.a);
+      pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
+  if (!L.on) return;
+  int idx = -1;
+  for (size_t i = 0; i < L.entries.size(); ++i) if (L.entries[i].name == name) { idx = (int)i; break; }
+  if (idx < 0) { L.entries.push_back(ProfEntry{name, 0, 0}); idx = (int)L.entries.size() - 1; }
+  Launcher::Pending p{idx, L.ev(), L.ev()};
+  (void)hipEventRecord(p.a, s);
+  L.pending.push_back(p);
+}
+void vc2_prof_end(Launcher &L, hipStream_t s) {
+  if (!L.on) return;
+  (void)hipEventRecord(L.pending.back().b, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct Buf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+enum { B_RAW, B_STORE, B_LL0, B_LL1, B_LL2, B_QIDX, B_SLOTS, B_SIZES, B_OFFS, B_LENS, B_PAYLOAD,
+       B_INDEX, B_PLANE, B_PLANE2, B_CBRB, B_CBRO, B_QM, B_COUNT };
+
+struct vc2hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  unsigned *d_err = nullptr;
+  unsigned *h_err = nullptr; // pinned
+  Buf buf[B_COUNT];
+  Launcher L;
+  std::string err;
+  // cached CBR / LD slice-size tables (re-uploaded only when the parameters change)
+  int cbr_key[5] = {-1, -1, -1, -1, -1};
+  uint64_t cbr_total = 0;
+};
+
+static const char *code_text(int code) {
+  switch (code) {
+    case VC2HIP_OK: return "ok";
+    case VC2HIP_EINVAL: return "invalid argument";
+    case VC2HIP_EQINDEX: return "quantization index exceeds maximum implemented value.";
+    case VC2HIP_ESCALAR: return "Slice scalar is too small, consider using a larger slice scalar.";
+    case VC2HIP_ECBR_TOOBIG: return "SliceIO, HQ CBR mode: Too many bytes for the slice";
+    case VC2HIP_ECBR_LEN: return "Slice component length exceeds 1 byte when divided by slice size scalar. See above for suggestions to prevent this.";
+    case VC2HIP_ECBR_WRONG: return "SliceIO, HQ CBR mode: Wrong number of bytes for a slice";
+    case VC2HIP_EBOUNDED: return "Attempt to write beyond end of bounded write";
+    case VC2HIP_ELD_TOOBIG: return "SliceIO, LD mode: Too many bytes for the U and V slices";
+    case VC2HIP_ECAP: return "output buffer too small";
+    case VC2HIP_ESTREAM: return "truncated or malformed slice data";
+    case VC2HIP_ECODE32: return "quantised coefficient magnitude exceeds 65534 (outside the 32-bit exp-Golomb code domain)";
+    case VC2HIP_EHIP: return "HIP runtime error";
+  }
+  return "unknown error";
+}
+extern "C" const char *vc2hip_error_string(int code) { return code_text(code); }
+
+static int set_err(vc2hip_ctx *c, int code, const char *msg = nullptr) {
+  if (c) c->err = msg ? msg : code_text(code);
+  return code;
+}
+static int hip_fail(vc2hip_ctx *c, hipError_t e, const char *what) {
+  char b[256];
+  snprintf(b, sizeof b, "HIP error in %s: %s", what, hipGetErrorString(e));
+  return set_err(c, VC2HIP_EHIP, b);
+}
+#define HIPCHK(ctx, call)                                       \
+  do {                                                          \
+    hipError_t e_ = (call);                                     \
+    if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);      \
+  } while (0)
+
+extern "C" const char *vc2hip_last_error(const vc2hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ---- host-side arithmetic shared with the bindings -----------------------------------------
+extern "C" int vc2hip_padded_size(int size, int depth) {
+  const int cell = 1 << depth;
+  return cell * ((size + cell - 1) / cell);
+}
+extern "C" int vc2hip_slice_size_is_valid(int depth, int len_luma, int len_chroma, int n_size) {
+  if (depth <= 0 || depth > 31) return 0;
+  const int unit = 1 << depth;
+  const int max_slices = (len_luma < len_chroma ? len_luma : len_chroma) / unit;
+  if (n_size <= 0 || n_size > max_slices) return 0;
+  const int ts = n_size * unit;
+  const int pl = vc2hip_padded_size(len_luma, depth), pc = vc2hip_padded_size(len_chroma, depth);
+  const int n = (pl + ts - 1) / ts;
+  if (pl % n == 0 && (pl / n) % unit == 0 && pc % n == 0 && (pc / n) % unit == 0) return n;
+  return 0;
+}
+// WaveletTransform.cpp:345-423: float variables, double pow, float log/floor (math.h overloads)
+extern "C" int vc2hip_quant_matrix(int kernel, int depth, int32_t *out) {
+  static const float A[7] = {1.280868846f, 1.224744871f, 1.280868846f, 1.414213562f, 1.414213562f, 0.682408629f, 1.139917028f};
+  static const float B[7] = {0.820572875f, 0.847791248f, 0.809253958f, 0.707106871f, 0.707106871f, 1.367856979f, 0.887168005f};
+  static const int S[7] = {1, 1, 1, 0, 1, 0, 1};
+  if (kernel < 0 || kernel > 6 || depth < 0 || depth > 30) return VC2HIP_EINVAL;
+  if (depth == 0) { out[0] = 0; return 0; }
+  const float a2 = A[kernel] * A[kernel], ab = A[kernel] * B[kernel], b2 = B[kernel] * B[kernel];
+  std::vector<float> gl(depth + 1), gh(depth + 1), gd(depth + 1);
+  float mn = 3.402823466e+38f;
+  for (int lv = depth; lv > 0; --lv) {
+    const float sc = (float)(pow((double)a2, depth - lv) / pow(2.0, S[kernel] * (depth - lv + 1)));
+    gl[lv] = sc * a2; gh[lv] = sc * ab; gd[lv] = sc * b2;
+    mn = fminf(fminf(fminf(gl[lv], gh[lv]), gd[lv]), mn);
+  }
+  auto qv = [&](float g) { return (int)floorf(4.0f * logf(g / mn) / logf(2.0f) + 0.5f); };
+  int i = 0;
+  out[i++] = qv(gl[1]);
+  for (int lv = 1; lv <= depth; ++lv) { out[i++] = qv(gh[lv]); out[i++] = qv(gh[lv]); out[i++] = qv(gd[lv]); }
+  return 0;
+}
+static int gcd_i(int a, int b) { a = abs(a); b = abs(b); while (b) { int t = a % b; a = b; b = t; } return a; }
+extern "C" int vc2hip_slice_bytes(int ys, int xs, int total_bytes, int scalar, int32_t *out) {
+  if (ys < 1 || xs < 1 || scalar < 1) return VC2HIP_EINVAL;
+  const int n = ys * xs;
+  int num = total_bytes / scalar - 4 * n, den = n;
+  const int g = gcd_i(num, den);
+  if (g) { num /= g; den /= g; }
+  const int ratio = num / den, rem = num - ratio * den;
+  int residue = 0;
+  for (int i = 0; i < n; ++i) {
+    residue += rem;
+    if (residue < den) out[i] = ratio * scalar + 4;
+    else { out[i] = (ratio + 1) * scalar + 4; residue -= den; }
+  }
+  return 0;
+}
+// SMPTE 2042-1 quant_factor / quant_offset (the reference holds them as a table, Quantisation.cpp:40-83)
+static void make_tables(QuantTables &t) {
+  for (int q = 0; q < 120; ++q) {
+    const uint64_t base = 1ull << (q / 4);
+    uint64_t f;
+    switch (q % 4) {
+      case 0: f = 4 * base; break;
+      case 1: f = (503829 * base + 52958) / 105917; break;
+      case 2: f = (665857 * base + 58854) / 117708; break;
+      default: f = (440253 * base + 32722) / 65444; break;
+    }
+    t.qf[q] = (int32_t)(uint32_t)f;
+    t.off[q] = q == 0 ? 1 : (q == 1 ? 2 : (int32_t)(((uint32_t)t.qf[q] + 1u)) / 2);
+  }
+}
+
+// ---- lifetime ---------------------------------------------------------------------------------
+static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **out) {
+  if (!out) return VC2HIP_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VC2HIP_EHIP;
+  vc2hip_ctx *c = new vc2hip_ctx;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return VC2HIP_EHIP; }
+  if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
+  c->stream = stream;
+  c->own_stream = own;
+  if (hipMalloc((void **)&c->d_err, sizeof(unsigned)) != hipSuccess ||
+      hipHostMalloc((void **)&c->h_err, sizeof(unsigned)) != hipSuccess) { delete c; return VC2HIP_EHIP; }
+  (void)hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream);
+  QuantTables t;
+  make_tables(t);
+  vc2_upload_tables(t, c->stream);
+  vc2_upload_tables_slices(t, c->stream);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return VC2HIP_EHIP; }
+  *out = c;
+  return VC2HIP_OK;
+}
+extern "C" int vc2hip_create(int device, vc2hip_ctx **out) { return create_common(device, nullptr, true, out); }
+extern "C" int vc2hip_create_on_stream(int device, void *s, vc2hip_ctx **out) { return create_common(device, (hipStream_t)s, false, out); }
+extern "C" void vc2hip_destroy(vc2hip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->L.collect();
+  for (auto e : c->L.pool) (void)hipEventDestroy(e);
+  for (auto &b : c->buf) if (b.p) (void)hipFree(b.p);
+  if (c->d_err) (void)hipFree(c->d_err);
+  if (c->h_err) (void)hipHostFree(c->h_err);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int err_from_flags(vc2hip_ctx *c, unsigned f) {
+  if (!f) return VC2HIP_OK;
+  if (f & VC2_DEVERR_QINDEX) return set_err(c, VC2HIP_EQINDEX);
+  if (f & VC2_DEVERR_SCALAR) return set_err(c, VC2HIP_ESCALAR);
+  if (f & VC2_DEVERR_CBR_TOOBIG) return set_err(c, VC2HIP_ECBR_TOOBIG);
+  if (f & VC2_DEVERR_CBR_LEN) return set_err(c, VC2HIP_ECBR_LEN);
+  if (f & VC2_DEVERR_CODE32) return set_err(c, VC2HIP_ECODE32);
+  if (f & VC2_DEVERR_LD_TOOBIG) return set_err(c, VC2HIP_ELD_TOOBIG);
+  return set_err(c, VC2HIP_ESTREAM);
+}
+extern "C" int vc2hip_sync(vc2hip_ctx *c) {
+  if (!c) return VC2HIP_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->L.collect();
+  return err_from_flags(c, *c->h_err);
+}
+
+static int need(vc2hip_ctx *c, int which, size_t bytes, void **out) {
+  Buf &b = c->buf[which];
+  if (b.cap < bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t cap = (bytes + 4095) & ~(size_t)4095;
+    HIPCHK(c, hipMalloc(&b.p, cap));
+    b.cap = cap;
+  }
+  *out = b.p;
+  return VC2HIP_OK;
+}
+#define NEED(ctx, which, bytes, ptr)                                   \
+  do {                                                                 \
+    void *p_;                                                          \
+    int rc_ = need(ctx, which, bytes, &p_);                            \
+    if (rc_) return rc_;                                               \
+    ptr = (decltype(ptr))p_;                                           \
+  } while (0)
+
+// ---- profiling ---------------------------------------------------------------------------------
+extern "C" int vc2hip_profile_enable(vc2hip_ctx *c, int on) { if (!c) return VC2HIP_EINVAL; c->L.on = on != 0; return 0; }
+extern "C" int vc2hip_profile_count(vc2hip_ctx *c) { return c ? (int)c->L.entries.size() : 0; }
+extern "C" int vc2hip_profile_get(vc2hip_ctx *c, int i, const char **name, int *launches, double *total_ms) {
+  if (!c || i < 0 || i >= (int)c->L.entries.size()) return VC2HIP_EINVAL;
+  if (name) *name = c->L.entries[i].name.c_str();
+  if (launches) *launches = c->L.entries[i].launches;
+  if (total_ms) *total_ms = c->L.entries[i].ms;
+  return 0;
+}
+extern "C" int vc2hip_profile_reset(vc2hip_ctx *c) { if (!c) return VC2HIP_EINVAL; c->L.collect(); c->L.entries.clear(); return 0; }
+
+// ------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------
+static int make_geom(Geom &g, const int ph[3], const int pw[3], const int h[3], const int w[3], int depth,
+                     int ys, int xs) {
+  if (depth < 1 || depth > VC2_MAX_DEPTH || ys < 1 || xs < 1) return VC2HIP_EINVAL;
+  g.depth = depth; g.ys = ys; g.xs = xs;
+  int off = 0;
+  for (int c = 0; c < 3; ++c) {
+    CompGeom &cg = g.c[c];
+    cg.h = h[c]; cg.w = w[c]; cg.ph = ph[c]; cg.pw = pw[c];
+    if (ph[c] == 0 || pw[c] == 0) { cg.sh = cg.sw = cg.n0 = 0; cg.coef_off = off; continue; }
+    if (ph[c] % ys || pw[c] % xs) return VC2HIP_EINVAL;
+    cg.sh = ph[c] / ys; cg.sw = pw[c] / xs;
+    if (cg.sh % (1 << depth) || cg.sw % (1 << depth)) return VC2HIP_EINVAL;
+    cg.n0 = (cg.sh >> depth) * (cg.sw >> depth);
+    cg.coef_off = off;
+    off += cg.sh * cg.sw;
+  }
+  g.slice_coefs = off;
+  return VC2HIP_OK;
+}
+
+static void chroma_dims(int h, int w, int cf, int *ch, int *cw) {
+  *ch = cf == VC2HIP_CF420 ? h / 2 : h;
+  *cw = cf == VC2HIP_CF444 ? w : w / 2;
+}
+
+// encoder-side picture geometry (WaveletTransform.cpp:1267-1273) or decoder-side
+// (DecodeStream.cpp:483-498: chroma derived from the padded luma size)
+static int picture_geom(Geom &g, const vc2hip_picture_format *f, const vc2hip_coding_params *cp, bool decoder) {
+  if (!f || !cp || f->width < 1 || f->height < 1 || f->word_bytes < 1 || f->word_bytes > 4 ||
+      f->bit_depth < 1 || f->bit_depth > 8 * f->word_bytes || f->chroma_format < 0 || f->chroma_format > 2)
+    return VC2HIP_EINVAL;
+  int ch, cw;
+  chroma_dims(f->height, f->width, f->chroma_format, &ch, &cw);
+  int h[3] = {f->height, ch, ch}, w[3] = {f->width, cw, cw}, ph[3], pw[3];
+  ph[0] = vc2hip_padded_size(f->height, cp->depth);
+  pw[0] = vc2hip_padded_size(f->width, cp->depth);
+  if (decoder) chroma_dims(ph[0], pw[0], f->chroma_format, &ph[1], &pw[1]);
+  else { ph[1] = vc2hip_padded_size(ch, cp->depth); pw[1] = vc2hip_padded_size(cw, cp->depth); }
+  ph[2] = ph[1]; pw[2] = pw[1];
+  return make_geom(g, ph, pw, h, w, cp->depth, cp->y_slices, cp->x_slices);
+}
+
+extern "C" size_t vc2hip_raw_picture_bytes(const vc2hip_picture_format *f) {
+  int ch, cw;
+  chroma_dims(f->height, f->width, f->chroma_format, &ch, &cw);
+  return ((size_t)f->height * f->width + 2 * (size_t)ch * cw) * f->word_bytes;
+}
+static size_t max_slice_bytes(int prefix, int scalar) { return (size_t)prefix + 4 + 3 * 255 * (size_t)scalar; }
+extern "C" size_t vc2hip_max_payload_bytes(const vc2hip_picture_format *f, const vc2hip_coding_params *cp) {
+  (void)f;
+  const size_t n = (size_t)cp->y_slices * cp->x_slices;
+  if (cp->mode == VC2HIP_HQ_CONSTQ) return n * max_slice_bytes(cp->prefix, cp->scalar);
+  if (cp->mode == VC2HIP_HQ_CBR) return (size_t)cp->compressed_bytes + n * (cp->prefix + (size_t)cp->scalar + 4);
+  return (size_t)cp->compressed_bytes + n;
+}
+
+// ------------------------------------------------------------------------------------------
+// level sequencing
+// ------------------------------------------------------------------------------------------
+struct LLPlanes { // per level l >= 1: compact LL_l planes for the three components
+  int32_t *p[VC2_MAX_DEPTH + 1][3];
+  long long stride[VC2_MAX_DEPTH + 1][3];
+};
+
+static size_t ll_bytes(const Geom &g, int n) {
+  size_t e = 0;
+  for (int l = 1; l <= g.depth; ++l)
+    for (int c = 0; c < 3; ++c) e += (size_t)(g.c[c].ph >> l) * (g.c[c].pw >> l);
+  return e * n * sizeof(int32_t);
+}
+static void ll_layout(const Geom &g, int n, int32_t *base, LLPlanes &ll) {
+  size_t off = 0;
+  for (int l = 1; l <= g.depth; ++l)
+    for (int c = 0; c < 3; ++c) {
+      const size_t e = (size_t)(g.c[c].ph >> l) * (g.c[c].pw >> l);
+      ll.p[l][c] = base + off;
+      ll.stride[l][c] = (long long)e;
+      off += e * n;
+    }
+}
+
+static void fill_level(LevelParams &p, const Geom &g, int level, int kernel, const int32_t *qm) {
+  const int D = g.depth, Lv = D - level;
+  p.band = 3 * (Lv - 1) + 1;
+  p.ys = g.ys; p.xs = g.xs; p.slice_coefs = g.slice_coefs;
+  const int hx = vc2_halo_x(kernel), hy = vc2_halo_y(kernel);
+  for (int c = 0; c < 3; ++c) {
+    const CompGeom &cg = g.c[c];
+    p.in_h[c] = cg.ph >> level; p.in_w[c] = cg.pw >> level;
+    p.pic_h[c] = cg.h; p.pic_w[c] = cg.w;
+    p.coef_off[c] = cg.coef_off;
+    if (cg.ph == 0) { p.tiles_x[c] = p.tiles_y[c] = 0; p.fh[c] = p.fw[c] = 2; p.tsy[c] = p.tsx[c] = 1; continue; }
+    p.fh[c] = cg.sh >> level; p.fw[c] = cg.sw >> level;
+    // tile ~64 x 128 samples, whole slices, power-of-two slice counts, LDS <= 64 KiB
+    int tsy = 1, tsx = 1;
+    while (tsy * 2 * p.fh[c] <= 64 && tsy * 2 <= g.ys) tsy *= 2;
+    while (tsx * 2 * p.fw[c] <= 128 && tsx * 2 <= g.xs) tsx *= 2;
+    while ((size_t)(tsy * p.fh[c] + 2 * hy) * (tsx * p.fw[c] + 2 * hx) * 4 > 150 * 1024) {
+      if (tsx > 1) tsx /= 2; else if (tsy > 1) tsy /= 2; else break;
+    }
+    p.tsy[c] = tsy; p.tsx[c] = tsx;
+    p.tiles_y[c] = (g.ys + tsy - 1) / tsy;
+    p.tiles_x[c] = (g.xs + tsx - 1) / tsx;
+    p.band_n[c] = (p.fh[c] / 2) * (p.fw[c] / 2);
+    p.band_off[c] = p.band_n[c]; // == n0 * 4^(Lv-1): HL at 1x, LH at 2x, HH at 3x
+  }
+  for (int b = 0; b < 3 * D + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
+}
+
+// forward transform of n pictures: raw words (first level fused) or int32 LL_0 planes -> store
+static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const void *const src[3],
+                       const long long src_stride[3], bool src_raw, const vc2hip_picture_format *f,
+                       int32_t *store, const LLPlanes &ll) {
+  for (int level = 0; level < g.depth; ++level) {
+    LevelParams p;
+    memset(&p, 0, sizeof p);
+    fill_level(p, g, level, kernel, nullptr);
+    p.store = store; p.store_stride = (long long)g.ys * g.xs * g.slice_coefs;
+    p.err = c->d_err;
+    p.ll_to_store = (level == g.depth - 1);
+    const bool first = (level == 0) && src_raw;
+    for (int k = 0; k < 3; ++k) {
+      if (level == 0) { p.plane[k] = (void *)src[k]; p.plane_stride[k] = src_stride[k]; }
+      else { p.plane[k] = ll.p[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
+      p.ll[k] = ll.p[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
+    }
+    if (first) {
+      p.word_bytes = f->word_bytes;
+      p.sample_shift = 8 * f->word_bytes - f->bit_depth;
+      p.sample_offset = 1 << (f->bit_depth - 1);
+    }
+    if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for one LDS tile");
+    int rc = vc2_launch_forward_level(c->L, kernel, first, p, n, c->stream);
+    if (rc) return set_err(c, rc, "invalid wavelet kernel");
+  }
+  return VC2HIP_OK;
+}
+
+// inverse transform of n pictures: store (optionally dequantised on load) -> int32 planes or raw words
+static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, int32_t *store, const int32_t *qidx,
+                       const int32_t *qm, bool dequant, bool ll_ready, const LLPlanes &ll, void *const dst[3],
+                       const long long dst_stride[3], bool dst_raw, const vc2hip_picture_format *f) {
+  for (int level = g.depth - 1; level >= 0; --level) {
+    LevelParams p;
+    memset(&p, 0, sizeof p);
+    fill_level(p, g, level, kernel, qm);
+    p.store = store; p.store_stride = (long long)g.ys * g.xs * g.slice_coefs;
+    p.qidx = qidx; p.err = c->d_err; p.dequant = dequant;
+    p.ll_from_store = (level == g.depth - 1) && !ll_ready;
+    const bool fin = (level == 0) && dst_raw;
+    for (int k = 0; k < 3; ++k) {
+      if (level == 0) { p.plane[k] = dst[k]; p.plane_stride[k] = dst_stride[k]; }
+      else { p.plane[k] = ll.p[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
+      p.ll[k] = ll.p[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
+    }
+    if (fin) {
+      p.word_bytes = f->word_bytes;
+      p.sample_shift = 8 * f->word_bytes - f->bit_depth;
+      p.sample_offset = 1 << (f->bit_depth - 1);
+      p.clip_lo = -(1 << (f->bit_depth - 1));
+      p.clip_hi = (1 << (f->bit_depth - 1)) - 1;
+    }
+    if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for one LDS tile");
+    int rc = vc2_launch_inverse_level(c->L, kernel, fin, p, n, c->stream);
+    if (rc) return set_err(c, rc, "invalid wavelet kernel");
+  }
+  return VC2HIP_OK;
+}
+
+static void fill_comp_arrays(const Geom &g, int n[3], int off[3], int n0[3]) {
+  for (int c = 0; c < 3; ++c) { n[c] = g.c[c].sh * g.c[c].sw; off[c] = g.c[c].coef_off; n0[c] = g.c[c].n0 ? g.c[c].n0 : 1; }
+}
+
+// pack n pictures from the store into d_payload; VBR goes through slots + scan + compaction
+static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const int32_t *store, const int32_t *d_qidx,
+                    const int32_t *qm, bool quantise, int prefix, int scalar, const int32_t *d_cbr_bytes,
+                    const uint32_t *d_cbr_offs, uint64_t cbr_total, uint8_t *d_payload, long long stride,
+                    unsigned long long *d_lens) {
+  const int ns = g.ys * g.xs;
+  PackParams p;
+  memset(&p, 0, sizeof p);
+  p.store = store; p.store_stride = (long long)ns * g.slice_coefs;
+  p.qidx = d_qidx; p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
+  p.depth = g.depth; p.prefix = prefix; p.scalar = scalar;
+  for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
+  p.err = c->d_err; p.quantise = quantise;
+  p.payload = d_payload; p.payload_stride = stride;
+  if (d_cbr_bytes) {
+    p.cbr_bytes = d_cbr_bytes; p.cbr_offsets = d_cbr_offs;
+    vc2_launch_pack(c->L, p, n, c->stream);
+    vc2_launch_fill_u64(c->L, d_lens, cbr_total, (size_t)n, c->stream);
+    return VC2HIP_OK;
+  }
+  const int slot = (int)((max_slice_bytes(prefix, scalar) + 15) & ~(size_t)15);
+  uint8_t *slots; uint32_t *sizes, *offs;
+  NEED(c, B_SLOTS, (size_t)n * ns * slot, slots);
+  NEED(c, B_SIZES, (size_t)n * ns * 4, sizes);
+  NEED(c, B_OFFS, (size_t)n * ns * 4, offs);
+  p.slots = slots; p.slot_bytes = slot; p.sizes = sizes;
+  vc2_launch_pack(c->L, p, n, c->stream);
+  vc2_launch_scan_sizes(c->L, sizes, offs, d_lens, ns, n, c->stream);
+  vc2_launch_compact(c->L, slots, slot, sizes, offs, d_payload, stride, ns, n, c->stream);
+  return VC2HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fine-grained entry points (host planes; test / drop-in granularity)
+// ------------------------------------------------------------------------------------------
+static int one_plane_geom(Geom &g, int ph, int pw, int depth, int ys, int xs) {
+  int phs[3] = {ph, 0, 0}, pws[3] = {pw, 0, 0};
+  return make_geom(g, phs, pws, phs, pws, depth, ys, xs);
+}
+
+extern "C" int vc2hip_dwt_forward(vc2hip_ctx *c, const int32_t *in, int h, int w, int kernel, int depth,
+                                  int32_t *out) {
+  if (!c || !in || !out || h < 1 || w < 1 || depth < 1 || depth > VC2_MAX_DEPTH) return set_err(c, VC2HIP_EINVAL);
+  if (kernel < 0 || kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int ph = vc2hip_padded_size(h, depth), pw = vc2hip_padded_size(w, depth);
+  Geom g;
+  int rc = one_plane_geom(g, ph, pw, depth, ph >> depth, pw >> depth);
+  if (rc) return set_err(c, rc);
+  // waveletPad (WaveletTransform.cpp:79-94) on the host for this test-granularity entry point
+  std::vector<int32_t> padded((size_t)ph * pw);
+  for (int y = 0; y < ph; ++y)
+    for (int x = 0; x < pw; ++x) padded[(size_t)y * pw + x] = in[(size_t)(y < h ? y : h - 1) * w + (x < w ? x : w - 1)];
+  int32_t *d_plane, *d_store, *d_ll;
+  const size_t pb = (size_t)ph * pw * 4;
+  NEED(c, B_PLANE, pb, d_plane);
+  NEED(c, B_STORE, pb, d_store);
+  NEED(c, B_LL0, ll_bytes(g, 1) + 16, d_ll);
+  LLPlanes ll;
+  ll_layout(g, 1, d_ll, ll);
+  HIPCHK(c, hipMemcpyAsync(d_plane, padded.data(), pb, hipMemcpyHostToDevice, c->stream));
+  const void *src[3] = {d_plane, nullptr, nullptr};
+  const long long ss[3] = {(long long)ph * pw, 0, 0};
+  rc = run_forward(c, g, kernel, 1, src, ss, false, nullptr, d_store, ll);
+  if (rc) return rc;
+  vc2_launch_store_to_plane(c->L, d_store, g.slice_coefs, 0, d_plane, ph, pw, depth, g.ys, g.xs, nullptr, nullptr, 0,
+                            c->d_err, c->stream);
+  HIPCHK(c, hipMemcpyAsync(out, d_plane, pb, hipMemcpyDeviceToHost, c->stream));
+  return vc2hip_sync(c);
+}
+
+extern "C" int vc2hip_dwt_inverse(vc2hip_ctx *c, const int32_t *in, int ph, int pw, int kernel, int depth,
+                                  int32_t *out, int h, int w) {
+  if (!c || !in || !out || depth < 1 || depth > VC2_MAX_DEPTH || h < 1 || w < 1 || h > ph || w > pw) return set_err(c, VC2HIP_EINVAL);
+  if (kernel < 0 || kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
+  if (ph % (1 << depth) || pw % (1 << depth)) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = one_plane_geom(g, ph, pw, depth, ph >> depth, pw >> depth);
+  if (rc) return set_err(c, rc);
+  int32_t *d_plane, *d_store, *d_ll;
+  const size_t pb = (size_t)ph * pw * 4;
+  NEED(c, B_PLANE, pb, d_plane);
+  NEED(c, B_STORE, pb, d_store);
+  NEED(c, B_LL0, ll_bytes(g, 1) + 16, d_ll);
+  LLPlanes ll;
+  ll_layout(g, 1, d_ll, ll);
+  HIPCHK(c, hipMemcpyAsync(d_plane, in, pb, hipMemcpyHostToDevice, c->stream));
+  vc2_launch_plane_to_store(c->L, d_plane, ph, pw, depth, g.ys, g.xs, d_store, g.slice_coefs, 0, c->stream);
+  void *dst[3] = {d_plane, nullptr, nullptr};
+  const long long ds[3] = {(long long)ph * pw, 0, 0};
+  rc = run_inverse(c, g, kernel, 1, d_store, nullptr, nullptr, false, false, ll, dst, ds, false, nullptr);
+  if (rc) return rc;
+  std::vector<int32_t> full((size_t)ph * pw);
+  HIPCHK(c, hipMemcpyAsync(full.data(), d_plane, pb, hipMemcpyDeviceToHost, c->stream));
+  rc = vc2hip_sync(c);
+  if (rc) return rc;
+  for (int y = 0; y < h; ++y) memcpy(out + (size_t)y * w, full.data() + (size_t)y * pw, (size_t)w * 4); // resize(shape), :340
+  return VC2HIP_OK;
+}
+
+// common body of quantise_np / dequantise_np / dequantise_ld
+static int plane_quant_op(vc2hip_ctx *c, const int32_t *in, int ph, int pw, int depth, const int32_t *qidx, int ys,
+                          int xs, const int32_t *qm, int32_t *out, int op /*0 quant,1 scale,2 scale+LD*/) {
+  if (!c || !in || !out || !qidx || !qm) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = one_plane_geom(g, ph, pw, depth, ys, xs);
+  if (rc) return set_err(c, rc);
+  const size_t pb = (size_t)ph * pw * 4;
+  const int ns = ys * xs, nb = 3 * depth + 1;
+  int32_t *d_plane, *d_store, *d_q, *d_ll = nullptr;
+  int *d_qm;
+  NEED(c, B_PLANE, pb, d_plane);
+  NEED(c, B_STORE, pb, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  NEED(c, B_QM, 256, d_qm);
+  HIPCHK(c, hipMemcpyAsync(d_plane, in, pb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_q, qidx, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_qm, qm, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+  vc2_launch_plane_to_store(c->L, d_plane, ph, pw, depth, ys, xs, d_store, g.slice_coefs, 0, c->stream);
+  if (op == 0) {
+    vc2_launch_quantise_store(c->L, d_store, ns, g.slice_coefs, g.c[0].sh * g.c[0].sw, 0, g.c[0].n0, d_q, d_qm, c->d_err, c->stream);
+    vc2_launch_store_to_plane(c->L, d_store, g.slice_coefs, 0, d_plane, ph, pw, depth, ys, xs, d_q, d_qm, 0, c->d_err, c->stream);
+  } else {
+    vc2_launch_store_to_plane(c->L, d_store, g.slice_coefs, 0, d_plane, ph, pw, depth, ys, xs, d_q, d_qm, 1, c->d_err, c->stream);
+  }
+  const int llh = ph >> depth, llw = pw >> depth;
+  if (op == 2) {
+    NEED(c, B_LL0, (size_t)llh * llw * 4, d_ll);
+    vc2_launch_ld_ll(c->L, d_store, 0, g.slice_coefs, 0, g.c[0].n0, llh, llw, ys, xs, d_q, qm[0], d_ll, 0, 1, c->d_err, c->stream);
+  }
+  HIPCHK(c, hipMemcpyAsync(out, d_plane, pb, hipMemcpyDeviceToHost, c->stream));
+  std::vector<int32_t> llh_host;
+  if (op == 2) {
+    llh_host.resize((size_t)llh * llw);
+    HIPCHK(c, hipMemcpyAsync(llh_host.data(), d_ll, llh_host.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  rc = vc2hip_sync(c);
+  if (rc) return rc;
+  if (op == 2) {
+    const int s = 1 << depth;
+    for (int y = 0; y < llh; ++y)
+      for (int x = 0; x < llw; ++x) out[(size_t)y * s * pw + (size_t)x * s] = llh_host[(size_t)y * llw + x];
+  }
+  return VC2HIP_OK;
+}
+extern "C" int vc2hip_quantise_np(vc2hip_ctx *c, const int32_t *coef, int ph, int pw, int depth, const int32_t *qidx,
+                                  int ys, int xs, const int32_t *qm, int32_t *out) {
+  return plane_quant_op(c, coef, ph, pw, depth, qidx, ys, xs, qm, out, 0);
+}
+extern "C" int vc2hip_dequantise_np(vc2hip_ctx *c, const int32_t *q, int ph, int pw, int depth, const int32_t *qidx,
+                                    int ys, int xs, const int32_t *qm, int32_t *out) {
+  return plane_quant_op(c, q, ph, pw, depth, qidx, ys, xs, qm, out, 1);
+}
+extern "C" int vc2hip_dequantise_ld(vc2hip_ctx *c, const int32_t *q, int ph, int pw, int depth, const int32_t *qidx,
+                                    int ys, int xs, const int32_t *qm, int32_t *out) {
+  return plane_quant_op(c, q, ph, pw, depth, qidx, ys, xs, qm, out, 2);
+}
+
+static int geom_from_abi(Geom &g, const vc2hip_geom *a) {
+  int ph[3] = {a->luma_h, a->chroma_h, a->chroma_h}, pw[3] = {a->luma_w, a->chroma_w, a->chroma_w};
+  return make_geom(g, ph, pw, ph, pw, a->depth, a->y_slices, a->x_slices);
+}
+
+// upload three planes and scatter them into the store
+static int planes_to_store(vc2hip_ctx *c, const Geom &g, const int32_t *const pl[3], int32_t *d_store) {
+  size_t mx = 0;
+  for (int k = 0; k < 3; ++k) mx = std::max(mx, (size_t)g.c[k].ph * g.c[k].pw * 4);
+  int32_t *d_plane;
+  NEED(c, B_PLANE, mx * 3, d_plane);
+  for (int k = 0; k < 3; ++k) {
+    int32_t *dp = d_plane + (mx / 4) * k;
+    HIPCHK(c, hipMemcpyAsync(dp, pl[k], (size_t)g.c[k].ph * g.c[k].pw * 4, hipMemcpyHostToDevice, c->stream));
+    vc2_launch_plane_to_store(c->L, dp, g.c[k].ph, g.c[k].pw, g.depth, g.ys, g.xs, d_store, g.slice_coefs, g.c[k].coef_off, c->stream);
+  }
+  return VC2HIP_OK;
+}
+static int store_to_planes(vc2hip_ctx *c, const Geom &g, const int32_t *d_store, int32_t *const pl[3]) {
+  size_t mx = 0;
+  for (int k = 0; k < 3; ++k) mx = std::max(mx, (size_t)g.c[k].ph * g.c[k].pw * 4);
+  int32_t *d_plane;
+  NEED(c, B_PLANE, mx * 3, d_plane);
+  for (int k = 0; k < 3; ++k) {
+    int32_t *dp = d_plane + (mx / 4) * k;
+    vc2_launch_store_to_plane(c->L, d_store, g.slice_coefs, g.c[k].coef_off, dp, g.c[k].ph, g.c[k].pw, g.depth, g.ys, g.xs,
+                              nullptr, nullptr, 0, c->d_err, c->stream);
+    HIPCHK(c, hipMemcpyAsync(pl[k], dp, (size_t)g.c[k].ph * g.c[k].pw * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  return VC2HIP_OK;
+}
+
+static int cbr_offsets_upload(vc2hip_ctx *c, const int32_t *bytes, int ns, int prefix, int32_t **d_b, uint32_t **d_o, uint64_t *total) {
+  c->cbr_key[0] = -1; // whatever was cached is overwritten
+  std::vector<uint32_t> offs(ns);
+  uint64_t run = 0;
+  for (int i = 0; i < ns; ++i) { offs[i] = (uint32_t)run; run += (uint64_t)bytes[i] + prefix; }
+  *total = run;
+  int32_t *db; uint32_t *dof;
+  NEED(c, B_CBRB, (size_t)ns * 4, db);
+  NEED(c, B_CBRO, (size_t)ns * 4, dof);
+  HIPCHK(c, hipMemcpyAsync(db, bytes, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dof, offs.data(), (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *d_b = db; *d_o = dof;
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_hq_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
+                              const int32_t *qidx, int prefix, int scalar, const int32_t *cbr, uint8_t *out, size_t cap,
+                              size_t *out_len) {
+  if (!c || !y || !u || !v || !ga || !qidx || !out || !out_len || prefix < 0 || scalar < 1) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = geom_from_abi(g, ga);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int32_t *d_store, *d_q; uint8_t *d_pay; unsigned long long *d_len;
+  NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  NEED(c, B_LENS, 64, d_len);
+  const int32_t *pl[3] = {y, u, v};
+  if ((rc = planes_to_store(c, g, pl, d_store))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d_q, qidx, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  size_t paycap = (size_t)ns * max_slice_bytes(prefix, scalar);
+  int32_t *d_cb = nullptr; uint32_t *d_co = nullptr; uint64_t total = 0;
+  if (cbr) {
+    if ((rc = cbr_offsets_upload(c, cbr, ns, prefix, &d_cb, &d_co, &total))) return rc;
+    paycap = total;
+  }
+  NEED(c, B_PAYLOAD, paycap + 64, d_pay);
+  rc = run_pack(c, g, 1, d_store, d_q, nullptr, false, prefix, scalar, d_cb, d_co, total, d_pay, (long long)paycap, d_len);
+  if (rc) return rc;
+  unsigned long long len = 0;
+  HIPCHK(c, hipMemcpyAsync(&len, d_len, 8, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = vc2hip_sync(c))) return rc;
+  if (len > cap) return set_err(c, VC2HIP_ECAP);
+  HIPCHK(c, hipMemcpy(out, d_pay, len, hipMemcpyDeviceToHost));
+  *out_len = (size_t)len;
+  return VC2HIP_OK;
+}
+
+// slice offsets of one VBR payload already on the device
+static int build_index(vc2hip_ctx *c, const uint8_t *d_pay, long long stride, const unsigned long long *d_lens, int n, int ns,
+                       int prefix, int scalar, uint32_t **d_offs_out) {
+  uint32_t *d_offs; void *ws;
+  NEED(c, B_OFFS, (size_t)n * ns * 4, d_offs);
+  const size_t wsb = vc2_slice_index_workspace(n, (size_t)stride, prefix, scalar);
+  NEED(c, B_INDEX, wsb, ws);
+  HIPCHK(c, hipMemsetAsync(d_offs, 0xFF, (size_t)n * ns * 4, c->stream)); // unreachable slices read past the payload
+  vc2_launch_slice_index(c->L, d_pay, stride, d_lens, d_offs, ns, prefix, scalar, n, c->d_err, c->stream, ws, wsb);
+  *d_offs_out = d_offs;
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_hq_unpack(vc2hip_ctx *c, const uint8_t *in, size_t len, const vc2hip_geom *ga, int prefix, int scalar,
+                                int32_t *y, int32_t *u, int32_t *v, int32_t *qidx, size_t *consumed) {
+  if (!c || !in || !ga || !y || !u || !v || !qidx || prefix < 0 || scalar < 1) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = geom_from_abi(g, ga);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int32_t *d_store, *d_q; uint8_t *d_pay; unsigned long long *d_len; uint32_t *d_offs;
+  NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  NEED(c, B_LENS, 64, d_len);
+  const size_t stride = (len + 63) & ~(size_t)63;
+  NEED(c, B_PAYLOAD, stride + 64, d_pay);
+  unsigned long long l64 = len;
+  HIPCHK(c, hipMemcpyAsync(d_pay, in, len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_len, &l64, 8, hipMemcpyHostToDevice, c->stream));
+  if ((rc = build_index(c, d_pay, (long long)stride, d_len, 1, ns, prefix, scalar, &d_offs))) return rc;
+  UnpackParams p;
+  memset(&p, 0, sizeof p);
+  p.payload = d_pay; p.payload_stride = (long long)stride; p.lens = d_len; p.offsets = d_offs;
+  p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
+  p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  int n0[3];
+  fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
+  p.prefix = prefix; p.scalar = scalar; p.err = c->d_err;
+  vc2_launch_unpack(c->L, p, 1, c->stream);
+  int32_t *pl[3] = {y, u, v};
+  if ((rc = store_to_planes(c, g, d_store, pl))) return rc;
+  HIPCHK(c, hipMemcpyAsync(qidx, d_q, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+  uint32_t last_off = 0;
+  HIPCHK(c, hipMemcpyAsync(&last_off, d_offs + ns - 1, 4, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = vc2hip_sync(c))) return rc;
+  if (consumed) { // end of the last slice
+    size_t pos = (size_t)last_off + prefix + 1;
+    for (int k = 0; k < 3 && pos < len; ++k) pos += 1 + (size_t)in[pos] * scalar;
+    *consumed = pos;
+  }
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
+                                   const int32_t *qm, const int32_t *slice_bytes, int scalar, int32_t *qidx) {
+  if (!c || !y || !u || !v || !ga || !qm || !slice_bytes || !qidx || scalar < 1) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = geom_from_abi(g, ga);
+  if (rc) return set_err(c, rc);
+  if ((size_t)g.slice_coefs * 16 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
+  const int ns = g.ys * g.xs;
+  int32_t *d_store, *d_q, *d_sb;
+  NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  NEED(c, B_CBRB, (size_t)ns * 4, d_sb);
+  c->cbr_key[0] = -1;
+  const int32_t *pl[3] = {y, u, v};
+  if ((rc = planes_to_store(c, g, pl, d_store))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d_sb, slice_bytes, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  CbrParams p;
+  memset(&p, 0, sizeof p);
+  p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q; p.slice_bytes = d_sb;
+  p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
+  p.scalar = scalar; p.err = c->d_err;
+  for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm[b];
+  vc2_launch_cbr(c->L, p, 1, c->stream);
+  HIPCHK(c, hipMemcpyAsync(qidx, d_q, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+  return vc2hip_sync(c);
+}
+
+static int ld_offsets_upload(vc2hip_ctx *c, const int32_t *bytes, int ns, int32_t **d_b, uint32_t **d_o, uint64_t *total) {
+  return cbr_offsets_upload(c, bytes, ns, 0, d_b, d_o, total);
+}
+
+static void fill_ld_unpack(LdUnpackParams &p, const Geom &g, const uint8_t *d_pay, long long stride, const int32_t *d_sb,
+                           const uint32_t *d_so, int32_t *d_store, int32_t *d_q, unsigned *err) {
+  memset(&p, 0, sizeof p);
+  const int ns = g.ys * g.xs;
+  p.payload = d_pay; p.payload_stride = stride; p.slice_bytes = d_sb; p.offsets = d_so;
+  p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
+  p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  int n0[3];
+  fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
+  p.err = err;
+}
+
+extern "C" int vc2hip_ld_unpack(vc2hip_ctx *c, const uint8_t *in, size_t len, const vc2hip_geom *ga, const int32_t *slice_bytes,
+                                int32_t *y, int32_t *u, int32_t *v, int32_t *qidx, size_t *consumed) {
+  if (!c || !in || !ga || !slice_bytes || !y || !u || !v || !qidx) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = geom_from_abi(g, ga);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int32_t *d_store, *d_q, *d_sb; uint32_t *d_so; uint8_t *d_pay; uint64_t total;
+  NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  if ((rc = ld_offsets_upload(c, slice_bytes, ns, &d_sb, &d_so, &total))) return rc;
+  if (total > len) return set_err(c, VC2HIP_ESTREAM);
+  NEED(c, B_PAYLOAD, len + 64, d_pay);
+  HIPCHK(c, hipMemcpyAsync(d_pay, in, len, hipMemcpyHostToDevice, c->stream));
+  LdUnpackParams p;
+  fill_ld_unpack(p, g, d_pay, (long long)len, d_sb, d_so, d_store, d_q, c->d_err);
+  vc2_launch_ld_unpack(c->L, p, 1, c->stream);
+  int32_t *pl[3] = {y, u, v};
+  if ((rc = store_to_planes(c, g, d_store, pl))) return rc;
+  HIPCHK(c, hipMemcpyAsync(qidx, d_q, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+  if (consumed) *consumed = (size_t)total;
+  return vc2hip_sync(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused picture path
+// ------------------------------------------------------------------------------------------
+static void raw_planes(const vc2hip_picture_format *f, const void *base, const void *pl[3], long long stride[3]) {
+  int ch, cw;
+  chroma_dims(f->height, f->width, f->chroma_format, &ch, &cw);
+  const size_t ln = (size_t)f->height * f->width * f->word_bytes, cn = (size_t)ch * cw * f->word_bytes;
+  pl[0] = base;
+  pl[1] = (const uint8_t *)base + ln;
+  pl[2] = (const uint8_t *)base + ln + cn;
+  stride[0] = stride[1] = stride[2] = (long long)(ln + 2 * cn);
+}
+
+extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, const vc2hip_picture_format *f,
+                                       const vc2hip_coding_params *cp, void *d_payload, size_t payload_stride,
+                                       uint64_t *d_lens) {
+  if (!c || !d_raw || n < 1 || !f || !cp || !d_payload || !d_lens) return set_err(c, VC2HIP_EINVAL);
+  if (cp->mode != VC2HIP_HQ_CONSTQ && cp->mode != VC2HIP_HQ_CBR) return set_err(c, VC2HIP_EINVAL, "only HQ modes are encoded");
+  if (cp->kernel < 0 || cp->kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
+  if (cp->scalar < 1 || cp->prefix < 0) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = picture_geom(g, f, cp, false);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int32_t qm[VC2_MAX_BANDS];
+  if ((rc = vc2hip_quant_matrix(cp->kernel, cp->depth, qm))) return set_err(c, rc);
+  int32_t *d_store, *d_ll, *d_q;
+  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
+  NEED(c, B_QIDX, (size_t)n * ns * 4, d_q);
+  LLPlanes ll;
+  ll_layout(g, n, d_ll, ll);
+  const void *src[3]; long long ss[3];
+  raw_planes(f, d_raw, src, ss);
+  if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll))) return rc;
+  int32_t *d_cb = nullptr; uint32_t *d_co = nullptr; uint64_t total = 0;
+  if (cp->mode == VC2HIP_HQ_CBR) {
+    if ((size_t)g.slice_coefs * 16 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
+    const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
+    if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
+      std::vector<int32_t> sb(ns);
+      vc2hip_slice_bytes(g.ys, g.xs, cp->compressed_bytes, cp->scalar, sb.data());
+      if ((rc = cbr_offsets_upload(c, sb.data(), ns, cp->prefix, &d_cb, &d_co, &total))) return rc;
+      memcpy(c->cbr_key, key, sizeof key);
+      c->cbr_total = total;
+    }
+    d_cb = (int32_t *)c->buf[B_CBRB].p; d_co = (uint32_t *)c->buf[B_CBRO].p; total = c->cbr_total;
+    if (total > payload_stride) return set_err(c, VC2HIP_ECAP);
+    CbrParams p;
+    memset(&p, 0, sizeof p);
+    p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q; p.slice_bytes = d_cb;
+    p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+    fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
+    p.scalar = cp->scalar; p.err = c->d_err;
+    for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm[b];
+    vc2_launch_cbr(c->L, p, n, c->stream);
+  } else {
+    if (payload_stride < vc2hip_max_payload_bytes(f, cp)) return set_err(c, VC2HIP_ECAP);
+    // quantIndicesConstQ, EncodeStream.cpp:128-138
+    vc2_launch_fill_i32(c->L, d_q, cp->q_index, (size_t)n * ns, c->stream);
+  }
+  return run_pack(c, g, n, d_store, d_q, qm, true, cp->prefix, cp->scalar, d_cb, d_co, total, (uint8_t *)d_payload,
+                  (long long)payload_stride, (unsigned long long *)d_lens);
+}
+
+static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens, int n,
+                               const vc2hip_picture_format *f, const vc2hip_coding_params *cp, void *d_raw_out, bool ld) {
+  if (!c || !d_payload || n < 1 || !f || !cp || !d_raw_out) return set_err(c, VC2HIP_EINVAL);
+  if (cp->kernel < 0 || cp->kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = picture_geom(g, f, cp, true);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int32_t qm[VC2_MAX_BANDS];
+  if ((rc = vc2hip_quant_matrix(cp->kernel, cp->depth, qm))) return set_err(c, rc);
+  int32_t *d_store, *d_ll, *d_q;
+  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
+  NEED(c, B_QIDX, (size_t)n * ns * 4, d_q);
+  LLPlanes ll;
+  ll_layout(g, n, d_ll, ll);
+  if (!ld) {
+    if (!d_lens || cp->scalar < 1 || cp->prefix < 0) return set_err(c, VC2HIP_EINVAL);
+    uint32_t *d_offs;
+    if ((rc = build_index(c, (const uint8_t *)d_payload, (long long)payload_stride, (const unsigned long long *)d_lens, n, ns,
+                          cp->prefix, cp->scalar, &d_offs))) return rc;
+    UnpackParams p;
+    memset(&p, 0, sizeof p);
+    p.payload = (const uint8_t *)d_payload; p.payload_stride = (long long)payload_stride;
+    p.lens = (const unsigned long long *)d_lens; p.offsets = d_offs;
+    p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
+    p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+    int n0[3];
+    fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
+    p.prefix = cp->prefix; p.scalar = cp->scalar; p.err = c->d_err;
+    vc2_launch_unpack(c->L, p, n, c->stream);
+  } else {
+    // DecodeStream.cpp:312, :331-333: per-slice sizes from the picture byte budget
+    int32_t *d_sb; uint32_t *d_so; uint64_t total;
+    const int key[5] = {g.ys, g.xs, cp->compressed_bytes, 1, -7};
+    if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
+      std::vector<int32_t> sb(ns);
+      vc2hip_slice_bytes(g.ys, g.xs, cp->compressed_bytes, 1, sb.data());
+      if ((rc = ld_offsets_upload(c, sb.data(), ns, &d_sb, &d_so, &total))) return rc;
+      memcpy(c->cbr_key, key, sizeof key);
+      c->cbr_total = total;
+    }
+    d_sb = (int32_t *)c->buf[B_CBRB].p; d_so = (uint32_t *)c->buf[B_CBRO].p; total = c->cbr_total;
+    if (total > payload_stride) return set_err(c, VC2HIP_ESTREAM);
+    LdUnpackParams p;
+    fill_ld_unpack(p, g, (const uint8_t *)d_payload, (long long)payload_stride, d_sb, d_so, d_store, d_q, c->d_err);
+    vc2_launch_ld_unpack(c->L, p, n, c->stream);
+    for (int k = 0; k < 3; ++k)
+      vc2_launch_ld_ll(c->L, d_store, (long long)ns * g.slice_coefs, g.slice_coefs, g.c[k].coef_off, g.c[k].n0,
+                       g.c[k].ph >> g.depth, g.c[k].pw >> g.depth, g.ys, g.xs, d_q, qm[0], ll.p[g.depth][k],
+                       ll.stride[g.depth][k], n, c->d_err, c->stream);
+  }
+  const void *dstc[3]; long long ds[3];
+  raw_planes(f, d_raw_out, dstc, ds);
+  void *dst[3] = {(void *)dstc[0], (void *)dstc[1], (void *)dstc[2]};
+  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f);
+}
+
+extern "C" int vc2hip_decode_batch_dev(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens,
+                                       int n, const vc2hip_picture_format *f, const vc2hip_coding_params *cp, void *d_raw_out) {
+  return decode_batch_common(c, d_payload, payload_stride, d_lens, n, f, cp, d_raw_out, cp && cp->mode == VC2HIP_LD);
+}
+
+extern "C" int vc2hip_encode_picture_hq(vc2hip_ctx *c, const void *raw, const vc2hip_picture_format *f,
+                                        const vc2hip_coding_params *cp, uint8_t *payload, size_t cap, size_t *len,
+                                        int32_t *qidx_out) {
+  if (!c || !raw || !f || !cp || !payload || !len) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rb = vc2hip_raw_picture_bytes(f), pcap = vc2hip_max_payload_bytes(f, cp);
+  uint8_t *d_raw, *d_pay; unsigned long long *d_len;
+  NEED(c, B_RAW, rb + 64, d_raw);
+  NEED(c, B_PAYLOAD, pcap + 64, d_pay);
+  NEED(c, B_LENS, 64, d_len);
+  HIPCHK(c, hipMemcpyAsync(d_raw, raw, rb, hipMemcpyHostToDevice, c->stream));
+  int rc = vc2hip_encode_batch_dev(c, d_raw, 1, f, cp, d_pay, pcap, (uint64_t *)d_len);
+  if (rc) return rc;
+  unsigned long long l = 0;
+  HIPCHK(c, hipMemcpyAsync(&l, d_len, 8, hipMemcpyDeviceToHost, c->stream));
+  if (qidx_out)
+    HIPCHK(c, hipMemcpyAsync(qidx_out, c->buf[B_QIDX].p, (size_t)cp->y_slices * cp->x_slices * 4, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = vc2hip_sync(c))) return rc;
+  if (l > cap) return set_err(c, VC2HIP_ECAP);
+  HIPCHK(c, hipMemcpy(payload, d_pay, l, hipMemcpyDeviceToHost));
+  *len = (size_t)l;
+  return VC2HIP_OK;
+}
+
+static int decode_picture_host(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,
+                               const vc2hip_coding_params *cp, void *raw_out, bool ld) {
+  if (!c || !payload || !f || !cp || !raw_out) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rb = vc2hip_raw_picture_bytes(f);
+  const size_t stride = (len + 63) & ~(size_t)63;
+  uint8_t *d_raw, *d_pay; unsigned long long *d_len;
+  NEED(c, B_RAW, rb + 64, d_raw);
+  NEED(c, B_PAYLOAD, stride + 64, d_pay);
+  NEED(c, B_LENS, 64, d_len);
+  unsigned long long l64 = len;
+  HIPCHK(c, hipMemcpyAsync(d_pay, payload, len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_len, &l64, 8, hipMemcpyHostToDevice, c->stream));
+  int rc = decode_batch_common(c, d_pay, stride, (const uint64_t *)d_len, 1, f, cp, d_raw, ld);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(raw_out, d_raw, rb, hipMemcpyDeviceToHost, c->stream));
+  return vc2hip_sync(c);
+}
+extern "C" int vc2hip_decode_picture_hq(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,
+                                        const vc2hip_coding_params *cp, void *raw_out) {
+  return decode_picture_host(c, payload, len, f, cp, raw_out, false);
+}
+extern "C" int vc2hip_decode_picture_ld(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,
+                                        const vc2hip_coding_params *cp, void *raw_out) {
+  return decode_picture_host(c, payload, len, f, cp, raw_out, true);
+}

@@ -1,0 +1,203 @@
+// Internal declarations shared by the libvc2hip translation units (not installed).
+//
+// Device data layout (DESIGN.md "Data layout in HBM"):
+//   * sample planes        : raw planar words exactly as in the file (big-endian, MSB justified)
+//   * LL planes            : one compact row-major int32 plane per wavelet level and component
+//   * coefficient store    : [picture][slice][component][band][row][col] int32 -- every slice's
+//                            coefficients already in the order the slice coder emits them, so the
+//                            pack / unpack kernels stream 4 KiB-contiguous records and the DWT
+//                            kernels write / gather whole band blocks of a slice contiguously.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/vc2hip.h"
+
+#define VC2_MAX_DEPTH 7
+#define VC2_MAX_BANDS (3 * VC2_MAX_DEPTH + 1)
+
+// device-side error flags (OR-ed into ctx->d_err by kernels)
+enum : unsigned {
+  VC2_DEVERR_QINDEX = 1u << 0,     // adjusted quantiser index > 119
+  VC2_DEVERR_SCALAR = 1u << 1,     // slice component needs > 255*scalar bytes
+  VC2_DEVERR_CBR_TOOBIG = 1u << 2, // CBR: V component does not fit the slice
+  VC2_DEVERR_CBR_LEN = 1u << 3,    // CBR: V length byte > 255
+  VC2_DEVERR_CODE32 = 1u << 4,     // |coef| > 65534
+  VC2_DEVERR_STREAM = 1u << 5,     // slice data runs past the payload
+  VC2_DEVERR_LD_TOOBIG = 1u << 6,
+};
+
+struct CompGeom {
+  int h, w;     // picture plane (unpadded)
+  int ph, pw;   // padded plane
+  int sh, sw;   // slice size in samples (ph / ys, pw / xs)
+  int coef_off; // first coefficient of this component inside a slice record
+  int n0;       // coefficients of one slice in the LL band: (sh >> depth) * (sw >> depth)
+};
+
+struct Geom {
+  CompGeom c[3];
+  int depth, ys, xs;
+  int slice_coefs; // coefficients per slice record (all three components)
+};
+
+// offset of band `band` (0 = LL, then HL,LH,HH per level, coarsest first) inside a component
+// record whose LL block has n0 coefficients: level L bands hold n0 * 4^(L-1) each.
+__host__ __device__ inline int band_offset(int n0, int band) {
+  if (band == 0) return 0;
+  const int L = (band - 1) / 3 + 1, kind = (band - 1) % 3;
+  // n0 * (1 + 3 * (4^(L-1) - 1) / 3) = n0 * 4^(L-1)
+  return n0 * ((1 << (2 * (L - 1))) * (1 + kind));
+}
+// band index of coefficient j (coding order) of a component record
+__host__ __device__ inline int band_of_index(int j, int n0) {
+  const int m = j / n0;
+  if (m == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int lg = 31 - __clz(m);
+#else
+  const int lg = 31 - __builtin_clz((unsigned)m);
+#endif
+  const int L = lg / 2 + 1;
+  return 3 * (L - 1) + (m >> (2 * (L - 1)));
+}
+
+struct QuantTables {
+  int32_t qf[120];
+  int32_t off[120];
+};
+
+// ------------------------------------------------------------------------------------------
+// kernel parameter blocks
+// ------------------------------------------------------------------------------------------
+struct LevelParams {
+  // input of a forward level / output of an inverse level
+  void *plane[3];             // FIRST/FINAL: raw sample words, else int32 LL_l plane
+  long long plane_stride[3];  // per picture, in bytes (raw) or elements (int32)
+  int32_t *ll[3];             // LL_{l+1} plane (forward: output unless LAST; inverse: input)
+  long long ll_stride[3];     // per picture, elements
+  int32_t *store;             // coefficient store
+  long long store_stride;     // per picture, elements
+  const int32_t *qidx;        // inverse: per-slice quantiser indices, n_pictures * ys * xs
+  int in_h[3], in_w[3];       // plane size at this level (padded >> level)
+  int pic_h[3], pic_w[3];     // FIRST/FINAL: unpadded picture size
+  int fh[3], fw[3];           // slice footprint at this level, samples
+  int tsy[3], tsx[3];         // slices per tile
+  int tiles_y[3], tiles_x[3];
+  int coef_off[3];
+  int band_off[3];            // offset of this level's HL band inside a component record
+  int band_n[3];              // coefficients per band block (bsh * bsw)
+  int band;                   // band index of HL at this level (for the quant matrix)
+  int ys, xs, slice_coefs;
+  int word_bytes, sample_shift, sample_offset; // raw sample format
+  int clip_lo, clip_hi;
+  int ll_from_store;          // inverse, coarsest level: LL comes from store band 0 (dequantised)
+  int ll_to_store;            // forward, last level: LL goes to store band 0
+  int dequant;                // inverse: apply scale() to store values
+  unsigned *err;              // device error flags
+  int qmatrix[VC2_MAX_BANDS];
+};
+
+struct PackParams {
+  const int32_t *store;
+  long long store_stride;
+  const int32_t *qidx;        // n_pictures * n_slices (ConstQ: filled by host)
+  int n_slices, slice_coefs;
+  int comp_n[3], comp_off[3], comp_n0[3];
+  int depth;
+  int prefix, scalar;
+  int qmatrix[VC2_MAX_BANDS];
+  // VBR: fixed-stride slots + sizes; CBR: direct
+  uint8_t *slots;             // n_pictures * n_slices * slot_bytes
+  int slot_bytes;
+  uint32_t *sizes;            // n_pictures * n_slices
+  const int32_t *cbr_bytes;   // per slice (one picture's worth, shared), NULL => VBR
+  const uint32_t *cbr_offsets;
+  uint8_t *payload;
+  long long payload_stride;
+  unsigned *err;
+  int quantise;               // 0: store already holds quantised values (fine-grained API)
+};
+
+struct UnpackParams {
+  const uint8_t *payload;
+  long long payload_stride;
+  const unsigned long long *lens; // per picture
+  const uint32_t *offsets;    // n_pictures * n_slices slice start offsets
+  int32_t *store;
+  long long store_stride;
+  int32_t *qidx;
+  int n_slices, slice_coefs;
+  int comp_n[3], comp_off[3];
+  int prefix, scalar;
+  unsigned *err;
+};
+
+struct CbrParams {
+  const int32_t *store;
+  long long store_stride;
+  int32_t *qidx;
+  const int32_t *slice_bytes;
+  int n_slices, slice_coefs;
+  int comp_n[3], comp_off[3], comp_n0[3];
+  int scalar;
+  int qmatrix[VC2_MAX_BANDS];
+  unsigned *err;
+};
+
+// ------------------------------------------------------------------------------------------
+// launchers (implemented in the kernel TUs)
+// ------------------------------------------------------------------------------------------
+struct Launcher; // profiling hook, defined in vc2hip_api.hip
+
+void vc2_upload_tables(const QuantTables &t, hipStream_t s);
+int vc2_launch_forward_level(Launcher &L, int kernel, bool first, const LevelParams &p, int n_pictures,
+                             hipStream_t s);
+int vc2_launch_inverse_level(Launcher &L, int kernel, bool final_level, const LevelParams &p,
+                             int n_pictures, hipStream_t s);
+size_t vc2_level_lds_bytes(int kernel, const LevelParams &p);
+
+void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s);
+void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets,
+                           unsigned long long *totals, int n_slices, int n_pictures, hipStream_t s);
+void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const uint32_t *sizes,
+                        const uint32_t *offsets, uint8_t *payload, long long payload_stride,
+                        int n_slices, int n_pictures, hipStream_t s);
+void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s);
+void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s);
+void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
+                            const unsigned long long *lens, uint32_t *offsets, int n_slices,
+                            int prefix, int scalar, int n_pictures, unsigned *err, hipStream_t s,
+                            void *workspace, size_t workspace_bytes);
+size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix, int scalar);
+
+// layout conversion for the fine-grained API (interleaved in-place plane <-> coefficient store)
+void vc2_launch_plane_to_store(Launcher &L, const int32_t *plane, int ph, int pw, int depth, int ys,
+                               int xs, int32_t *store, int slice_coefs, int coef_off, hipStream_t s);
+void vc2_launch_store_to_plane(Launcher &L, const int32_t *store, int slice_coefs, int coef_off,
+                               int32_t *plane, int ph, int pw, int depth, int ys, int xs,
+                               const int32_t *qidx, const int *qmatrix, int mode /*0 copy,1 scale*/,
+                               unsigned *err, hipStream_t s);
+void vc2_launch_quantise_store(Launcher &L, int32_t *store, int n_slices, int slice_coefs, int comp_n,
+                               int comp_off, int n0, const int32_t *qidx, const int *qmatrix,
+                               unsigned *err, hipStream_t s);
+// LD: DC-predicted reconstruction of the LL band of one component (Quantisation.cpp:287-306)
+void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride, int slice_coefs,
+                      int coef_off, int n0, int llh, int llw, int ys, int xs, const int32_t *qidx,
+                      int qm0, int32_t *ll_plane, long long ll_stride, int n_pictures, unsigned *err,
+                      hipStream_t s);
+struct LdUnpackParams {
+  const uint8_t *payload;
+  long long payload_stride;
+  const int32_t *slice_bytes; // per slice
+  const uint32_t *offsets;    // per slice (prefix sums of slice_bytes)
+  int32_t *store;
+  long long store_stride;
+  int32_t *qidx;
+  int n_slices, slice_coefs;
+  int comp_n[3], comp_off[3];
+  unsigned *err;
+};
+void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s);

@@ -1,0 +1,794 @@
+// Quantisation + HQ / LD slice coding kernels.
+//
+// Replaces, from /root/reference/src/Library/src:
+//   quant / quant_factor / adjust_quant_index        Quantisation.cpp:16-20, :40-76
+//   component_slice_bytes                            Slices.cpp:97-119
+//   HQSliceIO_VBR / HQSliceIO_CBR (out and in)       Slices.cpp:305-612 (over :645-694)
+//   LDSliceIO (in)                                   Slices.cpp:246-303
+//   interleaved exp-Golomb, bounded bit I/O          VLC.cpp:21-94, :151-257
+//   quantIndicesCBR + yss_for_slice                  EncodeStream.cpp:73-125, Quantisation.cpp:627-642
+//   inverse_quantise_LLSubband / predictDC           Quantisation.cpp:191-208, :287-306
+//
+// Work unit = one slice (HQ pack, CBR search: one wavefront per slice; unpack: one lane per
+// slice component).  The coefficient store keeps each slice's coefficients contiguous and in
+// coding order, so reads and writes here are plain streams.
+#include "vc2hip_internal.h"
+
+void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
+void vc2_prof_end(Launcher &L, hipStream_t s);
+
+__constant__ QuantTables c_qs;
+void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s) {
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_qs), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------
+// Quantisation.cpp:69-76
+__device__ __forceinline__ int quant_dev(int v, int aq) {
+  const int qf = c_qs.qf[aq];
+  const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+  int a = (int)(mag << 2);
+  a /= qf;
+  return v < 0 ? (int)(0u - (unsigned)a) : a;
+}
+// Quantisation.cpp:86-95
+__device__ __forceinline__ int scale_dev(int v, int aq) {
+  const int qf = c_qs.qf[aq], off = c_qs.off[aq];
+  const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+  int a = (int)(mag * (unsigned)qf);
+  if (a > 0) a = (int)((unsigned)a + (unsigned)off);
+  a = (int)((unsigned)a + 2u);
+  a /= 4;
+  return v < 0 ? (int)(0u - (unsigned)a) : a;
+}
+
+// SignedVLC(v).numOfBits(), VLC.cpp:78-85: 1 for 0, else 2*floor(log2(|v|+1)) + 2
+__device__ __forceinline__ int svlc_bits(int v) {
+  if (v == 0) return 1;
+  const unsigned m = (v < 0 ? 0u - (unsigned)v : (unsigned)v) + 1u;
+  return 2 * (31 - __clz(m)) + 2;
+}
+// spread the low 16 bits of x to the even bit positions
+__device__ __forceinline__ unsigned spread16(unsigned x) {
+  x &= 0xFFFFu;
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+// SignedVLC(v).code(), VLC.cpp:21-52, :78-85 (valid for |v| <= 65534, the reference's own domain)
+__device__ __forceinline__ unsigned svlc_code(int v) {
+  if (v == 0) return 1u;
+  const unsigned m = (v < 0 ? 0u - (unsigned)v : (unsigned)v) + 1u;
+  const int k = 31 - __clz(m);
+  const unsigned low = m & ((1u << k) - 1u);
+  const unsigned u = (spread16(low) << 1) | 1u; // (0 b)* 1
+  return (u << 1) | (v < 0 ? 1u : 0u);
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ long long wave_sum64(long long v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// OR a code of nb bits at MSB-first bit position pos of a big-endian-word bit buffer
+__device__ __forceinline__ void put_code(unsigned *buf, int pos, unsigned code, int nb) {
+  const int wi = pos >> 5, bo = pos & 31;
+  const unsigned long long v = (unsigned long long)code << (64 - nb - bo);
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  if (hi) atomicOr(&buf[wi], hi);
+  if (lo) atomicOr(&buf[wi + 1], lo);
+}
+
+// One component of one slice, processed by one wavefront: (optionally) quantise, measure the
+// code lengths, (optionally) write the codes into `bits`, and return the number of bits up to
+// and including the last non-zero coefficient (component_slice_bytes' `count`).
+template <bool QUANT, bool WRITE, class Src>
+__device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, const int *qm, int lane,
+                                              unsigned *bits, int region_bits, unsigned *err) {
+  int base = 0, count = 0;
+  for (int r0 = 0; r0 < n; r0 += 512) {
+    int v[8], nb[8];
+    int sum = 0, last_end = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int j = r0 + lane * 8 + k;
+      int c = 0;
+      if (j < n) {
+        c = src(j);
+        if (QUANT) {
+          const int aq = max(q - qm[band_of_index(j, n0)], 0);
+          if (aq > 119) { atomicOr(err, VC2_DEVERR_QINDEX); c = 0; }
+          else c = quant_dev(c, aq);
+        }
+        nb[k] = svlc_bits(c);
+        if (nb[k] > 32) { atomicOr(err, VC2_DEVERR_CODE32); c = 0; nb[k] = 1; }
+      } else {
+        nb[k] = 0;
+      }
+      v[k] = c;
+      sum += nb[k];
+      if (c != 0) last_end = sum;
+    }
+    const int incl = wave_incl_scan(sum, lane);
+    const int lane_base = base + incl - sum;
+    count = max(count, wave_max(last_end ? lane_base + last_end : 0));
+    if (WRITE) {
+      int pos = lane_base;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (nb[k] && pos + nb[k] <= region_bits) put_code(bits, pos, svlc_code(v[k]), nb[k]);
+        pos += nb[k];
+      }
+    }
+    base += __shfl(incl, 63);
+  }
+  return count;
+}
+
+// ------------------------------------------------------------------------------------------
+// HQ pack: one wavefront per slice
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
+  extern __shared__ unsigned lds_u[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  const int region_words = (255 * p.scalar + 3) / 4 + 2;
+  const int region_bits = (region_words - 1) * 32;
+  unsigned *buf = lds_u + wave * 3 * region_words;
+  const bool active = slice < p.n_slices;
+  for (int i = lane; i < 3 * region_words; i += 64) buf[i] = 0;
+  __syncthreads();
+
+  int bytes[3] = {0, 0, 0};
+  int q = 0;
+  if (active) {
+    q = p.qidx[(size_t)pic * p.n_slices + slice];
+    const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+    for (int c = 0; c < 3; ++c) {
+      const int32_t *src = rec + p.comp_off[c];
+      auto ld = [&](int j) -> int { return src[j]; };
+      int count;
+      if (p.quantise)
+        count = component_bits<true, true>(ld, p.comp_n[c], p.comp_n0[c], q, p.qmatrix, lane,
+                                           buf + c * region_words, region_bits, p.err);
+      else
+        count = component_bits<false, true>(ld, p.comp_n[c], p.comp_n0[c], q, p.qmatrix, lane,
+                                            buf + c * region_words, region_bits, p.err);
+      int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
+      if (len > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
+      bytes[c] = len * p.scalar;
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  uint8_t *dst;
+  if (p.cbr_bytes) { // Slices.cpp:352-368: V absorbs the remainder of the slice
+    const int vb = p.cbr_bytes[slice] - 4 - bytes[0] - bytes[1];
+    if (vb < bytes[2]) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); }
+    else if (vb / p.scalar > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); }
+    else bytes[2] = vb;
+    dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
+  } else {
+    dst = p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes;
+  }
+  const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
+  if (!p.cbr_bytes && lane == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
+  for (int i = lane; i < total; i += 64) {
+    int t = i - p.prefix;
+    unsigned b = 0;
+    if (t == 0) b = (unsigned)q & 0xFF;
+    else if (t > 0) {
+      t -= 1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (t >= 0 && t < 1 + bytes[c]) {
+          if (t == 0) b = (unsigned)(bytes[c] / p.scalar);
+          else {
+            const int k = t - 1;
+            b = (k < 4 * (region_words - 1)) ? (buf[c * region_words + (k >> 2)] >> (24 - 8 * (k & 3))) & 0xFF : 0;
+          }
+        }
+        t -= 1 + bytes[c];
+      }
+    }
+    dst[i] = (uint8_t)b;
+  }
+}
+
+void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s) {
+  const int region_words = (255 * p.scalar + 3) / 4 + 2;
+  const size_t lds = (size_t)4 * 3 * region_words * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_prof_begin(L, "hq_pack", s);
+  hipLaunchKernelGGL(k_hq_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), lds, s, p);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// VBR: exclusive scan of slice sizes (one workgroup per picture) + compaction
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_sizes(const uint32_t *sizes, uint32_t *offsets,
+                                                     unsigned long long *totals, int n) {
+  __shared__ unsigned part[1024];
+  const int pic = blockIdx.x, t = threadIdx.x;
+  const uint32_t *s = sizes + (size_t)pic * n;
+  uint32_t *o = offsets + (size_t)pic * n;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per, e = min(n, b + per);
+  unsigned sum = 0;
+  for (int i = b; i < e; ++i) sum += s[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned run = part[t] - sum;
+  for (int i = b; i < e; ++i) { o[i] = run; run += s[i]; }
+  if (t == 1023) totals[pic] = part[1023];
+}
+
+void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets,
+                           unsigned long long *totals, int n_slices, int n_pictures, hipStream_t s) {
+  vc2_prof_begin(L, "slice_offsets_scan", s);
+  hipLaunchKernelGGL(k_scan_sizes, dim3(n_pictures), dim3(1024), 0, s, sizes, offsets, totals, n_slices);
+  vc2_prof_end(L, s);
+}
+
+__global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_bytes,
+                                                 const uint32_t *sizes, const uint32_t *offsets,
+                                                 uint8_t *payload, long long payload_stride, int n) {
+  const int lane = threadIdx.x & 63, slice = blockIdx.x * 4 + (threadIdx.x >> 6), pic = blockIdx.y;
+  if (slice >= n) return;
+  const size_t si = (size_t)pic * n + slice;
+  const uint8_t *src = slots + si * slot_bytes;
+  uint8_t *dst = payload + (size_t)pic * payload_stride + offsets[si];
+  const int size = (int)sizes[si];
+  for (int i = lane; i < size; i += 64) dst[i] = src[i];
+}
+
+void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const uint32_t *sizes,
+                        const uint32_t *offsets, uint8_t *payload, long long payload_stride,
+                        int n_slices, int n_pictures, hipStream_t s) {
+  vc2_prof_begin(L, "slice_compact", s);
+  hipLaunchKernelGGL(k_compact, dim3((n_slices + 3) / 4, n_pictures), dim3(256), 0, s, slots, slot_bytes,
+                     sizes, offsets, payload, payload_stride, n_slices);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// HQ_CBR quantiser search: one wavefront per slice, slice coefficients staged in LDS
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
+  extern __shared__ int lds_i[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  if (slice >= p.n_slices) return; // no workgroup barriers below
+  int *co = lds_i + wave * p.slice_coefs;
+  const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
+  // LDS traffic of one wavefront is ordered; no cross-wave sharing of `co`
+
+  const int avail = p.slice_bytes[slice] - 4;
+  auto need_bytes = [&](int tq, bool &bad) -> int {
+    int need = 0;
+    for (int c = 0; c < 3; ++c) {
+      const int *src = co + p.comp_off[c];
+      auto ld = [&](int j) -> int { return src[j]; };
+      const int count = component_bits<true, false>(ld, p.comp_n[c], p.comp_n0[c], tq, p.qmatrix, lane,
+                                                    nullptr, 0, p.err);
+      const int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
+      if (len > 255) { bad = true; if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); }
+      need += len * p.scalar;
+    }
+    return need;
+  };
+  // luma-only sum of squared reconstruction error (int product, 64-bit sum)
+  auto yss = [&](int tq, bool &bad) -> long long {
+    long long acc = 0;
+    const int *src = co + p.comp_off[0];
+    for (int j = lane; j < p.comp_n[0]; j += 64) {
+      const int aq = max(tq - p.qmatrix[band_of_index(j, p.comp_n0[0])], 0);
+      if (aq > 119) { bad = true; continue; }
+      const int v = src[j];
+      const int d = (int)((unsigned)v - (unsigned)scale_dev(quant_dev(v, aq), aq));
+      acc += (int)((unsigned)d * (unsigned)d);
+    }
+    return wave_sum64(acc);
+  };
+
+  bool bad = false;
+  int trial = 63, q = 127, delta = 64;
+  while (delta > 0) {
+    delta >>= 1;
+    if (trial - 0 > 119 + 64) { bad = true; break; }
+    const int need = need_bytes(trial, bad);
+    if (bad) break;
+    if (need <= avail) { if (trial < q) q = trial; trial -= delta; }
+    else trial += delta;
+  }
+  if (!bad) {
+    trial = q;
+    long long prev = yss(trial, bad), d;
+    do {
+      ++trial;
+      const long long cur = yss(trial, bad);
+      bad = __any(bad);
+      if (bad) break;
+      d = cur - prev;
+      prev = cur;
+    } while (d < 0);
+    q = trial - 1;
+  }
+  if (__any(bad) && lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX);
+  if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
+}
+
+void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_cbr_search, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_prof_begin(L, "cbr_search", s);
+  hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256),
+                     (size_t)4 * p.slice_coefs * 4, s, p);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// HQ unpack: one lane per slice component
+// ------------------------------------------------------------------------------------------
+struct BitReader { // bounded MSB-first reader; past the bound (or the payload) bits read as 1
+  const uint8_t *p;
+  unsigned nbytes, pos;
+  unsigned long long acc;
+  int have;
+  __device__ __forceinline__ void init(const uint8_t *ptr, unsigned n) { p = ptr; nbytes = n; pos = 0; acc = 0; have = 0; }
+  __device__ __forceinline__ void refill() {
+    while (have <= 56) {
+      const unsigned b = pos < nbytes ? p[pos] : 0xFFu;
+      ++pos;
+      acc |= (unsigned long long)b << (56 - have);
+      have += 8;
+    }
+  }
+  __device__ __forceinline__ void skip(int n) { acc = n >= 64 ? 0 : acc << n; have -= n; }
+};
+
+__device__ __forceinline__ unsigned long long compact_odd64(unsigned long long x) {
+  // gather bits at positions 0,2,4,... into the low half
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+  return x;
+}
+
+// decode n signed exp-Golomb values (VLC.cpp:283-317) from a bounded region into out[0..n)
+__device__ void decode_component(const uint8_t *data, unsigned nbytes, int n, int32_t *out) {
+  BitReader br;
+  br.init(data, nbytes);
+  int j = 0;
+  while (j < n) {
+    br.refill();
+    // run of '1' bits = run of zero coefficients
+    const int ones = __clzll((long long)~br.acc);
+    if (ones > 0) {
+      const int z = min(min(ones, br.have), n - j);
+      for (int k = 0; k < z; ++k) out[j + k] = 0;
+      j += z;
+      br.skip(z);
+      continue;
+    }
+    // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
+    const unsigned long long follow = br.acc & 0xAAAAAAAAAAAAAAAAull;
+    const int K = follow ? __clzll((long long)follow) / 2 : 32;
+    if (2 * K + 2 <= br.have && K <= 27) {
+      const unsigned long long body = br.acc >> (64 - 2 * K); // top 2K bits: (0 b) pairs
+      const unsigned data_bits = (unsigned)compact_odd64(body);
+      const unsigned mag = ((1u << K) | data_bits) - 1u;
+      const int neg = (int)((br.acc >> (62 - 2 * K)) & 1ull);
+      out[j++] = neg ? (int)(0u - mag) : (int)mag;
+      br.skip(2 * K + 2);
+    } else {
+      // very long code (outside the reference's 32-bit domain): bit-serial, wraps like the oracle
+      unsigned value = 1;
+      for (;;) {
+        br.refill();
+        const int f = (int)(br.acc >> 63);
+        br.skip(1);
+        if (f) break;
+        br.refill();
+        value = (value << 1) | (unsigned)(br.acc >> 63);
+        br.skip(1);
+      }
+      value -= 1u;
+      int r = 0;
+      if (value) {
+        br.refill();
+        r = (br.acc >> 63) ? (int)(0u - value) : (int)value;
+        br.skip(1);
+      }
+      out[j++] = r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_hq_unpack(const UnpackParams p) {
+  const int t = blockIdx.x * 64 + threadIdx.x, pic = blockIdx.y;
+  if (t >= p.n_slices * 3) return;
+  const int slice = t / 3, comp = t - slice * 3;
+  const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
+  const unsigned long long plen = p.lens[pic];
+  unsigned long long pos = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
+  auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay[a] : 0u; };
+  if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(pos);
+  pos += 1;
+  for (int c = 0; c < comp; ++c) pos += 1 + (unsigned long long)rd(pos) * p.scalar;
+  unsigned len = rd(pos) * p.scalar;
+  pos += 1;
+  if (pos + len > plen) {
+    atomicOr(p.err, VC2_DEVERR_STREAM);
+    len = pos < plen ? (unsigned)(plen - pos) : 0;
+  }
+  int32_t *out = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
+  decode_component(pay + pos, len, p.comp_n[comp], out);
+}
+
+void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
+  vc2_prof_begin(L, "hq_unpack", s);
+  hipLaunchKernelGGL(k_hq_unpack, dim3((p.n_slices * 3 + 63) / 64, n_pictures), dim3(64), 0, s, p);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// slice index: start offset of every slice of a VBR picture payload.
+// The offsets form a serial chain through the length bytes; it is cut into CH-byte chunks:
+//   1. tables : per chunk, for every possible entry offset e, walk the chain to the chunk end
+//               -> (exit offset into the next chunk, slices started)       [parallel in e, chunk]
+//   2. chain  : per picture, follow entry -> exit through the chunk tables  [one lane/picture]
+//   3. emit   : per chunk, walk again from the now-known entry and write the offsets
+// ------------------------------------------------------------------------------------------
+static constexpr int IDX_CH = 32768;
+
+__device__ __forceinline__ int slice_len_lds(const uint8_t *b, int pos, int prefix, int scalar) {
+  int q = pos + prefix + 1;
+  q += 1 + b[q] * scalar;
+  q += 1 + b[q] * scalar;
+  q += 1 + b[q] * scalar;
+  return q - pos;
+}
+
+__device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long plen,
+                            unsigned long long c0, int nbytes) {
+  // nbytes is a multiple of 4; payload slots are 16-byte aligned
+  for (int i = threadIdx.x * 4; i < nbytes; i += blockDim.x * 4) {
+    unsigned v = 0;
+    const unsigned long long a = c0 + i;
+    if (a + 4 <= plen) v = *(const unsigned *)(pay + a);
+    else for (int k = 0; k < 4; ++k) if (a + k < plen) v |= (unsigned)pay[a + k] << (8 * k);
+    *(unsigned *)(lds + i) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_index_tables(const uint8_t *payload, long long stride,
+                                                      const unsigned long long *lens, uint2 *tables,
+                                                      int n_chunks, int E, int prefix, int scalar) {
+  extern __shared__ uint8_t lds_b[];
+  const int chunk = blockIdx.x, pic = blockIdx.y;
+  const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
+  uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
+  if (c0 >= plen) return;
+  const int nbytes = (IDX_CH + 2 * E + 8 + 3) & ~3;
+  stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    int pos = e, cnt = 0;
+    while (pos < IDX_CH) { pos += slice_len_lds(lds_b, pos, prefix, scalar); ++cnt; }
+    tab[e] = make_uint2((unsigned)(pos - IDX_CH), (unsigned)cnt);
+  }
+}
+
+__global__ void k_index_chain(const unsigned long long *lens, const uint2 *tables, uint2 *entries,
+                              int n_chunks, int E, int n_pictures) {
+  const int pic = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pic >= n_pictures) return;
+  const unsigned long long plen = lens[pic];
+  unsigned entry = 0, base = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    entries[(size_t)pic * n_chunks + c] = make_uint2(entry, base);
+    if ((unsigned long long)c * IDX_CH >= plen) continue;
+    const uint2 t = tables[((size_t)pic * n_chunks + c) * E + entry];
+    entry = t.x;
+    base += t.y;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_index_emit(const uint8_t *payload, long long stride,
+                                                   const unsigned long long *lens, const uint2 *entries,
+                                                   uint32_t *offsets, int n_chunks, int E, int n_slices,
+                                                   int prefix, int scalar, unsigned *err) {
+  extern __shared__ uint8_t lds_b[];
+  const int chunk = blockIdx.x, pic = blockIdx.y;
+  const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
+  if (c0 >= plen) return;
+  const uint2 en = entries[(size_t)pic * n_chunks + chunk];
+  if ((int)en.y >= n_slices || (int)en.x >= IDX_CH) return;
+  const int nbytes = (IDX_CH + E + 8 + 3) & ~3;
+  stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int pos = (int)en.x, k = (int)en.y;
+    while (pos < IDX_CH && k < n_slices) {
+      offsets[(size_t)pic * n_slices + k] = (uint32_t)(c0 + pos);
+      if (c0 + pos >= plen) atomicOr(err, VC2_DEVERR_STREAM);
+      pos += slice_len_lds(lds_b, pos, prefix, scalar);
+      ++k;
+    }
+  }
+}
+
+static int idx_entries(int prefix, int scalar) { return prefix + 4 + 3 * 255 * scalar; }
+
+size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix, int scalar) {
+  const size_t n_chunks = (max_payload + IDX_CH - 1) / IDX_CH + 1;
+  const size_t E = idx_entries(prefix, scalar);
+  return (size_t)n_pictures * n_chunks * (E + 1) * sizeof(uint2) + 256;
+}
+
+void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
+                            const unsigned long long *lens, uint32_t *offsets, int n_slices,
+                            int prefix, int scalar, int n_pictures, unsigned *err, hipStream_t s,
+                            void *workspace, size_t workspace_bytes) {
+  const int E = idx_entries(prefix, scalar);
+  // chunk count is bounded by the payload slot size (lens live on the device)
+  const int n_chunks = (int)(((size_t)payload_stride + IDX_CH - 1) / IDX_CH) + 1;
+  uint2 *tables = (uint2 *)workspace;
+  uint2 *entries = tables + (size_t)n_pictures * n_chunks * E;
+  (void)workspace_bytes;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)k_index_tables, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_index_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  vc2_prof_begin(L, "slice_index_tables", s);
+  hipLaunchKernelGGL(k_index_tables, dim3(n_chunks, n_pictures), dim3(256), (size_t)((IDX_CH + 2 * E + 8 + 3) & ~3), s,
+                     payload, payload_stride, lens, tables, n_chunks, E, prefix, scalar);
+  vc2_prof_end(L, s);
+  vc2_prof_begin(L, "slice_index_chain", s);
+  hipLaunchKernelGGL(k_index_chain, dim3((n_pictures + 63) / 64), dim3(64), 0, s, lens, tables, entries, n_chunks, E, n_pictures);
+  vc2_prof_end(L, s);
+  vc2_prof_begin(L, "slice_index_emit", s);
+  hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(64), (size_t)((IDX_CH + E + 8 + 3) & ~3), s, payload,
+                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// LD slices (decode only): one lane per slice, bit-serial (legacy profile, cfg 5)
+// ------------------------------------------------------------------------------------------
+struct SerialBits { // VLC.cpp:182-202 on a memory buffer
+  const uint8_t *p;
+  int nbytes, bitpos, bounded, left;
+  __device__ __forceinline__ int get() {
+    if (bounded && left < 1) return 1;
+    const int by = bitpos >> 3;
+    const int b = by < nbytes ? (p[by] >> (7 - (bitpos & 7))) & 1 : 1;
+    ++bitpos;
+    --left;
+    return b;
+  }
+  __device__ __forceinline__ unsigned bits(int n) { unsigned v = 0; while (n-- > 0) v = (v << 1) | (unsigned)get(); return v; }
+  __device__ __forceinline__ int svlc() {
+    unsigned value = 1;
+    while (!get()) value = (value << 1) | (unsigned)get();
+    value -= 1u;
+    if (!value) return 0;
+    return get() ? (int)(0u - value) : (int)value;
+  }
+  __device__ __forceinline__ void bound(int n) { bounded = 1; left = n; }
+  __device__ __forceinline__ void flush() { if (bounded) { if (left > 0) bitpos += left; left = 0; } }
+};
+
+__device__ __forceinline__ int intlog2_dev(int value) { int l = 0; --value; while (value > 0) { value >>= 1; ++l; } return l; }
+
+__global__ __launch_bounds__(64) void k_ld_unpack(const LdUnpackParams p) {
+  const int slice = blockIdx.x * 64 + threadIdx.x, pic = blockIdx.y;
+  if (slice >= p.n_slices) return;
+  const int size = p.slice_bytes[slice];
+  SerialBits br{p.payload + (size_t)pic * p.payload_stride + p.offsets[slice], size, 0, 0, 0};
+  p.qidx[(size_t)pic * p.n_slices + slice] = (int)br.bits(7);
+  const int split = intlog2_dev(8 * size - 7);
+  const int ybits = (int)br.bits(split);
+  const int uvbits = 8 * size - 7 - split - ybits;
+  int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  br.bound(ybits);
+  for (int j = 0; j < p.comp_n[0]; ++j) rec[p.comp_off[0] + j] = br.svlc();
+  br.flush();
+  br.bound(uvbits);
+  for (int j = 0; j < p.comp_n[1]; ++j) {
+    rec[p.comp_off[1] + j] = br.svlc();
+    rec[p.comp_off[2] + j] = br.svlc();
+  }
+}
+
+void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s) {
+  vc2_prof_begin(L, "ld_unpack", s);
+  hipLaunchKernelGGL(k_ld_unpack, dim3((p.n_slices + 63) / 64, n_pictures), dim3(64), 0, s, p);
+  vc2_prof_end(L, s);
+}
+
+// LL band with DC prediction: anti-diagonal wavefront, one workgroup per (picture).
+// restored(y,x) = scale(q(y,x), aq(slice of (y,x))) + predictDC(restored, y, x)
+__global__ __launch_bounds__(1024) void k_ld_ll(const int32_t *store, long long store_stride,
+                                                int slice_coefs, int coef_off, int n0, int llh, int llw,
+                                                int ys, int xs, const int32_t *qidx, int qm0,
+                                                int32_t *ll_plane, long long ll_stride, unsigned *err) {
+  const int pic = blockIdx.x;
+  const int32_t *st = store + (size_t)pic * store_stride;
+  const int32_t *qi = qidx + (size_t)pic * ys * xs;
+  int32_t *ll = ll_plane + (size_t)pic * ll_stride;
+  const int bh = llh / ys, bw = llw / xs; // LL block of one slice (bh*bw == n0)
+  (void)n0;
+  for (int d = 0; d < llh + llw - 1; ++d) {
+    const int ylo = max(0, d - (llw - 1)), yhi = min(llh - 1, d);
+    for (int y = ylo + (int)threadIdx.x; y <= yhi; y += blockDim.x) {
+      const int x = d - y;
+      const int sv = y / bh, sh = x / bw;
+      const int qv = st[(size_t)(sv * xs + sh) * slice_coefs + coef_off + (y - sv * bh) * bw + (x - sh * bw)];
+      // slice whose index quantises this LL sample: Quantisation.cpp:298-299
+      const int yb = ((y + 1) * ys - 1) / llh, xb = ((x + 1) * xs - 1) / llw;
+      const int aq = max(qi[yb * xs + xb] - qm0, 0);
+      if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
+      int pred;
+      if (y > 0 && x > 0) {
+        const int r = ll[(size_t)(y - 1) * llw + x - 1] + ll[(size_t)(y - 1) * llw + x] + ll[(size_t)y * llw + x - 1];
+        pred = r >= 0 ? (r + 1) / 3 : (r - 1) / 3;
+      } else if (y > 0) pred = ll[(size_t)(y - 1) * llw + x];
+      else if (x > 0) pred = ll[(size_t)y * llw + x - 1];
+      else pred = 0;
+      ll[(size_t)y * llw + x] = scale_dev(qv, min(aq, 119)) + pred;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride, int slice_coefs,
+                      int coef_off, int n0, int llh, int llw, int ys, int xs, const int32_t *qidx,
+                      int qm0, int32_t *ll_plane, long long ll_stride, int n_pictures, unsigned *err,
+                      hipStream_t s) {
+  vc2_prof_begin(L, "ld_ll_predict", s);
+  hipLaunchKernelGGL(k_ld_ll, dim3(n_pictures), dim3(1024), 0, s, store, store_stride, slice_coefs, coef_off, n0,
+                     llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// layout conversion + stand-alone (de)quantisation for the fine-grained API
+// ------------------------------------------------------------------------------------------
+// index of in-place plane position (yy,xx) of a slice tile inside the component record
+__device__ __forceinline__ int record_index(int yy, int xx, int sh, int sw, int depth, int *band_out) {
+  const int D = depth;
+  const int a = yy ? __ffs(yy) - 1 : 31, b = xx ? __ffs(xx) - 1 : 31;
+  const int m = min(a, b);
+  const int n0 = (sh >> D) * (sw >> D);
+  if (m >= D) { *band_out = 0; return (yy >> D) * (sw >> D) + (xx >> D); }
+  const int Lv = D - m, s = 1 << (m + 1);
+  const int kind = (a > m) ? 0 : (b > m ? 1 : 2);
+  const int band = 3 * (Lv - 1) + 1 + kind;
+  *band_out = band;
+  return band_offset(n0, band) + (yy / s) * (sw / s) + (xx / s);
+}
+
+__global__ void k_plane_to_store(const int32_t *plane, int ph, int pw, int depth, int ys, int xs,
+                                 int32_t *store, int slice_coefs, int coef_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)ph * pw) return;
+  const int y = (int)(i / pw), x = (int)(i % pw);
+  const int sh = ph / ys, sw = pw / xs;
+  const int sv = y / sh, shh = x / sw;
+  int band;
+  const int idx = record_index(y - sv * sh, x - shh * sw, sh, sw, depth, &band);
+  store[(size_t)(sv * xs + shh) * slice_coefs + coef_off + idx] = plane[i];
+}
+
+__global__ void k_store_to_plane(const int32_t *store, int slice_coefs, int coef_off, int32_t *plane,
+                                 int ph, int pw, int depth, int ys, int xs, const int32_t *qidx,
+                                 const int *qmatrix, int mode, unsigned *err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)ph * pw) return;
+  const int y = (int)(i / pw), x = (int)(i % pw);
+  const int sh = ph / ys, sw = pw / xs;
+  const int sv = y / sh, shh = x / sw;
+  int band;
+  const int idx = record_index(y - sv * sh, x - shh * sw, sh, sw, depth, &band);
+  int v = store[(size_t)(sv * xs + shh) * slice_coefs + coef_off + idx];
+  if (mode == 1) {
+    const int aq = max(qidx[sv * xs + shh] - qmatrix[band], 0);
+    if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
+    v = scale_dev(v, min(aq, 119));
+  }
+  plane[i] = v;
+}
+
+__global__ void k_quantise_store(int32_t *store, int n_slices, int slice_coefs, int comp_n, int comp_off,
+                                 int n0, const int32_t *qidx, const int *qmatrix, unsigned *err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_slices * comp_n) return;
+  const int slice = (int)(i / comp_n), j = (int)(i % comp_n);
+  const int aq = max(qidx[slice] - qmatrix[band_of_index(j, n0)], 0);
+  int32_t *p = &store[(size_t)slice * slice_coefs + comp_off + j];
+  if (aq > 119) { atomicOr(err, VC2_DEVERR_QINDEX); return; }
+  *p = quant_dev(*p, aq);
+}
+
+void vc2_launch_plane_to_store(Launcher &L, const int32_t *plane, int ph, int pw, int depth, int ys,
+                               int xs, int32_t *store, int slice_coefs, int coef_off, hipStream_t s) {
+  const size_t n = (size_t)ph * pw;
+  vc2_prof_begin(L, "plane_to_store", s);
+  hipLaunchKernelGGL(k_plane_to_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, plane, ph, pw, depth, ys, xs,
+                     store, slice_coefs, coef_off);
+  vc2_prof_end(L, s);
+}
+void vc2_launch_store_to_plane(Launcher &L, const int32_t *store, int slice_coefs, int coef_off,
+                               int32_t *plane, int ph, int pw, int depth, int ys, int xs,
+                               const int32_t *qidx, const int *qmatrix, int mode, unsigned *err,
+                               hipStream_t s) {
+  const size_t n = (size_t)ph * pw;
+  vc2_prof_begin(L, "store_to_plane", s);
+  hipLaunchKernelGGL(k_store_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, store, slice_coefs, coef_off,
+                     plane, ph, pw, depth, ys, xs, qidx, qmatrix, mode, err);
+  vc2_prof_end(L, s);
+}
+void vc2_launch_quantise_store(Launcher &L, int32_t *store, int n_slices, int slice_coefs, int comp_n,
+                               int comp_off, int n0, const int32_t *qidx, const int *qmatrix,
+                               unsigned *err, hipStream_t s) {
+  const size_t n = (size_t)n_slices * comp_n;
+  vc2_prof_begin(L, "quantise_store", s);
+  hipLaunchKernelGGL(k_quantise_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, store, n_slices, slice_coefs,
+                     comp_n, comp_off, n0, qidx, qmatrix, err);
+  vc2_prof_end(L, s);
+}
+
+__global__ void k_fill_i32(int32_t *p, int32_t v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_u64(unsigned long long *p, unsigned long long v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s) {
+  vc2_prof_begin(L, "fill", s);
+  hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+  vc2_prof_end(L, s);
+}
+void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s) {
+  vc2_prof_begin(L, "fill", s);
+  hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+  vc2_prof_end(L, s);
+}
