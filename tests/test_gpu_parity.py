@@ -208,11 +208,12 @@ def test_encode_picture_constq_all_kernels(hip, oracle, kernel):
 
 @pytest.mark.parametrize("cf,bits,word_bytes", [("444", 12, 2), ("420", 8, 1), ("422", 16, 2), ("420", 10, 2)])
 def test_encode_decode_formats_and_padding(hip, oracle, cf, bits, word_bytes):
-    w, h, depth = 176, 100, 2        # 100 is not a multiple of 4*... -> padded planes
+    w, h, depth = 174, 126, 2        # pads to 176 x 128 (chroma 87 -> 88, 63 -> 64)
     raw = synth(w, h, cf, bits, 43, word_bytes=word_bytes)
-    p = make_params(w, h, cf, bits, "DD97", depth, 2, 2, q=5, scalar=4, word_bytes=word_bytes)
+    q = 5 if bits < 16 else 30   # 16-bit: keep |quantised| <= 65534 (the reference's VLC domain)
+    p = make_params(w, h, cf, bits, "DD97", depth, 2, 2, q=q, scalar=4, word_bytes=word_bytes)
     stream, dec = _oracle_payload(oracle, p, raw)
-    fmt, cp = _fmt_cp(hip, w, h, cf, bits, "DD97", depth, 2, 2, q=5, scalar=4, word_bytes=word_bytes)
+    fmt, cp = _fmt_cp(hip, w, h, cf, bits, "DD97", depth, 2, 2, q=q, scalar=4, word_bytes=word_bytes)
     payload, _ = hip.encode_picture_hq(raw, fmt, cp)
     assert payload == stream[-13 - len(payload):-13]
     assert hip.decode_picture(payload, fmt, cp) == dec

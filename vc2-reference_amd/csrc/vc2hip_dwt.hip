@@ -293,8 +293,9 @@ __global__ __launch_bounds__(256) void k_inv_level(const LevelParams p) {
 
   // ---- inverse lifting: vertical on every window column, then horizontal on the core rows
   run_steps<K, true, false>(w, ky_base, npy, 0, w.wxp);
-  // horizontal pass only needs the core rows; running it on all rows keeps the code uniform
-  run_steps<K, true, true>(w, kx_base, npx, HX / 2, HX / 2 + TX / 2);
+  // the horizontal pass lifts along x, so it must cover the whole window width (the second step
+  // reads first-step results in the halo columns); only the core rows are consumed afterwards
+  run_steps<K, true, true>(w, kx_base, npx, 0, w.wxp);
 
   // ---- interleave, round, and write (FINAL: clip + offset + justify + big-endian words)
   const int lim_h = FINAL ? p.pic_h[comp] : out_h, lim_w = FINAL ? p.pic_w[comp] : out_w;

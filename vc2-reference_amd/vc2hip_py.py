@@ -57,6 +57,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever copy is loaded first serves the whole
+    # process, and torch cannot initialise on top of the system runtime.  Let torch win when present.
+    if os.environ.get("VC2HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.vc2hip_create.argtypes = [C.c_int, C.POINTER(vp)]
