@@ -57,6 +57,20 @@ def test_dwt_large_plane_all_tiles(hip, oracle):
         assert np.array_equal(hip.dwt_inverse(c, KERNELS[name], 4, plane.shape), plane), name
 
 
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_dwt_fast_path_all_kernels(hip, oracle, kernel):
+    # planes larger than the 64 x 128 register-blocked tile (ragged: 200 x 264, 136 x 392), every
+    # wavelet, both directions; deeper levels fall back to the generic kernel (mixed pipeline)
+    rng = np.random.default_rng(15)
+    for shape, depth in (((200, 264), 3), ((136, 392), 2), ((64, 128), 1)):
+        plane = rng.integers(-2048, 2048, size=shape).astype(np.int32)
+        c = oracle.dwt_forward(plane, KERNELS[kernel], depth)
+        assert np.array_equal(hip.dwt_forward(plane, KERNELS[kernel], depth), c), (kernel, shape)
+        coef = rng.integers(-5000, 5000, size=c.shape).astype(np.int32)
+        want = oracle.dwt_inverse(coef, KERNELS[kernel], depth, shape)
+        assert np.array_equal(hip.dwt_inverse(coef, KERNELS[kernel], depth, shape), want), (kernel, shape)
+
+
 def test_quantise_dequantise_match_oracle(hip, oracle):
     rng = np.random.default_rng(14)
     depth, ys, xs = 3, 4, 5

@@ -14,6 +14,10 @@
 void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s);
 int vc2_halo_x(int kernel);
 int vc2_halo_y(int kernel);
+void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
+bool vc2_fast_level_applicable(LevelParams &p);
+int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, hipStream_t s);
+int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, hipStream_t s);
 void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s);
 void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 
@@ -84,6 +88,7 @@ struct vc2hip_ctx {
   // cached CBR / LD slice-size tables (re-uploaded only when the parameters change)
   int cbr_key[5] = {-1, -1, -1, -1, -1};
   uint64_t cbr_total = 0;
+  bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
 };
 
 static const char *code_text(int code) {
@@ -200,6 +205,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VC2HIP_EHIP;
   vc2hip_ctx *c = new vc2hip_ctx;
   c->device = device;
+  { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
   c->stream = stream;
@@ -211,6 +217,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   make_tables(t);
   vc2_upload_tables(t, c->stream);
   vc2_upload_tables_slices(t, c->stream);
+  vc2_upload_tables_fast(t, c->stream);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   *out = c;
   return VC2HIP_OK;
@@ -417,6 +424,12 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
       p.sample_shift = 8 * f->word_bytes - f->bit_depth;
       p.sample_offset = 1 << (f->bit_depth - 1);
     }
+    LevelParams pf = p;
+    if (!c->force_generic && vc2_fast_level_applicable(pf)) {
+      int rc = vc2_launch_forward_fast(c->L, kernel, first, pf, n, c->stream);
+      if (rc) return set_err(c, rc, "invalid wavelet kernel");
+      continue;
+    }
     if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for one LDS tile");
     int rc = vc2_launch_forward_level(c->L, kernel, first, p, n, c->stream);
     if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -447,6 +460,12 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, int32_t 
       p.sample_offset = 1 << (f->bit_depth - 1);
       p.clip_lo = -(1 << (f->bit_depth - 1));
       p.clip_hi = (1 << (f->bit_depth - 1)) - 1;
+    }
+    LevelParams pf = p;
+    if (!c->force_generic && vc2_fast_level_applicable(pf)) {
+      int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, c->stream);
+      if (rc) return set_err(c, rc, "invalid wavelet kernel");
+      continue;
     }
     if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for one LDS tile");
     int rc = vc2_launch_inverse_level(c->L, kernel, fin, p, n, c->stream);

@@ -1,0 +1,513 @@
+// Register-blocked DWT / IDWT level kernels (the hot configuration of the generic kernels in
+// vc2hip_dwt.hip; same reference semantics, same LevelParams).
+//
+// Tile = 64 x 128 samples of whole slices, anchored inside the plane (the last tile of a row /
+// column is shifted back so its core never crosses the plane edge; overlapping cores write
+// identical values).  Differences from the generic kernel:
+//   * all tile geometry is compile-time (no integer divisions in the inner loops)
+//   * 16-byte global loads / stores; 16-byte LDS accesses (ds_read_b128 / ds_write_b128)
+//   * each lifting PASS (all steps of one direction) runs in registers: a thread loads a run of
+//     4 coefficient pairs plus its halo from the parity planes, applies every step, and writes the
+//     4 results after one barrier -- 2 LDS round trips per pass instead of one per tap
+//   * plane-edge tap clamping = replication of the edge pair inside the register window
+#include <algorithm>
+
+#include "vc2hip_internal.h"
+#include "vc2hip_wavelets.h"
+
+void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
+void vc2_prof_end(Launcher &L, hipStream_t s);
+
+__constant__ QuantTables c_qd;
+void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s) {
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_qd), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
+}
+
+namespace {
+
+constexpr int TY = 64, TX = 128, NT = 256;
+
+struct I4 {
+  int x, y, z, w;
+};
+__device__ __forceinline__ I4 operator+(I4 a, I4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ I4 operator-(I4 a, I4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ I4 operator-(I4 a) { return {-a.x, -a.y, -a.z, -a.w}; }
+__device__ __forceinline__ I4 operator+(I4 a, int b) { return {a.x + b, a.y + b, a.z + b, a.w + b}; }
+__device__ __forceinline__ I4 operator*(int s, I4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+__device__ __forceinline__ I4 operator>>(I4 a, int s) { return {a.x >> s, a.y >> s, a.z >> s, a.w >> s}; }
+__device__ __forceinline__ I4 &operator+=(I4 &a, I4 b) { a = a + b; return a; }
+__device__ __forceinline__ I4 &operator-=(I4 &a, I4 b) { a = a - b; return a; }
+
+__device__ __forceinline__ I4 lds_ld4(const int *p) { const int4 v = *(const int4 *)p; return {v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void lds_st4(int *p, I4 v) { *(int4 *)p = make_int4(v.x, v.y, v.z, v.w); }
+
+template <int K> struct Cfg {
+  static constexpr int HY = halo_y<K>(), HX = halo_x<K>();
+  static constexpr int WY = TY + 2 * HY, WX = TX + 2 * HX, WYP = WY / 2, WXP = WX / 2;
+  static constexpr int PADQ = HX / 8;        // halo quads (of pairs) per side, horizontal runs
+  static constexpr int NWH = 4 + 8 * PADQ;   // register window of a horizontal run (pairs)
+  static constexpr int PADV = HY / 2;        // halo pairs per side, vertical runs
+  static constexpr int NWV = 4 + 2 * PADV;
+  static constexpr int PLANE = WYP * WXP;    // ints per parity plane
+  static constexpr size_t LDS = (size_t)4 * PLANE * 4;
+};
+
+// one lifting step on a register window; E / O are the even / odd parity values of NW pairs
+template <int K, int S, bool INV, int NW, class T>
+__device__ __forceinline__ void reg_step(T (&E)[NW], T (&O)[NW]) {
+  constexpr bool odd = step_targets_odd<K, S>();
+  constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    if (i + dmin >= 0 && i + dmax < NW) {
+      auto at = [&](int d) -> T { return odd ? E[i + d] : O[i + d]; };
+      const T dlt = lift_delta<K, S>(at);
+      if constexpr (odd) { if (INV) O[i] -= dlt; else O[i] += dlt; }
+      else { if (INV) E[i] -= dlt; else E[i] += dlt; }
+    }
+  }
+}
+// replicate the plane-edge pair into the out-of-plane part of the window (tap clamping)
+template <int NW, class T> __device__ __forceinline__ void replicate(T (&A)[NW], int nl, int nr) {
+#pragma unroll
+  for (int i = NW - 2; i >= 0; --i) if (i < nl) A[i] = A[i + 1];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) if (i > nr) A[i] = A[i - 1];
+}
+template <int K, int S, bool INV, int NW, class T>
+__device__ __forceinline__ void reg_step_edge(T (&E)[NW], T (&O)[NW], bool edge, int nl, int nr) {
+  reg_step<K, S, INV>(E, O);
+  if (edge) { if (step_targets_odd<K, S>()) replicate(O, nl, nr); else replicate(E, nl, nr); }
+}
+template <int K, bool INV, int NW, class T>
+__device__ __forceinline__ void reg_pass(T (&E)[NW], T (&O)[NW], bool edge, int nl, int nr) {
+  if (edge) { replicate(E, nl, nr); replicate(O, nl, nr); }
+  constexpr int N = WT<K>::nsteps;
+  if constexpr (!INV) {
+    reg_step_edge<K, 0, false>(E, O, edge, nl, nr);
+    reg_step_edge<K, 1, false>(E, O, edge, nl, nr);
+    if constexpr (N == 4) { reg_step_edge<K, 2, false>(E, O, edge, nl, nr); reg_step_edge<K, 3, false>(E, O, edge, nl, nr); }
+  } else {
+    if constexpr (N == 4) { reg_step_edge<K, 3, true>(E, O, edge, nl, nr); reg_step_edge<K, 2, true>(E, O, edge, nl, nr); }
+    reg_step_edge<K, 1, true>(E, O, edge, nl, nr);
+    reg_step_edge<K, 0, true>(E, O, edge, nl, nr);
+  }
+}
+
+// horizontal pass over rows [row_lo, row_hi) of both row parities, core columns only.
+// NIT = iterations of 256 threads; results are held in registers across the barrier.
+template <int K, bool INV, int NIT>
+__device__ __forceinline__ void h_pass(int *lds, int row_lo, int n_rows, int kx_base, int npx) {
+  using C = Cfg<K>;
+  constexpr int NW = C::NWH, P = 4 * C::PADQ;
+  I4 re[NIT], ro[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = it * NT + threadIdx.x;
+    if (id < n_rows * 16) {
+      const int rr = row_lo + (id >> 4), t = id & 15; // rr indexes rows of the (2*WYP)-row stack
+      const int j0 = C::HX / 2 + 4 * t;
+      const int *erow = lds + (rr / C::WYP * 2 + 0) * C::PLANE + (rr % C::WYP) * C::WXP + j0 - P;
+      const int *orow = erow + C::PLANE;
+      int E[NW], O[NW];
+#pragma unroll
+      for (int q = 0; q < NW / 4; ++q) {
+        const I4 a = lds_ld4(erow + 4 * q), b = lds_ld4(orow + 4 * q);
+        E[4 * q] = a.x; E[4 * q + 1] = a.y; E[4 * q + 2] = a.z; E[4 * q + 3] = a.w;
+        O[4 * q] = b.x; O[4 * q + 1] = b.y; O[4 * q + 2] = b.z; O[4 * q + 3] = b.w;
+      }
+      const int k0 = kx_base + j0 - P; // plane pair index of window entry 0
+      const int nl = -k0, nr = npx - 1 - k0;
+      reg_pass<K, INV>(E, O, nl > 0 || nr < NW - 1, nl, nr);
+      re[it] = {E[P], E[P + 1], E[P + 2], E[P + 3]};
+      ro[it] = {O[P], O[P + 1], O[P + 2], O[P + 3]};
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = it * NT + threadIdx.x;
+    if (id < n_rows * 16) {
+      const int rr = row_lo + (id >> 4), t = id & 15;
+      int *erow = lds + (rr / C::WYP * 2 + 0) * C::PLANE + (rr % C::WYP) * C::WXP + C::HX / 2 + 4 * t;
+      lds_st4(erow, re[it]);
+      lds_st4(erow + C::PLANE, ro[it]);
+    }
+  }
+  __syncthreads();
+}
+
+// vertical pass over the core row pairs, column quads [cq_lo, cq_lo + n_cq) of both column parities
+template <int K, bool INV, int NIT>
+__device__ __forceinline__ void v_pass(int *lds, int cq_lo, int n_cq, int ky_base, int npy) {
+  using C = Cfg<K>;
+  constexpr int NW = C::NWV, P = C::PADV;
+  I4 re[NIT][4], ro[NIT][4];
+  const int items = n_cq * 2 * (TY / 8);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = it * NT + threadIdx.x;
+    if (id < items) {
+      const int cq = cq_lo + id % n_cq, rest = id / n_cq;
+      const int cp = rest & 1, rr = rest >> 1;
+      const int i0 = C::HY / 2 + 4 * rr;
+      const int *ep = lds + (0 * 2 + cp) * C::PLANE + (i0 - P) * C::WXP + 4 * cq;
+      const int *op = ep + 2 * C::PLANE;
+      I4 E[NW], O[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { E[k] = lds_ld4(ep + k * C::WXP); O[k] = lds_ld4(op + k * C::WXP); }
+      const int k0 = ky_base + i0 - P;
+      const int nl = -k0, nr = npy - 1 - k0;
+      reg_pass<K, INV>(E, O, nl > 0 || nr < NW - 1, nl, nr);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { re[it][k] = E[P + k]; ro[it][k] = O[P + k]; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = it * NT + threadIdx.x;
+    if (id < items) {
+      const int cq = cq_lo + id % n_cq, rest = id / n_cq;
+      const int cp = rest & 1, rr = rest >> 1;
+      const int i0 = C::HY / 2 + 4 * rr;
+      int *ep = lds + (0 * 2 + cp) * C::PLANE + i0 * C::WXP + 4 * cq;
+      int *op = ep + 2 * C::PLANE;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { lds_st4(ep + k * C::WXP, re[it][k]); lds_st4(op + k * C::WXP, ro[it][k]); }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int dequant_f(int v, int qf, int off) {
+  if (v == 0) return 0;
+  const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+  int a = (int)(mag * (unsigned)qf);
+  if (a > 0) a = (int)((unsigned)a + (unsigned)off);
+  a = (int)((unsigned)a + 2u);
+  a /= 4;
+  return v < 0 ? (int)(0u - (unsigned)a) : a;
+}
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+// ------------------------------------------------------------------------------------------
+// forward level
+// ------------------------------------------------------------------------------------------
+template <int K, bool FIRST>
+__global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
+  using C = Cfg<K>;
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
+  if ((int)blockIdx.x >= p.tiles_x[comp] || (int)blockIdx.y >= p.tiles_y[comp]) return;
+  constexpr int HY = C::HY, HX = C::HX, WX = C::WX, WY = C::WY, WXP = C::WXP, ACC = WT<K>::accuracy;
+  const int in_h = p.in_h[comp], in_w = p.in_w[comp];
+  const int y0 = min((int)blockIdx.y * TY, in_h - TY), x0 = min((int)blockIdx.x * TX, in_w - TX);
+
+  // ---- stage tile + halo: 8 samples per item, split into even / odd column planes
+  {
+    const int pic_h = p.pic_h[comp], pic_w = p.pic_w[comp];
+    const bool vec_ok = FIRST ? (p.word_bytes == 2 && (pic_w & 7) == 0) : ((in_w & 3) == 0);
+    for (int id = threadIdx.x; id < WY * (WX / 8); id += NT) {
+      const int r = id / (WX / 8), ch = id - r * (WX / 8);
+      const int gy = y0 - HY + r, gx0 = x0 - HX + 8 * ch;
+      if (gy < 0 || gy >= in_h || gx0 + 8 <= 0 || gx0 >= in_w) continue;
+      int s[8];
+      if constexpr (FIRST) {
+        const int sy = min(gy, pic_h - 1);
+        const uint8_t *row = (const uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] +
+                             (size_t)sy * pic_w * p.word_bytes;
+        if (vec_ok && gx0 >= 0 && gx0 + 8 <= pic_w) {
+          const uint4 v = *(const uint4 *)(row + (size_t)gx0 * 2);
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const unsigned b = __builtin_bswap32(wv[k]);
+            s[2 * k] = (int)(b >> 16);
+            s[2 * k + 1] = (int)(b & 0xFFFFu);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int sx = min(max(gx0 + k, 0), pic_w - 1);
+            const uint8_t *q = row + (size_t)sx * p.word_bytes;
+            unsigned u = 0;
+            for (int b = 0; b < p.word_bytes; ++b) u = (u << 8) | q[b];
+            s[k] = (int)u;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = (int)((unsigned)((int)((unsigned)s[k] >> p.sample_shift) - p.sample_offset) << ACC);
+      } else {
+        const int32_t *row = (const int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w;
+        if (vec_ok && gx0 >= 0 && gx0 + 8 <= in_w) {
+          const int4 a = *(const int4 *)(row + gx0), b = *(const int4 *)(row + gx0 + 4);
+          s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s[k] = row[min(max(gx0 + k, 0), in_w - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = (int)((unsigned)s[k] << ACC);
+      }
+      int *e = lds + ((r & 1) * 2 + 0) * C::PLANE + (r >> 1) * WXP + 4 * ch;
+      lds_st4(e, {s[0], s[2], s[4], s[6]});
+      lds_st4(e + C::PLANE, {s[1], s[3], s[5], s[7]});
+    }
+  }
+  __syncthreads();
+
+  // ---- lifting in registers: horizontal over all in-plane window rows, vertical over the core
+  {
+    // window rows gy in [0,in_h): stack index rr = rp*WYP + i, row r = 2*i + rp.  Rows outside the
+    // plane are skipped (the vertical pass replicates across the plane edge itself).
+    constexpr int NITH = (2 * C::WYP * 16 + NT - 1) / NT;
+    h_pass<K, false, NITH>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
+    v_pass<K, false, 1>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+  }
+
+  // ---- write the four bands of the core
+  const int fh = p.fh[comp], fw = p.fw[comp];
+  const int bsh = fh >> 1, bsw = fw >> 1;
+  const int lbsw = ilog2(bsw), lblk = ilog2(bsh) + lbsw;
+  const int tsx_l = ilog2(TX / fw);           // slices per tile row (log2)
+  const int s_y0 = y0 / fh, s_x0 = x0 / fw;
+  int32_t *store = p.store + (size_t)pic * p.store_stride;
+  const int *core = lds + (HY / 2) * WXP + HX / 2;
+#pragma unroll 1
+  for (int band = 0; band < 4; ++band) {
+    const int *src = core + band * C::PLANE;
+    if (band == 0 && !p.ll_to_store) {
+      int32_t *ll = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+      const int ow = in_w >> 1;
+      const bool v4 = (ow & 3) == 0;
+      for (int id = threadIdx.x; id < (TY / 2) * (TX / 8); id += NT) {
+        const int i = id >> 4, jq = id & 15;
+        const I4 v = lds_ld4(src + i * WXP + 4 * jq);
+        int32_t *d = ll + (size_t)(y0 / 2 + i) * ow + x0 / 2 + 4 * jq;
+        if (v4) *(int4 *)d = make_int4(v.x, v.y, v.z, v.w);
+        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+      }
+      continue;
+    }
+    const int off = p.coef_off[comp] + (band == 0 ? 0 : p.band_off[comp] * band);
+    if (lbsw >= 2) { // 16-byte stores: a quad never crosses a block row
+      for (int id = threadIdx.x; id < (TY / 2) * (TX / 8); id += NT) {
+        const int e = id << 2;
+        const int s = e >> lblk, rem = e & ((1 << lblk) - 1);
+        const int si = s >> tsx_l, sj = s & ((1 << tsx_l) - 1);
+        const int r = rem >> lbsw, c = rem & (bsw - 1);
+        const I4 v = lds_ld4(src + ((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c);
+        int32_t *d = store + (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem;
+        *(int4 *)d = make_int4(v.x, v.y, v.z, v.w);
+      }
+    } else {
+      for (int e = threadIdx.x; e < (TY / 2) * (TX / 2); e += NT) {
+        const int s = e >> lblk, rem = e & ((1 << lblk) - 1);
+        const int si = s >> tsx_l, sj = s & ((1 << tsx_l) - 1);
+        const int r = rem >> lbsw, c = rem & (bsw - 1);
+        store[(size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem] =
+            src[((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse level
+// ------------------------------------------------------------------------------------------
+template <int K, bool FINAL>
+__global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
+  using C = Cfg<K>;
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
+  if ((int)blockIdx.x >= p.tiles_x[comp] || (int)blockIdx.y >= p.tiles_y[comp]) return;
+  constexpr int HY = C::HY, HX = C::HX, WXP = C::WXP, WYP = C::WYP, ACC = WT<K>::accuracy;
+  const int out_h = p.in_h[comp], out_w = p.in_w[comp];
+  const int y0 = min((int)blockIdx.y * TY, out_h - TY), x0 = min((int)blockIdx.x * TX, out_w - TX);
+  const int npy = out_h >> 1, npx = out_w >> 1;
+  const int ky_base = (y0 - HY) / 2, kx_base = (x0 - HX) / 2;
+  const int fh = p.fh[comp], fw = p.fw[comp];
+  const int bsh = fh >> 1, bsw = fw >> 1;
+  const int lbsh = ilog2(bsh), lbsw = ilog2(bsw);
+  const int32_t *store = p.store + (size_t)pic * p.store_stride;
+  const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * p.xs : nullptr;
+
+  // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in
+#pragma unroll 1
+  for (int band = 0; band < 4; ++band) {
+    int *dst = lds + band * C::PLANE;
+    const bool from_plane = (band == 0 && !p.ll_from_store);
+    const int off = p.coef_off[comp] + (band == 0 ? 0 : p.band_off[comp] * band);
+    const int qm = band == 0 ? p.qmatrix[0] : p.qmatrix[p.band + band - 1];
+    const int32_t *llp = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+    const bool vec = from_plane ? ((npx & 3) == 0) : (lbsw >= 2);
+    for (int id = threadIdx.x; id < WYP * (WXP / 4); id += NT) {
+      const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
+      const int by = ky_base + i, bx0 = kx_base + 4 * jq;
+      if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
+      I4 v;
+      if (from_plane) {
+        const int32_t *row = llp + (size_t)by * npx;
+        if (vec && bx0 >= 0 && bx0 + 4 <= npx) { const int4 t = *(const int4 *)(row + bx0); v = {t.x, t.y, t.z, t.w}; }
+        else v = {row[min(max(bx0, 0), npx - 1)], row[min(max(bx0 + 1, 0), npx - 1)],
+                  row[min(max(bx0 + 2, 0), npx - 1)], row[min(max(bx0 + 3, 0), npx - 1)]};
+      } else {
+        const int sv = by >> lbsh, r = by & (bsh - 1);
+        int e[4];
+        if (vec && bx0 >= 0 && bx0 + 4 <= npx) {
+          const int sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
+          const int4 t = *(const int4 *)(store + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c);
+          e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w;
+          if (p.dequant) {
+            const int aq = max(qidx[sv * p.xs + sh] - qm, 0);
+            if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+            const int qf = c_qd.qf[min(aq, 119)], qo = c_qd.off[min(aq, 119)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int bx = min(max(bx0 + k, 0), npx - 1);
+            const int sh = bx >> lbsw, c = bx & (bsw - 1);
+            int t = store[(size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c];
+            if (p.dequant) {
+              const int aq = max(qidx[sv * p.xs + sh] - qm, 0);
+              if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+              t = dequant_f(t, c_qd.qf[min(aq, 119)], c_qd.off[min(aq, 119)]);
+            }
+            e[k] = t;
+          }
+        }
+        v = {e[0], e[1], e[2], e[3]};
+      }
+      lds_st4(dst + i * WXP + 4 * jq, v);
+    }
+  }
+  __syncthreads();
+
+  // ---- inverse lifting in registers: vertical over every window column, horizontal over the core rows
+  {
+    constexpr int NQ = WXP / 4;
+    constexpr int NITV = (NQ * 2 * (TY / 8) + NT - 1) / NT;
+    v_pass<K, true, NITV>(lds, 0, NQ, ky_base, npy);
+    // core rows of both parities: stack rows rp*WYP + HY/2 + [0, TY/2); h_pass takes one contiguous
+    // range, so run it once per row parity
+    constexpr int NITH = ((TY / 2) * 16 + NT - 1) / NT;
+    h_pass<K, true, NITH>(lds, HY / 2, TY / 2, kx_base, npx);
+    h_pass<K, true, NITH>(lds, WYP + HY / 2, TY / 2, kx_base, npx);
+  }
+
+  // ---- interleave, round, write (FINAL: clip + offset + justify + big-endian 16-bit words)
+  const int lim_h = FINAL ? p.pic_h[comp] : out_h, lim_w = FINAL ? p.pic_w[comp] : out_w;
+  const bool vec_out = FINAL ? (p.word_bytes == 2 && (lim_w & 7) == 0) : ((out_w & 3) == 0);
+  for (int id = threadIdx.x; id < TY * (TX / 8); id += NT) {
+    const int r = id >> 4, ch = id & 15;
+    const int gy = y0 + r, gx0 = x0 + 8 * ch;
+    if (gy >= lim_h || gx0 >= lim_w) continue;
+    const int *e = lds + ((r & 1) * 2 + 0) * C::PLANE + ((r + HY) >> 1) * WXP + HX / 2 + 4 * ch;
+    const I4 a = lds_ld4(e), b = lds_ld4(e + C::PLANE);
+    int s[8] = {a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w};
+    if (ACC) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] = (s[k] + (1 << (ACC > 0 ? ACC - 1 : 0))) >> ACC;
+    }
+    if constexpr (FINAL) {
+      uint8_t *row = (uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * lim_w * p.word_bytes;
+      unsigned u[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = (unsigned)(min(max(s[k], p.clip_lo), p.clip_hi) + p.sample_offset) << p.sample_shift;
+      if (vec_out && gx0 + 8 <= lim_w) {
+        unsigned wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv[k] = __builtin_bswap32(((u[2 * k] & 0xFFFFu) << 16) | (u[2 * k + 1] & 0xFFFFu));
+        *(uint4 *)(row + (size_t)gx0 * 2) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      } else {
+        for (int k = 0; k < 8; ++k) {
+          if (gx0 + k >= lim_w) break;
+          uint8_t *q = row + (size_t)(gx0 + k) * p.word_bytes;
+          for (int b2 = 0; b2 < p.word_bytes; ++b2) q[b2] = (uint8_t)(u[k] >> (8 * (p.word_bytes - 1 - b2)));
+        }
+      }
+    } else {
+      int32_t *row = (int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * out_w;
+      if (vec_out) {
+        *(int4 *)(row + gx0) = make_int4(s[0], s[1], s[2], s[3]);
+        *(int4 *)(row + gx0 + 4) = make_int4(s[4], s[5], s[6], s[7]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[gx0 + k] = s[k];
+      }
+    }
+  }
+}
+
+template <int K, bool EDGE, bool INV>
+void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t s) {
+  int gx = 0, gy = 0;
+  for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.tiles_x[c]); gy = std::max(gy, p.tiles_y[c]); }
+  dim3 grid(gx, gy, 3 * n_pictures), block(NT);
+  const size_t lds = Cfg<K>::LDS;
+  if constexpr (INV) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_inv_fast<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
+    hipLaunchKernelGGL((k_inv_fast<K, EDGE>), grid, block, lds, s, p);
+  } else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_fwd_fast<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
+    hipLaunchKernelGGL((k_fwd_fast<K, EDGE>), grid, block, lds, s, p);
+  }
+  vc2_prof_end(L, s);
+}
+
+template <bool INV> int dispatch_fast(Launcher &L, int kernel, bool edge, const LevelParams &p, int n, hipStream_t s) {
+#define VC2_CASE(KK)                                                   \
+  case KK:                                                             \
+    if (edge) launch_fast<KK, true, INV>(L, p, n, s);                  \
+    else launch_fast<KK, false, INV>(L, p, n, s);                      \
+    return 0;
+  switch (kernel) {
+    VC2_CASE(VC2HIP_DD97)
+    VC2_CASE(VC2HIP_LEGALL)
+    VC2_CASE(VC2HIP_DD137)
+    VC2_CASE(VC2HIP_HAAR0)
+    VC2_CASE(VC2HIP_HAAR1)
+    VC2_CASE(VC2HIP_FIDELITY)
+    VC2_CASE(VC2HIP_DAUB97)
+  }
+#undef VC2_CASE
+  return VC2HIP_EINVAL;
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+} // namespace
+
+// The fast kernels apply when every active component has power-of-two slice footprints that divide
+// the 64 x 128 tile and a plane at least one tile large.  Rewrites the tiling fields of p.
+bool vc2_fast_level_applicable(LevelParams &p) {
+  for (int c = 0; c < 3; ++c) {
+    if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
+    if (!pow2(p.fh[c]) || !pow2(p.fw[c]) || p.fh[c] > TY || p.fw[c] > TX || p.fh[c] < 2 || p.fw[c] < 2) return false;
+    if (p.in_h[c] < TY || p.in_w[c] < TX || (p.in_w[c] & 7)) return false;
+  }
+  for (int c = 0; c < 3; ++c) {
+    if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
+    p.tsy[c] = TY / p.fh[c];
+    p.tsx[c] = TX / p.fw[c];
+    p.tiles_y[c] = (p.in_h[c] + TY - 1) / TY;
+    p.tiles_x[c] = (p.in_w[c] + TX - 1) / TX;
+  }
+  return true;
+}
+int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, hipStream_t s) {
+  return dispatch_fast<false>(L, kernel, first, p, n, s);
+}
+int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, hipStream_t s) {
+  return dispatch_fast<true>(L, kernel, final_level, p, n, s);
+}
