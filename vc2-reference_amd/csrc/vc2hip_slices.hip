@@ -436,30 +436,143 @@ __device__ void decode_component(const uint8_t *data, unsigned nbytes, int n, in
   }
 }
 
-__global__ __launch_bounds__(64) void k_hq_unpack(const UnpackParams p) {
-  const int t = blockIdx.x * 64 + threadIdx.x, pic = blockIdx.y;
-  if (t >= p.n_slices * 3) return;
-  const int slice = t / 3, comp = t - slice * 3;
-  const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
-  const unsigned long long plen = p.lens[pic];
-  unsigned long long pos = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
-  auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay[a] : 0u; };
-  if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(pos);
-  pos += 1;
-  for (int c = 0; c < comp; ++c) pos += 1 + (unsigned long long)rd(pos) * p.scalar;
-  unsigned len = rd(pos) * p.scalar;
-  pos += 1;
-  if (pos + len > plen) {
-    atomicOr(p.err, VC2_DEVERR_STREAM);
-    len = pos < plen ? (unsigned)(plen - pos) : 0;
+// Word-wise bounded reader: 32-bit big-endian words, the next word prefetched while the current one
+// is consumed; bytes past the component bound read as 0xFF (VLC.cpp:182-185).
+struct WordReader {
+  const unsigned *w4;  // 4-byte aligned base
+  int lead, len;       // bytes to skip in word 0; bounded length in bytes
+  int k;               // next word index to fetch
+  unsigned nxt;
+  unsigned long long acc;
+  int have;
+  __device__ __forceinline__ unsigned fetch(int idx) const {
+    const int rel = 4 * idx - lead; // byte offset of this word relative to the data start
+    if (rel >= len) return 0xFFFFFFFFu;
+    unsigned v = __builtin_bswap32(w4[idx]);
+    if (rel + 4 > len) v |= 0xFFFFFFFFu >> (8 * (len - rel));
+    return v;
   }
-  int32_t *out = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
-  decode_component(pay + pos, len, p.comp_n[comp], out);
+  __device__ __forceinline__ void init(const uint8_t *data, int nbytes) {
+    const size_t a = (size_t)data;
+    w4 = (const unsigned *)(a & ~(size_t)3);
+    lead = (int)(a & 3);
+    len = nbytes;
+    acc = (unsigned long long)fetch(0) << 32;
+    have = 32;
+    nxt = fetch(1);
+    k = 2;
+    acc <<= 8 * lead;
+    have -= 8 * lead;
+  }
+  __device__ __forceinline__ void refill() { // guarantees have >= 33
+    if (have <= 32) {
+      acc |= (unsigned long long)nxt << (32 - have);
+      have += 32;
+      nxt = fetch(k++);
+    }
+  }
+  __device__ __forceinline__ void skip(int n) { acc = n >= 64 ? 0 : acc << n; have -= n; }
+};
+
+// HQ unpack v2: one lane per slice component, grouped by component type so that all lanes of a
+// wavefront decode the same number of coefficients.  Decoded values are staged 16 per lane in LDS
+// and flushed with 16-byte stores (four lanes cover one component's 64-byte run).
+__global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
+  __shared__ int stage[4][64 * 17];
+  __shared__ unsigned long long outp[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pic = blockIdx.y, comp = blockIdx.z;
+  const int slice = blockIdx.x * 256 + threadIdx.x;
+  const bool active = slice < p.n_slices;
+  const int n = p.comp_n[comp];
+  int *st = stage[wave] + lane * 17;
+  WordReader br;
+  {
+    int32_t *out = nullptr;
+    const uint8_t *data = nullptr;
+    unsigned len = 0;
+    if (active) {
+      const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
+      const unsigned long long plen = p.lens[pic];
+      unsigned long long pos = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
+      auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay[a] : 0u; };
+      if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(pos);
+      pos += 1;
+      for (int c = 0; c < comp; ++c) pos += 1 + (unsigned long long)rd(pos) * p.scalar;
+      len = rd(pos) * p.scalar;
+      pos += 1;
+      if (pos + len > plen) {
+        atomicOr(p.err, VC2_DEVERR_STREAM);
+        len = pos < plen ? (unsigned)(plen - pos) : 0;
+      }
+      data = pay + (pos < plen ? pos : 0);
+      out = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
+    }
+    outp[wave][lane] = (unsigned long long)out;
+    if (active) br.init(data, (int)len); else { br.w4 = nullptr; br.lead = 0; br.len = 0; br.acc = ~0ull; br.have = 64; br.nxt = ~0u; br.k = 0; }
+  }
+  for (int base = 0; base < n; base += 16) {
+    const int room = min(16, n - base);
+    int cnt = 0;
+    while (cnt < room) {
+      br.refill();
+      const int ones = __clzll((long long)~br.acc);
+      if (ones > 0) { // run of '1' bits = run of zero coefficients
+        const int z = min(min(ones, br.have), room - cnt);
+        for (int k = 0; k < z; ++k) st[cnt + k] = 0;
+        cnt += z;
+        br.skip(z);
+        continue;
+      }
+      const unsigned long long follow = br.acc & 0xAAAAAAAAAAAAAAAAull;
+      const int K = follow ? __clzll((long long)follow) / 2 : 32;
+      if (2 * K + 2 <= br.have) {
+        const unsigned long long body = br.acc >> (64 - 2 * K);
+        const unsigned data_bits = (unsigned)compact_odd64(body);
+        const unsigned mag = ((1u << K) | data_bits) - 1u;
+        const int neg = (int)((br.acc >> (62 - 2 * K)) & 1ull);
+        st[cnt++] = neg ? (int)(0u - mag) : (int)mag;
+        br.skip(2 * K + 2);
+      } else { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
+        unsigned value = 1;
+        for (;;) {
+          br.refill();
+          const int f = (int)(br.acc >> 63);
+          br.skip(1);
+          if (f) break;
+          br.refill();
+          value = (value << 1) | (unsigned)(br.acc >> 63);
+          br.skip(1);
+        }
+        value -= 1u;
+        int r = 0;
+        if (value) {
+          br.refill();
+          r = (br.acc >> 63) ? (int)(0u - value) : (int)value;
+          br.skip(1);
+        }
+        st[cnt++] = r;
+      }
+    }
+    // flush: 4 lanes x 16 bytes per component run (trip counts are uniform across the workgroup)
+    __syncthreads();
+    const int *sw = stage[wave];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 16 + (lane >> 2), c = (lane & 3) * 4;
+      int32_t *dst = (int32_t *)outp[wave][r];
+      if (dst && c < room) {
+        const int *q = sw + r * 17 + c;
+        *(int4 *)(dst + base + c) = make_int4(q[0], q[1], q[2], q[3]);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "hq_unpack", s);
-  hipLaunchKernelGGL(k_hq_unpack, dim3((p.n_slices * 3 + 63) / 64, n_pictures), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(k_hq_unpack, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
 
