@@ -87,6 +87,17 @@ def test_quantise_dequantise_match_oracle(hip, oracle):
                               oracle.dequantise_ld(q_want, depth, qidx, qm))
 
 
+def test_quantiser_full_index_range(hip, oracle):
+    # every quantiser index the reference table serves with a positive factor (0..115), large values
+    rng = np.random.default_rng(16)
+    depth, ys, xs = 2, 29, 4
+    coef = rng.integers(-(1 << 28), 1 << 28, size=(ys * 4, xs * 8)).astype(np.int32)
+    coef[::3, ::5] = rng.integers(-40, 40, size=coef[::3, ::5].shape)
+    qidx = np.arange(ys * xs, dtype=np.int32).reshape(ys, xs)
+    qm = np.zeros(7, np.int32)
+    assert np.array_equal(hip.quantise_np(coef, depth, qidx, qm), oracle.quantise_np(coef, depth, qidx, qm))
+
+
 def test_quantiser_index_limit_error(hip, oracle):
     from vc2hip_py import Vc2HipError
     coef = np.ones((16, 16), np.int32)

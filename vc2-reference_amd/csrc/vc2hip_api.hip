@@ -194,6 +194,15 @@ static void make_tables(QuantTables &t) {
     }
     t.qf[q] = (int32_t)(uint32_t)f;
     t.off[q] = q == 0 ? 1 : (q == 1 ? 2 : (int32_t)(((uint32_t)t.qf[q] + 1u)) / 2);
+    t.magic[q] = 0;
+    t.shift[q] = 0;
+    if (t.qf[q] > 1) {
+      const uint64_t d = (uint64_t)t.qf[q];
+      int l = 0;
+      while ((1ull << l) < d) ++l;
+      t.magic[q] = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+      t.shift[q] = l - 1;
+    }
   }
 }
 

@@ -67,6 +67,10 @@ __host__ __device__ inline int band_of_index(int j, int n0) {
 struct QuantTables {
   int32_t qf[120];
   int32_t off[120];
+  // exact unsigned division by qf (Granlund-Montgomery): n / qf = (t + ((n - t) >> 1)) >> (l - 1),
+  // t = mulhi(magic, n); valid for every 32-bit n when qf > 0 (indices 0..115)
+  uint32_t magic[120];
+  int32_t shift[120];
 };
 
 // ------------------------------------------------------------------------------------------

@@ -30,8 +30,20 @@ __device__ __forceinline__ int quant_dev(int v, int aq) {
   const int qf = c_qs.qf[aq];
   const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
   int a = (int)(mag << 2);
-  a /= qf;
+  if (qf > 1 && a >= 0) { // exact reciprocal multiply (the reference's domain); else the literal int division
+    const unsigned n = (unsigned)a, t = __umulhi(c_qs.magic[aq], n);
+    a = (int)((t + ((n - t) >> 1)) >> c_qs.shift[aq]);
+  } else {
+    a /= qf;
+  }
   return v < 0 ? (int)(0u - (unsigned)a) : a;
+}
+// band index of coefficient j when n0 is (usually) a power of two: no integer division
+__device__ __forceinline__ int band_of_index_fast(int j, int n0, int n0_shift) {
+  const int m = n0_shift >= 0 ? (j >> n0_shift) : (j / n0);
+  if (m == 0) return 0;
+  const int L = (31 - __clz(m)) / 2 + 1;
+  return 3 * (L - 1) + (m >> (2 * (L - 1)));
 }
 // Quantisation.cpp:86-95
 __device__ __forceinline__ int scale_dev(int v, int aq) {
@@ -104,6 +116,7 @@ template <bool QUANT, bool WRITE, class Src>
 __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, const int *qm, int lane,
                                               unsigned *bits, int region_bits, unsigned *err) {
   int base = 0, count = 0;
+  const int n0_shift = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
   for (int r0 = 0; r0 < n; r0 += 512) {
     int v[8], nb[8];
     int sum = 0, last_end = 0;
@@ -114,7 +127,7 @@ __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, con
       if (j < n) {
         c = src(j);
         if (QUANT) {
-          const int aq = max(q - qm[band_of_index(j, n0)], 0);
+          const int aq = max(q - qm[band_of_index_fast(j, n0, n0_shift)], 0);
           if (aq > 119) { atomicOr(err, VC2_DEVERR_QINDEX); c = 0; }
           else c = quant_dev(c, aq);
         }
@@ -596,31 +609,79 @@ __device__ __forceinline__ int slice_len_lds(const uint8_t *b, int pos, int pref
 
 __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long plen,
                             unsigned long long c0, int nbytes) {
-  // nbytes is a multiple of 4; payload slots are 16-byte aligned
-  for (int i = threadIdx.x * 4; i < nbytes; i += blockDim.x * 4) {
-    unsigned v = 0;
+  // nbytes is a multiple of 16; payload slots and chunk starts are 16-byte aligned
+  for (int i = threadIdx.x * 16; i < nbytes; i += blockDim.x * 16) {
+    uint4 v = make_uint4(0, 0, 0, 0);
     const unsigned long long a = c0 + i;
-    if (a + 4 <= plen) v = *(const unsigned *)(pay + a);
-    else for (int k = 0; k < 4; ++k) if (a + k < plen) v |= (unsigned)pay[a + k] << (8 * k);
-    *(unsigned *)(lds + i) = v;
+    if (a + 16 <= plen) v = *(const uint4 *)(pay + a);
+    else {
+      unsigned w[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 16; ++k) if (a + k < plen) w[k >> 2] |= (unsigned)pay[a + k] << (8 * (k & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *(uint4 *)(lds + i) = v;
   }
 }
 
+// Per chunk: (exit offset, slices started) for every possible entry offset e in [0, E).
+// All E walkers advance stripe by stripe (stripe width = E = the longest possible slice, so a
+// walker leaving a stripe lands inside the next one).  At every stripe boundary walkers that
+// landed on the same byte are merged -- chains of random-looking length bytes coalesce quickly,
+// so only a handful of walkers survive the first few stripes; merged walkers keep a link
+// (owner, hop difference) that is resolved at the end.
 __global__ __launch_bounds__(256) void k_index_tables(const uint8_t *payload, long long stride,
                                                       const unsigned long long *lens, uint2 *tables,
                                                       int n_chunks, int E, int prefix, int scalar) {
-  extern __shared__ uint8_t lds_b[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
   uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
   if (c0 >= plen) return;
-  const int nbytes = (IDX_CH + 2 * E + 8 + 3) & ~3;
+  const int nbytes = (IDX_CH + E + 16 + 15) & ~15;
+  unsigned short *w_pos = (unsigned short *)(lds_b + nbytes);
+  unsigned short *w_hops = w_pos + E;
+  unsigned short *w_owner = w_hops + E;   // 0xFFFF: alive / survivor, else the walker merged into
+  short *w_delta = (short *)(w_owner + E);
+  unsigned short *z_owner = (unsigned short *)(w_delta + E); // per landing offset: winner id, its hops
+  unsigned short *z_hops = z_owner + E;
+  unsigned *bitmap = (unsigned *)(((size_t)(z_hops + E) + 3) & ~(size_t)3);
+  const int bm_words = (E + 31) / 32;
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
+  for (int e = threadIdx.x; e < E; e += blockDim.x) { w_pos[e] = (unsigned short)e; w_hops[e] = 0; w_owner[e] = 0xFFFF; }
+  for (int i = threadIdx.x; i < bm_words; i += blockDim.x) bitmap[i] = 0;
+  __syncthreads();
+  const int n_stripes = (IDX_CH + E - 1) / E;
+  for (int s = 0; s < n_stripes; ++s) {
+    const int end = min((s + 1) * E, IDX_CH);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      if (w_owner[e] != 0xFFFF) continue;
+      int pos = w_pos[e], hops = w_hops[e];
+      while (pos < end) { pos += slice_len_lds(lds_b, pos, prefix, scalar); ++hops; }
+      w_pos[e] = (unsigned short)pos;
+      w_hops[e] = (unsigned short)hops;
+      if (s + 1 < n_stripes) { // claim the landing byte
+        const int key = pos - end;
+        const unsigned bit = 1u << (key & 31);
+        if (!(atomicOr(&bitmap[key >> 5], bit) & bit)) { z_owner[key] = (unsigned short)e; z_hops[key] = (unsigned short)hops; }
+      }
+    }
+    if (s + 1 == n_stripes) break;
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      if (w_owner[e] != 0xFFFF) continue;
+      const int key = (int)w_pos[e] - end;
+      const int o = z_owner[key];
+      if (o != e) { w_owner[e] = (unsigned short)o; w_delta[e] = (short)((int)w_hops[e] - (int)z_hops[key]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bm_words; i += blockDim.x) bitmap[i] = 0;
+    __syncthreads();
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    int pos = e, cnt = 0;
-    while (pos < IDX_CH) { pos += slice_len_lds(lds_b, pos, prefix, scalar); ++cnt; }
-    tab[e] = make_uint2((unsigned)(pos - IDX_CH), (unsigned)cnt);
+    int cur = e, d = 0;
+    while (w_owner[cur] != 0xFFFF) { d += w_delta[cur]; cur = w_owner[cur]; }
+    tab[e] = make_uint2((unsigned)((int)w_pos[cur] - IDX_CH), (unsigned)((int)w_hops[cur] + d));
   }
 }
 
@@ -639,17 +700,17 @@ __global__ void k_index_chain(const unsigned long long *lens, const uint2 *table
   }
 }
 
-__global__ __launch_bounds__(64) void k_index_emit(const uint8_t *payload, long long stride,
+__global__ __launch_bounds__(256) void k_index_emit(const uint8_t *payload, long long stride,
                                                    const unsigned long long *lens, const uint2 *entries,
                                                    uint32_t *offsets, int n_chunks, int E, int n_slices,
                                                    int prefix, int scalar, unsigned *err) {
-  extern __shared__ uint8_t lds_b[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
   if (c0 >= plen) return;
   const uint2 en = entries[(size_t)pic * n_chunks + chunk];
   if ((int)en.y >= n_slices || (int)en.x >= IDX_CH) return;
-  const int nbytes = (IDX_CH + E + 8 + 3) & ~3;
+  const int nbytes = (IDX_CH + E + 16 + 15) & ~15;
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -688,14 +749,15 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     attr = true;
   }
   vc2_prof_begin(L, "slice_index_tables", s);
-  hipLaunchKernelGGL(k_index_tables, dim3(n_chunks, n_pictures), dim3(256), (size_t)((IDX_CH + 2 * E + 8 + 3) & ~3), s,
+  const size_t lds_tab = (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)E * 12 + 4 * ((E + 31) / 32) + 16;
+  hipLaunchKernelGGL(k_index_tables, dim3(n_chunks, n_pictures), dim3(256), lds_tab, s,
                      payload, payload_stride, lens, tables, n_chunks, E, prefix, scalar);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_chain", s);
   hipLaunchKernelGGL(k_index_chain, dim3((n_pictures + 63) / 64), dim3(64), 0, s, lens, tables, entries, n_chunks, E, n_pictures);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
-  hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(64), (size_t)((IDX_CH + E + 8 + 3) & ~3), s, payload,
+  hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(256), (size_t)((IDX_CH + E + 16 + 15) & ~15), s, payload,
                      payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err);
   vc2_prof_end(L, s);
 }
