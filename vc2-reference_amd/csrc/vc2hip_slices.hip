@@ -157,79 +157,216 @@ __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, con
 }
 
 // ------------------------------------------------------------------------------------------
-// HQ pack: one wavefront per slice
+// HQ pack: one wavefront per slice.  The slice's byte image (prefix, qindex, then per component
+// a length byte + bounded exp-Golomb data, Slices.cpp:469-533 / :305-382) is assembled in LDS as
+// big-endian words and copied out with dword stores.  Each lane owns 8 consecutive coefficients,
+// merges their codes in registers and ORs whole words into the image.
 // ------------------------------------------------------------------------------------------
+struct Coef8 {
+  int v[8], nb[8];
+  int sum, last_end;
+};
+
+// load (and quantise) the 8 coefficients [j0, j0+8) of a component record
+template <bool QUANT>
+__device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int n, int n0, int n0_shift, int q,
+                                      const int *qm, unsigned *err) {
+  c.sum = 0;
+  c.last_end = 0;
+  int raw[8];
+  const bool full = j0 + 8 <= n;
+  if (full) {
+    const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
+    raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = j0 + k < n ? src[j0 + k] : 0;
+  }
+  if (QUANT) {
+    const int b0 = band_of_index_fast(min(j0, n - 1), n0, n0_shift), b7 = band_of_index_fast(min(j0 + 7, n - 1), n0, n0_shift);
+    if (b0 == b7) { // the usual case: all eight coefficients in one subband
+      const int aq = max(q - qm[b0], 0);
+      if (aq > 119) {
+        atomicOr(err, VC2_DEVERR_QINDEX);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) raw[k] = 0;
+      } else {
+        const int qf = c_qs.qf[aq], sh = c_qs.shift[aq];
+        const unsigned mg = c_qs.magic[aq];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int v = raw[k];
+          const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+          int a = (int)(mag << 2);
+          if (qf > 1 && a >= 0) { const unsigned t = __umulhi(mg, (unsigned)a); a = (int)((t + (((unsigned)a - t) >> 1)) >> sh); }
+          else a /= qf;
+          raw[k] = v < 0 ? (int)(0u - (unsigned)a) : a;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (j0 + k >= n) continue;
+        const int aq = max(q - qm[band_of_index_fast(j0 + k, n0, n0_shift)], 0);
+        if (aq > 119) { atomicOr(err, VC2_DEVERR_QINDEX); raw[k] = 0; }
+        else raw[k] = quant_dev(raw[k], aq);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int nb = 0;
+    if (j0 + k < n) {
+      nb = svlc_bits(raw[k]);
+      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); raw[k] = 0; nb = 1; }
+    }
+    c.v[k] = raw[k];
+    c.nb[k] = nb;
+    c.sum += nb;
+    if (raw[k] != 0) c.last_end = c.sum;
+  }
+}
+
+// merge the lane's codes and OR them into the image at absolute bit position pos (codes that
+// would cross `limit` are dropped: by construction they are trailing '1's, VLC.cpp:151-156)
+__device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const Coef8 &c) {
+  int wi = pos >> 5, fill = pos & 31;
+  unsigned long long acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int nb = c.nb[k];
+    if (nb != 0 && pos + nb <= limit) { // once one code is past the limit, every later one is too
+      acc |= (unsigned long long)svlc_code(c.v[k]) << (64 - fill - nb);
+      fill += nb;
+      if (fill >= 32) {
+        atomicOr(&img[wi], (unsigned)(acc >> 32));
+        acc <<= 32;
+        fill -= 32;
+        ++wi;
+      }
+    }
+    pos += nb;
+  }
+  if (acc) atomicOr(&img[wi], (unsigned)(acc >> 32));
+}
+__device__ __forceinline__ void put_byte(unsigned *img, int off, unsigned b) { atomicOr(&img[off >> 2], b << (24 - 8 * (off & 3))); }
+
+__device__ __forceinline__ int half_max(int v) { // max within each 32-lane half
+#pragma unroll
+  for (int d = 16; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   extern __shared__ unsigned lds_u[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
-  const int region_words = (255 * p.scalar + 3) / 4 + 2;
-  const int region_bits = (region_words - 1) * 32;
-  unsigned *buf = lds_u + wave * 3 * region_words;
+  const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
+  unsigned *img = lds_u + wave * img_words;
   const bool active = slice < p.n_slices;
-  for (int i = lane; i < 3 * region_words; i += 64) buf[i] = 0;
+  for (int i = lane; i < img_words; i += 64) img[i] = 0;
   __syncthreads();
 
   int bytes[3] = {0, 0, 0};
   int q = 0;
+  bool bad_cbr = false;
   if (active) {
     q = p.qidx[(size_t)pic * p.n_slices + slice];
     const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-    for (int c = 0; c < 3; ++c) {
-      const int32_t *src = rec + p.comp_off[c];
-      auto ld = [&](int j) -> int { return src[j]; };
-      int count;
-      if (p.quantise)
-        count = component_bits<true, true>(ld, p.comp_n[c], p.comp_n0[c], q, p.qmatrix, lane,
-                                           buf + c * region_words, region_bits, p.err);
-      else
-        count = component_bits<false, true>(ld, p.comp_n[c], p.comp_n0[c], q, p.qmatrix, lane,
-                                            buf + c * region_words, region_bits, p.err);
+    const int cbr_total = p.cbr_bytes ? p.cbr_bytes[slice] : 0;
+    auto comp_len = [&](int count) -> int {
       int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
       if (len > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
-      bytes[c] = len * p.scalar;
+      return len * p.scalar;
+    };
+    auto cbr_v = [&](int need) -> int { // Slices.cpp:352-368: V absorbs the remainder of the slice
+      if (!p.cbr_bytes) return need;
+      const int vb = cbr_total - 4 - bytes[0] - bytes[1];
+      if (vb < need) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); bad_cbr = true; return need; }
+      if (vb / p.scalar > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); bad_cbr = true; return need; }
+      return vb;
+    };
+    int base = p.prefix + 1; // byte offset of the next component's length byte
+    const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2];
+    if (fast) {
+      Coef8 c;
+      { // luma: one round
+        const int n = p.comp_n[0], n0 = p.comp_n0[0];
+        const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
+        if (p.quantise) load8<true>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+        else load8<false>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+        const int incl = wave_incl_scan(c.sum, lane);
+        const int count = wave_max(c.last_end ? incl - c.sum + c.last_end : 0);
+        bytes[0] = comp_len(count);
+        write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c);
+        if (lane == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
+        base += 1 + bytes[0];
+      }
+      { // both chroma components in one round: lanes 0-31 U, lanes 32-63 V
+        const int n = p.comp_n[1], n0 = p.comp_n0[1];
+        const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
+        const int half = lane >> 5, cc = 1 + half;
+        if (p.quantise) load8<true>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err);
+        else load8<false>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err);
+        const int incl = wave_incl_scan(c.sum, lane);
+        const int total_u = __shfl(incl, 31);
+        const int rel = incl - c.sum - (half ? total_u : 0);
+        const int cnt = half_max(c.last_end ? rel + c.last_end : 0);
+        bytes[1] = comp_len(__shfl(cnt, 0));
+        bytes[2] = cbr_v(comp_len(__shfl(cnt, 32)));
+        const int base_c = half ? base + 1 + bytes[1] : base;
+        write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c);
+        if (lane == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
+        if (lane == 32) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
+      }
+    } else { // any geometry: two passes per component (measure, then write), 512 coefficients per round
+      for (int cc = 0; cc < 3; ++cc) {
+        const int n = p.comp_n[cc], n0 = p.comp_n0[cc];
+        const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
+        const int32_t *src = rec + p.comp_off[cc];
+        Coef8 c;
+        int run = 0, count = 0;
+        for (int r0 = 0; r0 < n; r0 += 512) {
+          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+          const int incl = wave_incl_scan(c.sum, lane);
+          count = max(count, wave_max(c.last_end ? run + incl - c.sum + c.last_end : 0));
+          run += __shfl(incl, 63);
+        }
+        bytes[cc] = comp_len(count);
+        if (cc == 2) bytes[2] = cbr_v(bytes[2]);
+        run = 0;
+        for (int r0 = 0; r0 < n; r0 += 512) {
+          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+          const int incl = wave_incl_scan(c.sum, lane);
+          write8(img, 8 * (base + 1) + run + incl - c.sum, 8 * (base + 1 + bytes[cc]), c);
+          run += __shfl(incl, 63);
+        }
+        if (lane == 0) put_byte(img, base, (unsigned)(bytes[cc] / p.scalar));
+        base += 1 + bytes[cc];
+      }
     }
+    if (lane == 0) put_byte(img, p.prefix, (unsigned)q & 0xFF);
   }
   __syncthreads();
   if (!active) return;
 
-  uint8_t *dst;
-  if (p.cbr_bytes) { // Slices.cpp:352-368: V absorbs the remainder of the slice
-    const int vb = p.cbr_bytes[slice] - 4 - bytes[0] - bytes[1];
-    if (vb < bytes[2]) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); }
-    else if (vb / p.scalar > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); }
-    else bytes[2] = vb;
-    dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
-  } else {
-    dst = p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes;
-  }
   const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
-  if (!p.cbr_bytes && lane == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
-  for (int i = lane; i < total; i += 64) {
-    int t = i - p.prefix;
-    unsigned b = 0;
-    if (t == 0) b = (unsigned)q & 0xFF;
-    else if (t > 0) {
-      t -= 1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if (t >= 0 && t < 1 + bytes[c]) {
-          if (t == 0) b = (unsigned)(bytes[c] / p.scalar);
-          else {
-            const int k = t - 1;
-            b = (k < 4 * (region_words - 1)) ? (buf[c * region_words + (k >> 2)] >> (24 - 8 * (k & 3))) & 0xFF : 0;
-          }
-        }
-        t -= 1 + bytes[c];
-      }
-    }
-    dst[i] = (uint8_t)b;
+  if (p.cbr_bytes) {
+    if (bad_cbr) return;
+    uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
+    for (int i = lane; i < total; i += 64) dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3)));
+  } else {
+    unsigned *dst = (unsigned *)(p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes);
+    if (lane == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
+    for (int i = lane; i < (total + 3) / 4; i += 64) dst[i] = __builtin_bswap32(img[i]);
   }
 }
 
 void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s) {
-  const int region_words = (255 * p.scalar + 3) / 4 + 2;
-  const size_t lds = (size_t)4 * 3 * region_words * 4;
+  const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
+  const size_t lds = (size_t)4 * img_words * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   vc2_prof_begin(L, "hq_pack", s);
