@@ -24,6 +24,38 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
+def picture_shard(n_pictures, rank, world):
+    """Pictures are independent: picture k belongs to rank k mod world."""
+    return list(range(rank, n_pictures, world))
+
+
+def dry_run(args, rank, world):
+    """CPU-only exercise of the multi-rank control flow (tests/test_multi_rank.py): rendezvous, barrier,
+    MAX-over-ranks of the step time, picture sharding and the rank-0 JSON line.  No codec work is done
+    and the line is marked dry_run: it is not a measurement."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    mine = picture_shard(args.batch * world, rank, world)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))       # ranks finish at different times: MAX must pick the slowest
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    counts = torch.tensor([len(mine)], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "pictures": int(counts.item()),
+                          "ms_per_step": dt.item() * 1e3, "scaling": "weak"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +77,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    if os.environ.get("VC2_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
