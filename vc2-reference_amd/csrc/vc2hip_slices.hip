@@ -627,15 +627,27 @@ struct WordReader {
 // HQ unpack v2: one lane per slice component, grouped by component type so that all lanes of a
 // wavefront decode the same number of coefficients.  Decoded values are staged 16 per lane in LDS
 // and flushed with 16-byte stores (four lanes cover one component's 64-byte run).
+// gather the bits at even positions (0,2,4,...) of a 32-bit word into the low half
+__device__ __forceinline__ unsigned compact_even32(unsigned x) {
+  x &= 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+  x = (x | (x >> 4)) & 0x00FF00FFu;
+  x = (x | (x >> 8)) & 0x0000FFFFu;
+  return x;
+}
+
+constexpr int UNP_PITCH = 20; // ints per staging row: 16 coefficients, 16-byte aligned rows
+
 __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
-  __shared__ int stage[4][64 * 17];
+  __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
   __shared__ unsigned long long outp[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y, comp = blockIdx.z;
   const int slice = blockIdx.x * 256 + threadIdx.x;
   const bool active = slice < p.n_slices;
   const int n = p.comp_n[comp];
-  int *st = stage[wave] + lane * 17;
+  int *st = stage[wave] + lane * UNP_PITCH;
   WordReader br;
   {
     int32_t *out = nullptr;
@@ -663,24 +675,29 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   }
   for (int base = 0; base < n; base += 16) {
     const int room = min(16, n - base);
+    // zero coefficients are the common case: clear the row, then only non-zero values are stored
+    *(int4 *)(st) = make_int4(0, 0, 0, 0);
+    *(int4 *)(st + 4) = make_int4(0, 0, 0, 0);
+    *(int4 *)(st + 8) = make_int4(0, 0, 0, 0);
+    *(int4 *)(st + 12) = make_int4(0, 0, 0, 0);
     int cnt = 0;
     while (cnt < room) {
       br.refill();
-      const int ones = __clzll((long long)~br.acc);
-      if (ones > 0) { // run of '1' bits = run of zero coefficients
-        const int z = min(min(ones, br.have), room - cnt);
-        for (int k = 0; k < z; ++k) st[cnt + k] = 0;
-        cnt += z;
-        br.skip(z);
-        continue;
-      }
-      const unsigned long long follow = br.acc & 0xAAAAAAAAAAAAAAAAull;
-      const int K = follow ? __clzll((long long)follow) / 2 : 32;
-      if (2 * K + 2 <= br.have) {
-        const unsigned long long body = br.acc >> (64 - 2 * K);
-        const unsigned data_bits = (unsigned)compact_odd64(body);
-        const unsigned mag = ((1u << K) | data_bits) - 1u;
-        const int neg = (int)((br.acc >> (62 - 2 * K)) & 1ull);
+      // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0)
+      const int z = min(min(__clzll((long long)~br.acc), br.have), room - cnt);
+      cnt += z;
+      br.skip(z);
+      if (cnt >= room) break;
+      br.refill();
+      if (br.acc >> 63) continue; // the run continues in the freshly loaded word
+      // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
+      const unsigned hi = (unsigned)(br.acc >> 32);
+      const unsigned follow = hi & 0xAAAAAAAAu;
+      if (follow != 0 && 2 * (__clz(follow) >> 1) + 2 <= 32) {
+        const int K = __clz(follow) >> 1;                       // 1..15
+        const unsigned body = hi >> (32 - 2 * K);               // top 2K bits: (0 b) pairs
+        const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
+        const int neg = (int)((hi >> (30 - 2 * K)) & 1u);
         st[cnt++] = neg ? (int)(0u - mag) : (int)mag;
         br.skip(2 * K + 2);
       } else { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
@@ -711,10 +728,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     for (int j = 0; j < 4; ++j) {
       const int r = j * 16 + (lane >> 2), c = (lane & 3) * 4;
       int32_t *dst = (int32_t *)outp[wave][r];
-      if (dst && c < room) {
-        const int *q = sw + r * 17 + c;
-        *(int4 *)(dst + base + c) = make_int4(q[0], q[1], q[2], q[3]);
-      }
+      if (dst && c < room) *(int4 *)(dst + base + c) = *(const int4 *)(sw + r * UNP_PITCH + c);
     }
     __syncthreads();
   }
@@ -761,11 +775,14 @@ __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long
 }
 
 // Per chunk: (exit offset, slices started) for every possible entry offset e in [0, E).
-// All E walkers advance stripe by stripe (stripe width = E = the longest possible slice, so a
-// walker leaving a stripe lands inside the next one).  At every stripe boundary walkers that
-// landed on the same byte are merged -- chains of random-looking length bytes coalesce quickly,
-// so only a handful of walkers survive the first few stripes; merged walkers keep a link
-// (owner, hop difference) that is resolved at the end.
+// Every entry offset gets a walker.  Walkers hop independently; each byte position a walker lands
+// on is claimed in an LDS hash table (64-bit compare-and-swap: position | owner | owner's hop
+// count).  A walker that lands on a claimed byte merges into the owner and stops, so every
+// position's outgoing hop is taken exactly once -- chains of pseudo-random length bytes coalesce
+// within a few hops and only a handful of walkers reach the end of the chunk.  Merged walkers keep
+// (owner, hop difference) links that are resolved at the end.
+static constexpr int IDX_T = 4096; // hash slots
+
 __global__ __launch_bounds__(256) void k_index_tables(const uint8_t *payload, long long stride,
                                                       const unsigned long long *lens, uint2 *tables,
                                                       int n_chunks, int E, int prefix, int scalar) {
@@ -775,50 +792,51 @@ __global__ __launch_bounds__(256) void k_index_tables(const uint8_t *payload, lo
   uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
   if (c0 >= plen) return;
   const int nbytes = (IDX_CH + E + 16 + 15) & ~15;
-  unsigned short *w_pos = (unsigned short *)(lds_b + nbytes);
-  unsigned short *w_hops = w_pos + E;
-  unsigned short *w_owner = w_hops + E;   // 0xFFFF: alive / survivor, else the walker merged into
+  unsigned long long *claims = (unsigned long long *)(lds_b + nbytes);
+  unsigned short *w_owner = (unsigned short *)(claims + IDX_T); // 0xFFFF: reached the chunk end itself
   short *w_delta = (short *)(w_owner + E);
-  unsigned short *z_owner = (unsigned short *)(w_delta + E); // per landing offset: winner id, its hops
-  unsigned short *z_hops = z_owner + E;
-  unsigned *bitmap = (unsigned *)(((size_t)(z_hops + E) + 3) & ~(size_t)3);
-  const int bm_words = (E + 31) / 32;
+  unsigned short *w_exit = (unsigned short *)(w_delta + E);
+  unsigned short *w_hops = w_exit + E;
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
-  for (int e = threadIdx.x; e < E; e += blockDim.x) { w_pos[e] = (unsigned short)e; w_hops[e] = 0; w_owner[e] = 0xFFFF; }
-  for (int i = threadIdx.x; i < bm_words; i += blockDim.x) bitmap[i] = 0;
+  for (int i = threadIdx.x; i < IDX_T; i += blockDim.x) claims[i] = 0;
   __syncthreads();
-  const int n_stripes = (IDX_CH + E - 1) / E;
-  for (int s = 0; s < n_stripes; ++s) {
-    const int end = min((s + 1) * E, IDX_CH);
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-      if (w_owner[e] != 0xFFFF) continue;
-      int pos = w_pos[e], hops = w_hops[e];
-      while (pos < end) { pos += slice_len_lds(lds_b, pos, prefix, scalar); ++hops; }
-      w_pos[e] = (unsigned short)pos;
-      w_hops[e] = (unsigned short)hops;
-      if (s + 1 < n_stripes) { // claim the landing byte
-        const int key = pos - end;
-        const unsigned bit = 1u << (key & 31);
-        if (!(atomicOr(&bitmap[key >> 5], bit) & bit)) { z_owner[key] = (unsigned short)e; z_hops[key] = (unsigned short)hops; }
+  // the chain ends with the payload: never walk the zero fill behind it (4-byte hops)
+  const int lim = (int)min((unsigned long long)IDX_CH, plen - c0);
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    int pos = e, hops = 0, owner = 0xFFFF, delta = 0;
+    bool claim = true;
+    while (pos < lim) {
+      pos += slice_len_lds(lds_b, pos, prefix, scalar);
+      ++hops;
+      if (pos >= lim) break;
+      if (pos < E) { owner = pos; delta = hops; break; } // walker `pos` starts here with 0 hops
+      if (!claim) continue;
+      const unsigned long long mine = ((unsigned long long)(pos + 1) << 32) | ((unsigned)e << 16) | (unsigned)hops;
+      unsigned h = ((unsigned)pos * 2654435761u) >> 20; // top 12 bits
+      int probes = 0;
+      for (;;) {
+        const unsigned long long old = atomicCAS(&claims[h], 0ull, mine);
+        if (old == 0) break;
+        if ((unsigned)(old >> 32) == (unsigned)(pos + 1)) {
+          owner = (int)((old >> 16) & 0xFFFF);
+          delta = hops - (int)(old & 0xFFFF);
+          break;
+        }
+        h = (h + 1) & (IDX_T - 1);
+        if (++probes >= IDX_T) { claim = false; break; } // table full: keep walking unclaimed
       }
+      if (owner != 0xFFFF) break;
     }
-    if (s + 1 == n_stripes) break;
-    __syncthreads();
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-      if (w_owner[e] != 0xFFFF) continue;
-      const int key = (int)w_pos[e] - end;
-      const int o = z_owner[key];
-      if (o != e) { w_owner[e] = (unsigned short)o; w_delta[e] = (short)((int)w_hops[e] - (int)z_hops[key]); }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < bm_words; i += blockDim.x) bitmap[i] = 0;
-    __syncthreads();
+    w_owner[e] = (unsigned short)owner;
+    w_delta[e] = (short)delta;
+    w_exit[e] = (unsigned short)(pos >= IDX_CH ? pos - IDX_CH : 0);
+    w_hops[e] = (unsigned short)hops;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     int cur = e, d = 0;
     while (w_owner[cur] != 0xFFFF) { d += w_delta[cur]; cur = w_owner[cur]; }
-    tab[e] = make_uint2((unsigned)((int)w_pos[cur] - IDX_CH), (unsigned)((int)w_hops[cur] + d));
+    tab[e] = make_uint2((unsigned)w_exit[cur], (unsigned)((int)w_hops[cur] + d));
   }
 }
 
@@ -886,7 +904,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     attr = true;
   }
   vc2_prof_begin(L, "slice_index_tables", s);
-  const size_t lds_tab = (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)E * 12 + 4 * ((E + 31) / 32) + 16;
+  const size_t lds_tab = (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)IDX_T * 8 + (size_t)E * 8 + 16;
   hipLaunchKernelGGL(k_index_tables, dim3(n_chunks, n_pictures), dim3(256), lds_tab, s,
                      payload, payload_stride, lens, tables, n_chunks, E, prefix, scalar);
   vc2_prof_end(L, s);
