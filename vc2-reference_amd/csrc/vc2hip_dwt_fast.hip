@@ -25,7 +25,7 @@ void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s) {
 
 namespace {
 
-constexpr int TY = 64, TX = 128, NT = 256;
+constexpr int TY = 32, TX = 128, NT = 256;
 
 struct I4 {
   int x, y, z, w;
