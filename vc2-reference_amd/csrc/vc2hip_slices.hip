@@ -586,42 +586,46 @@ __device__ void decode_component(const uint8_t *data, unsigned nbytes, int n, in
   }
 }
 
-// Word-wise bounded reader: 32-bit big-endian words, the next word prefetched while the current one
-// is consumed; bytes past the component bound read as 0xFF (VLC.cpp:182-185).
+// Bounded bit reader over 64-bit big-endian words with one word of lookahead: `acc` holds `have`
+// unread bits (top aligned), `nxt` the following 64 bits, so peek() always shows 64 valid bits and
+// a whole token (zero run + one code, <= 48 bits) is consumed with a single refill check.
+// Bytes past the component bound read as 0xFF (VLC.cpp:182-185).
 struct WordReader {
-  const unsigned *w4;  // 4-byte aligned base
+  const uint2 *w8;     // 8-byte aligned base
   int lead, len;       // bytes to skip in word 0; bounded length in bytes
   int k;               // next word index to fetch
-  unsigned nxt;
-  unsigned long long acc;
+  unsigned long long acc, nxt;
   int have;
-  __device__ __forceinline__ unsigned fetch(int idx) const {
-    const int rel = 4 * idx - lead; // byte offset of this word relative to the data start
-    if (rel >= len) return 0xFFFFFFFFu;
-    unsigned v = __builtin_bswap32(w4[idx]);
-    if (rel + 4 > len) v |= 0xFFFFFFFFu >> (8 * (len - rel));
+  __device__ __forceinline__ unsigned long long fetch(int idx) const {
+    const int rel = 8 * idx - lead; // byte offset of this word relative to the data start
+    if (rel >= len) return ~0ull;
+    const uint2 w = w8[idx];
+    unsigned long long v = ((unsigned long long)__builtin_bswap32(w.x) << 32) | __builtin_bswap32(w.y);
+    if (rel + 8 > len) v |= ~0ull >> (8 * (len - rel));
     return v;
   }
   __device__ __forceinline__ void init(const uint8_t *data, int nbytes) {
     const size_t a = (size_t)data;
-    w4 = (const unsigned *)(a & ~(size_t)3);
-    lead = (int)(a & 3);
+    w8 = (const uint2 *)(a & ~(size_t)7);
+    lead = (int)(a & 7);
     len = nbytes;
-    acc = (unsigned long long)fetch(0) << 32;
-    have = 32;
+    acc = fetch(0) << (8 * lead);
+    have = 64 - 8 * lead;
     nxt = fetch(1);
     k = 2;
-    acc <<= 8 * lead;
-    have -= 8 * lead;
   }
-  __device__ __forceinline__ void refill() { // guarantees have >= 33
-    if (have <= 32) {
-      acc |= (unsigned long long)nxt << (32 - have);
-      have += 32;
+  __device__ __forceinline__ void init_ones() { w8 = nullptr; lead = 0; len = 0; k = 0; acc = nxt = ~0ull; have = 64; }
+  // the next 64 unread bits
+  __device__ __forceinline__ unsigned long long peek() const { return have >= 64 ? acc : (acc | (nxt >> have)); }
+  __device__ __forceinline__ void skip(int n) { // n <= 64
+    if (n < have) { acc <<= n; have -= n; }
+    else {
+      const int r = n - have; // 0..63 bits into nxt
+      acc = r >= 64 ? 0 : nxt << r;
+      have = 64 - r;
       nxt = fetch(k++);
     }
   }
-  __device__ __forceinline__ void skip(int n) { acc = n >= 64 ? 0 : acc << n; have -= n; }
 };
 
 // HQ unpack v2: one lane per slice component, grouped by component type so that all lanes of a
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
       out = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
     }
     outp[wave][lane] = (unsigned long long)out;
-    if (active) br.init(data, (int)len); else { br.w4 = nullptr; br.lead = 0; br.len = 0; br.acc = ~0ull; br.have = 64; br.nxt = ~0u; br.k = 0; }
+    if (active) br.init(data, (int)len); else br.init_ones();
   }
   for (int base = 0; base < n; base += 16) {
     const int room = min(16, n - base);
@@ -682,40 +686,35 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     *(int4 *)(st + 12) = make_int4(0, 0, 0, 0);
     int cnt = 0;
     while (cnt < room) {
-      br.refill();
+      const unsigned long long win = br.peek();
       // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0)
-      const int z = min(min(__clzll((long long)~br.acc), br.have), room - cnt);
+      const int z = min(__clzll((long long)~win), room - cnt);
       cnt += z;
-      br.skip(z);
-      if (cnt >= room) break;
-      br.refill();
-      if (br.acc >> 63) continue; // the run continues in the freshly loaded word
+      if (cnt >= room || z >= 32) { br.skip(z); continue; }
       // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
-      const unsigned hi = (unsigned)(br.acc >> 32);
+      const unsigned hi = (unsigned)((win << z) >> 32);
       const unsigned follow = hi & 0xAAAAAAAAu;
-      if (follow != 0 && 2 * (__clz(follow) >> 1) + 2 <= 32) {
-        const int K = __clz(follow) >> 1;                       // 1..15
+      if (follow != 0) {
+        const int K = __clz(follow) >> 1;                       // 1..15 (bit 31 of hi is 0 here)
         const unsigned body = hi >> (32 - 2 * K);               // top 2K bits: (0 b) pairs
         const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
         const int neg = (int)((hi >> (30 - 2 * K)) & 1u);
         st[cnt++] = neg ? (int)(0u - mag) : (int)mag;
-        br.skip(2 * K + 2);
+        br.skip(z + 2 * K + 2);
       } else { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
+        br.skip(z);
         unsigned value = 1;
         for (;;) {
-          br.refill();
-          const int f = (int)(br.acc >> 63);
+          const int f = (int)(br.peek() >> 63);
           br.skip(1);
           if (f) break;
-          br.refill();
-          value = (value << 1) | (unsigned)(br.acc >> 63);
+          value = (value << 1) | (unsigned)(br.peek() >> 63);
           br.skip(1);
         }
         value -= 1u;
         int r = 0;
         if (value) {
-          br.refill();
-          r = (br.acc >> 63) ? (int)(0u - value) : (int)value;
+          r = (br.peek() >> 63) ? (int)(0u - value) : (int)value;
           br.skip(1);
         }
         st[cnt++] = r;
