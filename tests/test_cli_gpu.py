@@ -1,0 +1,144 @@
+"""GPU tests of the drop-in tools: EncodeStream / DecodeStream (vc2-reference_amd/bin) against whole
+streams and decoded files of the oracle, and against the reference's own digests at full size."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from synth import noise_frame, synth
+from vc2lib import KERNELS, make_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vc2-reference_amd", "bin")
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_digests.json")))
+
+
+@pytest.fixture(scope="module")
+def tools():
+    if not os.path.exists(os.path.join(BIN, "EncodeStream")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "vc2-reference_amd", "host")], stdout=subprocess.DEVNULL)
+    return BIN
+
+
+def run(tool, *args):
+    out = subprocess.run([os.path.join(BIN, tool)] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    return out
+
+
+def enc_args(w, h, cf, bits, kernel, depth, u, a, mode="HQ_ConstQ", q=None, s=None, scalar=1, prefix=0, n=2):
+    args = ["-m", mode, "-k", kernel, "-d", depth, "-u", u, "-a", a, "-f", {"444": "4:4:4", "422": "4:2:2", "420": "4:2:0"}[cf],
+            "-x", w, "-y", h, "-l", bits, "-n", n, "-S", scalar, "-P", prefix]
+    if q is not None:
+        args += ["-q", q]
+    if s is not None:
+        args += ["-s", s]
+    return args
+
+
+@pytest.mark.parametrize("kernel", ["DD97", "Fidelity", "Haar0"])
+def test_stream_roundtrip_matches_oracle(tools, oracle, tmp_path, kernel):
+    w, h, frames = 208, 120, 3
+    raw = synth(w, h, "422", 10, 51, frames=frames)
+    p = make_params(w, h, "422", 10, kernel, 3, 1, 2, q=9, scalar=3, prefix=1)
+    want_stream = oracle.encode_stream(p, raw, frames)
+    want_dec, n = oracle.decode_stream(p, want_stream, frames)
+    (tmp_path / "in.raw").write_bytes(raw)
+    run("EncodeStream", *enc_args(w, h, "422", 10, kernel, 3, 1, 2, q=9, scalar=3, prefix=1), tmp_path / "in.raw", tmp_path / "out.vc2")
+    assert (tmp_path / "out.vc2").read_bytes() == want_stream
+    run("DecodeStream", tmp_path / "out.vc2", tmp_path / "dec.raw")
+    assert (tmp_path / "dec.raw").read_bytes() == want_dec
+
+
+def test_cbr_stream_and_8bit(tools, oracle, tmp_path):
+    w, h = 256, 128
+    raw = synth(w, h, "420", 8, 52, frames=2, word_bytes=1)
+    p = make_params(w, h, "420", 8, "LeGall", 3, 1, 2, mode="HQ_CBR", s=20000, scalar=2, word_bytes=1)
+    want = oracle.encode_stream(p, raw, 2)
+    (tmp_path / "in.raw").write_bytes(raw)
+    run("EncodeStream", *enc_args(w, h, "420", 8, "LeGall", 3, 1, 2, mode="HQ_CBR", s=20000, scalar=2, n=1), tmp_path / "in.raw", tmp_path / "o.vc2")
+    assert (tmp_path / "o.vc2").read_bytes() == want
+    run("DecodeStream", tmp_path / "o.vc2", tmp_path / "d.raw")
+    assert (tmp_path / "d.raw").read_bytes() == oracle.decode_stream(p, want, 2)[0]
+
+
+def _planes_be4(data, shapes):
+    out, pos = [], 0
+    for s in shapes:
+        n = s[0] * s[1]
+        out.append(np.frombuffer(data[pos:pos + 4 * n], ">i4").astype(np.int32).reshape(s))
+        pos += 4 * n
+    assert pos == len(data)
+    return out
+
+
+def test_diagnostic_outputs_match_oracle(tools, oracle, tmp_path):
+    # -o Transform / Quantised / Indices / Packaged (EncodeParams.cpp:251-296), DecodeStream -o Quantised / Transform / Indices
+    w, h, depth, kernel = 128, 64, 3, "DD97"
+    raw = synth(w, h, "422", 10, 53)
+    (tmp_path / "in.raw").write_bytes(raw)
+    k = KERNELS[kernel]
+    y = oracle.ingest(raw[:w * h * 2], 2, 10, (h, w))
+    u = oracle.ingest(raw[w * h * 2:w * h * 3], 2, 10, (h, w // 2))
+    v = oracle.ingest(raw[w * h * 3:], 2, 10, (h, w // 2))
+    t = [oracle.dwt_forward(pl, k, depth) for pl in (y, u, v)]
+    base = enc_args(w, h, "422", 10, kernel, depth, 1, 2, mode="HQ_CBR", s=6000)
+    run("EncodeStream", *base, "-o", "Transform", tmp_path / "in.raw", tmp_path / "t.bin")
+    got = _planes_be4((tmp_path / "t.bin").read_bytes(), [a.shape for a in t])
+    assert all(np.array_equal(a, b) for a, b in zip(got, t))
+    qm = oracle.quant_matrix(k, depth)
+    sb = oracle.slice_bytes(8, 4, 6000, 1)
+    qi = oracle.cbr_qindices(t[0], t[1], t[2], depth, qm, sb, 1)
+    run("EncodeStream", *base, "-o", "Indices", tmp_path / "in.raw", tmp_path / "i.bin")
+    assert np.array_equal(np.frombuffer((tmp_path / "i.bin").read_bytes(), np.uint8).reshape(8, 4), qi)
+    q = [oracle.quantise_np(a, depth, qi, qm) for a in t]
+    run("EncodeStream", *base, "-o", "Quantised", tmp_path / "in.raw", tmp_path / "q.bin")
+    got = _planes_be4((tmp_path / "q.bin").read_bytes(), [a.shape for a in q])
+    assert all(np.array_equal(a, b) for a, b in zip(got, q))
+    run("EncodeStream", *base, "-o", "Packaged", tmp_path / "in.raw", tmp_path / "p.bin")
+    assert (tmp_path / "p.bin").read_bytes() == bytes(oracle.hq_pack(q[0], q[1], q[2], depth, qi, 0, 1, cbr=sb))
+    run("EncodeStream", *base, tmp_path / "in.raw", tmp_path / "s.vc2")
+    run("DecodeStream", "-o", "Quantised", tmp_path / "s.vc2", tmp_path / "dq.bin")
+    got = _planes_be4((tmp_path / "dq.bin").read_bytes(), [a.shape for a in q])
+    assert all(np.array_equal(a, b) for a, b in zip(got, q))
+    run("DecodeStream", "-o", "Indices", tmp_path / "s.vc2", tmp_path / "di.bin")
+    assert np.array_equal(np.frombuffer((tmp_path / "di.bin").read_bytes(), np.uint8).reshape(8, 4), qi)
+    run("DecodeStream", "-o", "Transform", tmp_path / "s.vc2", tmp_path / "dt.bin")
+    want = [oracle.dequantise_np(a, depth, qi, qm) for a in q]
+    got = _planes_be4((tmp_path / "dt.bin").read_bytes(), [a.shape for a in want])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_decodestream_ld_stream(tools, oracle, tmp_path):
+    w, h = 256, 120
+    raw = synth(w, h, "422", 8, 54, frames=2, word_bytes=1)
+    p = make_params(w, h, "422", 8, "LeGall", 3, 1, 2, mode="LD", s=12000, word_bytes=1)
+    stream = oracle.encode_stream(p, raw, 2)
+    (tmp_path / "ld.vc2").write_bytes(stream)
+    run("DecodeStream", tmp_path / "ld.vc2", tmp_path / "ld.raw")
+    assert (tmp_path / "ld.raw").read_bytes() == oracle.decode_stream(p, stream, 2)[0]
+
+
+def test_error_reporting_like_the_reference(tools, tmp_path):
+    # "Error: <what()>" on standard output, exit status 1 (EncodeStream.cpp:782-785)
+    w, h = 64, 64
+    (tmp_path / "in.raw").write_bytes(noise_frame(w, h, "444", 12, 5, full_scale=True))
+    out = subprocess.run([os.path.join(BIN, "EncodeStream")] + [str(a) for a in enc_args(w, h, "444", 12, "Fidelity", 2, 4, 4, q=0, scalar=1)]
+                         + [str(tmp_path / "in.raw"), str(tmp_path / "o.vc2")], capture_output=True, text=True)
+    assert out.returncode == 1
+    assert "Error: Slice scalar is too small, consider using a larger slice scalar." in out.stdout
+
+
+def test_cfg1_full_size_against_reference_digests(tools, tmp_path):
+    """BASELINE config 1 through the tools only: byte-identical to the reference's stream and decode."""
+    g = GOLD["cfg1"]
+    (tmp_path / "in.raw").write_bytes(synth(1920, 1080, "422", 10, 1234))
+    run("EncodeStream", *enc_args(1920, 1080, "422", 10, "LeGall", 2, 2, 4, q=12), tmp_path / "in.raw", tmp_path / "o.vc2")
+    s = (tmp_path / "o.vc2").read_bytes()
+    assert len(s) == g["stream"]["bytes"] and hashlib.sha256(s).hexdigest() == g["stream"]["sha256"]
+    run("DecodeStream", tmp_path / "o.vc2", tmp_path / "d.raw")
+    assert hashlib.sha256((tmp_path / "d.raw").read_bytes()).hexdigest() == g["decoded"]["sha256"]

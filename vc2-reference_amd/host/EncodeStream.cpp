@@ -1,0 +1,333 @@
+// EncodeStream -- command-line compatible with /root/reference/src/EncodeStream (EncodeParams.cpp:55-249
+// flags and validation, EncodeStream.cpp:247-788 flow and output modes), with the per-picture body
+// running on MI355X through libvc2hip.  Extension: --gpus N encodes frame k on GPU k mod N.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <thread>
+
+#include "Args.h"
+#include "DataUnit.h"
+#include "Hip.h"
+#include "Picture.h"
+#include "Quantisation.h"
+#include "Slices.h"
+#include "Utils.h"
+#include "WaveletTransform.h"
+
+using std::cerr; using std::clog; using std::cout; using std::endl; using std::string;
+
+enum Mode { HQ_ConstQ, HQ_CBR, LD };
+enum Output { TRANSFORM, QUANTISED, INDICES, PACKAGED, STREAM, DECODED, PSNR };
+
+static Mode parseMode(const string &t) {
+  if (t == "HQ_ConstQ") return HQ_ConstQ;
+  if (t == "HQ_CBR") return HQ_CBR;
+  if (t == "LD") return LD;
+  throw std::invalid_argument("invalid mode");
+}
+static Output parseOutput(const string &t) {
+  if (t == "Transform") return TRANSFORM;
+  if (t == "Quantised") return QUANTISED;
+  if (t == "Indices") return INDICES;
+  if (t == "Packaged") return PACKAGED;
+  if (t == "Stream") return STREAM;
+  if (t == "Decoded") return DECODED;
+  if (t == "PSNR") return PSNR;
+  throw std::invalid_argument("invalid output");
+}
+static const char *modeName(Mode m) { return m == HQ_ConstQ ? "HQ_ConstQ" : (m == HQ_CBR ? "HQ_CBR" : "LD"); }
+static const char *outputName(Output o) {
+  static const char *n[] = {"Transform", "Quantised", "Indices", "Packaged", "Stream", "Decoded", "PSNR"};
+  return n[o];
+}
+
+static void writeSigned4(std::ostream &os, const Array2D &a) { // pictureio::wordWidth(4) + signed_binary
+  std::vector<unsigned char> b(a.num_elements() * 4);
+  for (std::size_t i = 0; i < a.num_elements(); ++i) {
+    const unsigned v = (unsigned)a.data()[i];
+    b[4 * i] = (unsigned char)(v >> 24); b[4 * i + 1] = (unsigned char)(v >> 16);
+    b[4 * i + 2] = (unsigned char)(v >> 8); b[4 * i + 3] = (unsigned char)v;
+  }
+  os.write((const char *)b.data(), (std::streamsize)b.size());
+}
+static void writePicture4(std::ostream &os, const Picture &p) { writeSigned4(os, p.y()); writeSigned4(os, p.c1()); writeSigned4(os, p.c2()); }
+
+static const std::vector<ArgSpec> SPECS = {
+    {'v', "verbose", false, ""}, {'m', "mode", true, ""}, {'o', "output", true, ""}, {'a', "hSlice", true, ""},
+    {'u', "vSlice", true, ""}, {'d', "waveletDepth", true, ""}, {'k', "kernel", true, ""},
+    {'b', "bottomFieldFirst", false, ""}, {'t', "topFieldFirst", false, ""}, {'i', "interlace", false, ""},
+    {'p', "progressive", false, ""}, {'c', "chromaDepth", true, ""}, {'l', "lumaDepth", true, ""},
+    {'z', "bitDepth", true, ""}, {'n', "bytes", true, ""}, {'f', "format", true, ""}, {'x', "width", true, ""},
+    {'y', "height", true, ""}, {'r', "framerate", true, ""}, {'S', "scalar", true, ""}, {'P', "prefix", true, ""},
+    {'F', "fragmentLength", true, ""}, {'s', "compressedBytes", true, ""}, {'q', "quantIndex", true, ""},
+    {'G', "gpus", true, ""}, {'h', "help", false, ""}};
+
+static const char *USAGE =
+    "EncodeStream (MI355X / libvc2hip)\n"
+    "Usage: EncodeStream -m <HQ_ConstQ|HQ_CBR> -k <kernel> -d <depth> -u <vSlice> -a <hSlice> -f <4:4:4|4:2:2|4:2:0>\n"
+    "       -x <width> -y <height> [-l lumaDepth] [-c chromaDepth] [-z bitDepth] [-n bytes] [-r framerate]\n"
+    "       [-q quantIndex] [-s compressedBytes] [-S scalar] [-P prefix] [-o Transform|Quantised|Indices|Packaged|\n"
+    "       Stream|Decoded|PSNR] [-v] [--gpus N] inFile outFile      (\"-\" = standard input / output)\n";
+
+struct Encoded { std::vector<unsigned char> payload; Array2D qidx; string error; };
+
+int main(int argc, char *argv[]) {
+  try {
+    if (argc < 2) { clog << USAGE; return EXIT_SUCCESS; }
+    // ---- parameters: EncodeParams.cpp:80-204 ----
+    string inFileName, outFileName; bool verbose; int height, width, bytes, lumaDepth, chromaDepth; ColourFormat chromaFormat;
+    WaveletKernel kernel; int waveletDepth, ySize, xSize; Output output; Mode mode; int frameRate, sliceScalar, slicePrefix;
+    int fragmentLength, compressedBytes, qIndex, gpus;
+    try {
+      Args a(SPECS, argc, argv);
+      if (a.isSet("help")) { cout << USAGE; return EXIT_SUCCESS; }
+      if (a.positional.size() != 2) throw std::invalid_argument("Required arguments missing: inFile, outFile");
+      for (const char *r : {"mode", "hSlice", "vSlice", "waveletDepth", "kernel", "format", "width", "height"}) a.require(r);
+      inFileName = a.positional[0]; outFileName = a.positional[1];
+      verbose = a.isSet("verbose");
+      height = a.getInt("height", 0); width = a.getInt("width", 0);
+      chromaFormat = parseColourFormat(a.get("format"));
+      bytes = a.getInt("bytes", 2);
+      int bitDepth = a.getInt("bitDepth", 0);
+      lumaDepth = a.getInt("lumaDepth", 0); chromaDepth = a.getInt("chromaDepth", 0);
+      kernel = parseWaveletKernel(a.get("kernel"));
+      waveletDepth = a.getInt("waveletDepth", 0); ySize = a.getInt("vSlice", 0); xSize = a.getInt("hSlice", 0);
+      output = a.isSet("output") ? parseOutput(a.get("output")) : STREAM;
+      mode = parseMode(a.get("mode"));
+      frameRate = a.getInt("framerate", 3);
+      sliceScalar = a.getInt("scalar", 1); slicePrefix = a.getInt("prefix", 0);
+      fragmentLength = a.getInt("fragmentLength", 0); compressedBytes = a.getInt("compressedBytes", 0);
+      qIndex = a.getInt("quantIndex", 0); gpus = a.getInt("gpus", 1);
+      if (a.isSet("bitDepth") && (a.isSet("lumaDepth") || a.isSet("chromaDepth")))
+        throw std::invalid_argument("bitDepth is incompatible with luma depth (and/or chroma depth): use one or the other");
+      if (a.isSet("progressive") && a.isSet("interlace"))
+        throw std::invalid_argument("image can't be both interlaced and progressive: specify one or the other");
+      if (a.isSet("progressive") && (a.isSet("topFieldFirst") || a.isSet("bottomFieldFirst")))
+        throw std::invalid_argument("field parity is incompatible with progressive image");
+      if (a.isSet("topFieldFirst") && a.isSet("bottomFieldFirst"))
+        throw std::invalid_argument("image can't be both top field first and bottom field first: specify one or the other");
+      if (!a.isSet("bitDepth")) bitDepth = 8 * bytes;
+      if (!a.isSet("lumaDepth")) lumaDepth = bitDepth;
+      if (!a.isSet("chromaDepth")) chromaDepth = lumaDepth;
+      if (height < 1) throw std::invalid_argument("picture height must be > 0");
+      if (width < 1) throw std::invalid_argument("picture width must be > 0");
+      if (bytes < 1 || bytes > 4) throw std::invalid_argument("bytes must be in range 1 to 4");
+      if (a.isSet("bitDepth")) { if (bitDepth < 1 || bitDepth > 8 * bytes) throw std::invalid_argument("bit depth must be in range 1 to 8*(bytes per sample)"); }
+      else {
+        if (lumaDepth < 1 || lumaDepth > 8 * bytes) throw std::invalid_argument("luma bit depth must be in range 1 to 8*(bytes per sample)");
+        if (chromaDepth < 1 || chromaDepth > 8 * bytes) throw std::invalid_argument("chroma bit depth must be in range 1 to 8*(bytes per sample)");
+      }
+      if (kernel == NullKernel) throw std::invalid_argument("invalid wavelet kernel");
+      if (waveletDepth < 1) throw std::invalid_argument("wavelet depth must be 1 or more");
+      const bool hq = mode == HQ_CBR || mode == HQ_ConstQ;
+      if (!hq && a.isSet("scalar")) throw std::invalid_argument("Slice Scalar is only used in HQ_CBR and HQ_ConstQ modes");
+      if (!hq && a.isSet("prefix")) throw std::invalid_argument("Slice Prefix is only used in HQ_CBR and HQ_ConstQ modes");
+      if (mode == HQ_ConstQ && a.isSet("fragmentLength")) throw std::invalid_argument("Fragment length is only used in HQ_CBR and LD modes");
+      if (mode == HQ_ConstQ && a.isSet("compressedBytes")) throw std::invalid_argument("Compressed bytes is only used in HQ_CBR and LD modes");
+      if (mode != HQ_ConstQ && a.isSet("quantIndex")) throw std::invalid_argument("Quantisation index is only used in HQ_ConstQ mode");
+      if (mode != HQ_ConstQ && !a.isSet("compressedBytes")) throw std::invalid_argument("Compressed bytes must be set in HQ_CBR and LD modes");
+      if (mode == HQ_ConstQ && !a.isSet("quantIndex")) throw std::invalid_argument("Quantisation index must be set in HQ_ConstQ mode");
+      if (hq && sliceScalar < 1) throw std::invalid_argument("slice scalar must be >=1");
+      if (hq && slicePrefix < 0) throw std::invalid_argument("slice prefix must be >=0");
+      if (mode != HQ_ConstQ && compressedBytes < 1) throw std::invalid_argument("number of compressed bytes must be >0");
+      if (mode == HQ_ConstQ && (qIndex < 0 || qIndex > 119)) throw std::invalid_argument("quantisation index must be in the range 0 to 119");
+      if (a.isSet("interlace")) throw std::invalid_argument("interlaced coding is not supported by the MI355X tools yet (progressive only)");
+      if (gpus < 1) throw std::invalid_argument("gpus must be >= 1");
+    } catch (const std::exception &e) {
+      cerr << "Command line error: " << e.what() << endl;
+      return EXIT_FAILURE;
+    }
+    if (mode == LD) throw std::logic_error("LD encoding is obsolete and not offered by the MI355X tools (LD streams are decoded)");
+    if (fragmentLength > 0) throw std::logic_error("picture fragments are not supported by the MI355X tools yet");
+    if (lumaDepth != chromaDepth) throw std::logic_error("luma and chroma bit depths must be equal in the MI355X tools");
+
+    // ---- streams ----
+    std::ifstream inFile; std::ofstream outFile;
+    std::istream *in = &std::cin; std::ostream *out = &cout;
+    if (inFileName != "-") { inFile.open(inFileName.c_str(), std::ios::binary); if (!inFile) { perror((string("Failed to open input file \"") + inFileName + "\"").c_str()); return EXIT_FAILURE; } in = &inFile; }
+    if (outFileName != "-") { outFile.open(outFileName.c_str(), std::ios::binary); if (!outFile) { perror((string("Failed to open output file \"") + outFileName + "\"").c_str()); return EXIT_FAILURE; } out = &outFile; }
+
+    const PictureFormat format(height, width, chromaFormat);
+    if (verbose) {
+      clog << "mode= " << modeName(mode) << endl << "bytes per sample= " << bytes << endl;
+      clog << "luma depth (bits) = " << lumaDepth << endl << "chroma depth (bits) = " << chromaDepth << endl;
+      clog << "height = " << height << endl << "width = " << width << endl << "chroma format = " << chromaFormat << endl;
+      clog << "interlaced = false" << endl << "wavelet kernel = " << kernel << endl << "wavelet depth = " << waveletDepth << endl;
+      clog << "vertical slice size (in units of 2**(wavelet depth)) = " << ySize << endl;
+      clog << "horizontal slice size (in units of 2**(wavelet depth)) = " << xSize << endl;
+      clog << "compressed bytes = " << compressedBytes << endl << "output = " << outputName(output) << endl;
+    }
+    const int ySlices = sliceSizeIsValid(waveletDepth, format.lumaHeight(), format.chromaHeight(), ySize);
+    const int xSlices = sliceSizeIsValid(waveletDepth, format.lumaWidth(), format.chromaWidth(), xSize);
+    if (ySlices == 0 || xSlices == 0)
+      throw std::logic_error("The given waveletDepth, hSlice, and vSlice parameters cannot encode this input. See above for suggested parameters.");
+    const int pictureBytes = compressedBytes;
+    if (verbose) {
+      clog << "Vertical slices per picture          = " << ySlices << endl;
+      clog << "Horizontal slices per picture        = " << xSlices << endl;
+      if (mode == HQ_CBR) {
+        const utils::Rational r = utils::rationalise(pictureBytes, ySlices * xSlices);
+        clog << "Slice bytes numerator                = " << r.numerator << endl;
+        clog << "Slice bytes denominator              = " << r.denominator << endl;
+      }
+    }
+    const Array1D qMatrix = quantMatrix(kernel, waveletDepth);
+    if (verbose) {
+      clog << "Quantisation matrix = " << qMatrix[0];
+      for (std::size_t i = 1; i < qMatrix.size(); ++i) clog << ", " << qMatrix[i];
+      clog << endl;
+    }
+
+    vc2hip_picture_format pf = {width, height, (int)chromaFormat, lumaDepth, bytes};
+    vc2hip_coding_params cp = {(int)kernel, waveletDepth, ySlices, xSlices, mode == HQ_CBR ? VC2HIP_HQ_CBR : VC2HIP_HQ_CONSTQ,
+                               qIndex, pictureBytes, slicePrefix, sliceScalar};
+    const std::size_t frameBytes = (std::size_t)format.samples() * bytes;
+
+    std::vector<unsigned char> du; // output staging of the ordered writer
+    unsigned long prev_parse_offset = 0;
+    int major_version = 2;
+    if (output == STREAM) {
+      if (verbose) clog << endl << "Writing Sequence Header" << endl << endl;
+      const SequenceHeader sh(PROFILE_HQ, height, width, chromaFormat, false, (FrameRate)frameRate, true, lumaDepth);
+      const std::vector<unsigned char> body = writeSequenceHeader(sh, false, &major_version);
+      writeParseInfo(du, SEQUENCE_HEADER, body.size() + 13, prev_parse_offset);
+      prev_parse_offset = body.size() + 13;
+      du.insert(du.end(), body.begin(), body.end());
+      out->write((const char *)du.data(), (std::streamsize)du.size());
+    }
+
+    unsigned long long frame = 0;
+    bool done = false;
+    std::vector<std::vector<unsigned char> > raws((std::size_t)gpus);
+    while (!done) {
+      // read up to `gpus` frames
+      int got = 0;
+      for (; got < gpus; ++got) {
+        raws[got].resize(frameBytes);
+        if (verbose) clog << "Reading input frame number " << frame + got;
+        in->read((char *)raws[got].data(), (std::streamsize)frameBytes);
+        if ((std::size_t)in->gcount() < frameBytes) {
+          if (frame + got == 0) { cerr << "\rFailed to read input frame number 0" << endl; return EXIT_FAILURE; }
+          if (verbose) clog << "\rEnd of input reached after " << frame + got << " frames" << endl;
+          done = true;
+          break;
+        } else if (verbose) clog << endl;
+      }
+      if (got == 0) break;
+
+      if (output == STREAM) {
+        // fused picture path: frame k of this group on GPU k (EncodeStream.cpp:482-647 on the device)
+        std::vector<Encoded> enc((std::size_t)got);
+        std::vector<std::thread> th;
+        for (int g = 0; g < got; ++g)
+          th.emplace_back([&, g]() {
+            try {
+              vc2hip_ctx *c = hipContext(g);
+              enc[g].payload.resize(vc2hip_max_payload_bytes(&pf, &cp) + 64);
+              enc[g].qidx = Array2D(ySlices, xSlices);
+              std::size_t len = 0;
+              hipCheck(c, vc2hip_encode_picture_hq(c, raws[g].data(), &pf, &cp, enc[g].payload.data(), enc[g].payload.size(),
+                                                   &len, enc[g].qidx.data()));
+              enc[g].payload.resize(len);
+            } catch (const std::exception &e) { enc[g].error = e.what(); }
+          });
+        for (auto &t : th) t.join();
+        for (int g = 0; g < got; ++g) { // ordered writer: parse offsets and picture numbers chain in frame order
+          if (!enc[g].error.empty()) throw std::logic_error(enc[g].error);
+          if (verbose) clog << "Forward transform" << endl << "Quantise transform coefficients" << endl << "Writing compressed output to file" << endl;
+          const unsigned long picnum = utils::getPictureNumber(0, frame + g, 1);
+          const std::vector<unsigned char> hdr = writePictureHeaderHQ(picnum, kernel, waveletDepth, xSlices, ySlices, slicePrefix, sliceScalar, major_version);
+          du.clear();
+          const unsigned long next = (unsigned long)(hdr.size() + enc[g].payload.size() + 13);
+          writeParseInfo(du, HQ_PICTURE, next, prev_parse_offset);
+          prev_parse_offset = next;
+          du.insert(du.end(), hdr.begin(), hdr.end());
+          out->write((const char *)du.data(), (std::streamsize)du.size());
+          out->write((const char *)enc[g].payload.data(), (std::streamsize)enc[g].payload.size());
+          if (!*out) { cerr << "Failed to write output file \"" << outFileName << "\"" << endl; return EXIT_FAILURE; }
+        }
+        frame += got;
+        continue;
+      }
+
+      // diagnostic outputs: the fine-grained Library functions, one frame at a time
+      for (int g = 0; g < got; ++g, ++frame) {
+        Picture picture(format);
+        { Array2D y(format.lumaShape()), u(format.chromaShape()), v(format.chromaShape());
+          const unsigned char *p = raws[g].data();
+          unpackSamples(p, bytes, lumaDepth, true, true, y); p += y.num_elements() * bytes;
+          unpackSamples(p, bytes, chromaDepth, true, true, u); p += u.num_elements() * bytes;
+          unpackSamples(p, bytes, chromaDepth, true, true, v);
+          picture.y(y); picture.c1(u); picture.c2(v); }
+        if (verbose) clog << "Forward transform" << endl;
+        const Picture transform = waveletTransform(picture, kernel, waveletDepth);
+        if (output == TRANSFORM) { clog << "Writing transform coefficients to output file" << endl; writePicture4(*out, transform); continue; }
+        Array2D qIndices(ySlices, xSlices), sliceBytes;
+        if (mode == HQ_CBR) {
+          if (verbose) clog << "Determine quantisation indices" << endl;
+          sliceBytes = slice_bytes(ySlices, xSlices, pictureBytes, sliceScalar);
+          qIndices = quantIndicesCBR(transform, qMatrix, sliceBytes, sliceScalar);
+        } else for (std::size_t i = 0; i < qIndices.num_elements(); ++i) qIndices.data()[i] = qIndex;
+        int stats[128] = {0};
+        for (std::size_t i = 0; i < qIndices.num_elements(); ++i) ++stats[qIndices.data()[i] & 127];
+        if (output == INDICES) {
+          clog << "Writing quantisation indices to output file" << endl;
+          for (std::size_t i = 0; i < qIndices.num_elements(); ++i) out->put((char)qIndices.data()[i]);
+          continue;
+        }
+        if (verbose) clog << "Quantise transform coefficients" << endl;
+        const Picture quantised = quantise_transform_np(transform, qIndices, qMatrix);
+        if (output == QUANTISED) { clog << "Writing quantised transform coefficients to output file" << endl; writePicture4(*out, quantised); continue; }
+        if (output == PACKAGED) {
+          const std::vector<unsigned char> b = packSlicesHQ(quantised, waveletDepth, qIndices, slicePrefix, sliceScalar, mode == HQ_CBR ? &sliceBytes : nullptr);
+          out->write((const char *)b.data(), (std::streamsize)b.size());
+          continue;
+        }
+        if (verbose) clog << "Inverse quantise" << endl;
+        const Picture restored = inverse_quantise_transform_np(quantised, qIndices, qMatrix);
+        if (verbose) clog << "Inverse transform" << endl;
+        Picture decoded = inverseWaveletTransform(restored, kernel, waveletDepth, format);
+        decoded = clip(decoded, -utils::pow(2, lumaDepth - 1), utils::pow(2, lumaDepth - 1) - 1, -utils::pow(2, chromaDepth - 1), utils::pow(2, chromaDepth - 1) - 1);
+        // quantiser statistics + PSNR, EncodeStream.cpp:676-753
+        float mean = 0, meanSquare = 0;
+        const int totalSlices = ySlices * xSlices;
+        for (int z = 0; z < 128; ++z) { mean += z * stats[z]; meanSquare += z * z * stats[z]; }
+        mean /= totalSlices; meanSquare /= totalSlices;
+        const float stdDev = std::sqrt(meanSquare - mean * mean);
+        auto psnr = [](const Array2D &a, const Array2D &b, int depth) {
+          long long ss = 0;
+          for (std::size_t i = 0; i < a.num_elements(); ++i) { const int d = a.data()[i] - b.data()[i]; ss += (long long)(d * d); }
+          const float rms = std::sqrt(float(ss) / float(a.num_elements())) / utils::pow(2, depth);
+          return -20 * std::log10(rms);
+        };
+        const float yp = psnr(picture.y(), decoded.y(), lumaDepth), up = psnr(picture.c1(), decoded.c1(), chromaDepth), vp = psnr(picture.c2(), decoded.c2(), chromaDepth);
+        if (verbose) {
+          clog << std::fixed << std::setprecision(2) << "Mean, Standard Deviation of quantiser index = " << mean << ", " << stdDev << endl;
+          clog << std::fixed << std::setprecision(4) << "PSNR for Y/R, U/G, V/B = " << yp << ", " << up << ", " << vp << endl;
+        }
+        if (output == DECODED) { // wordWidth(bytes) + offset_binary, right justified (EncodeStream.cpp:756-760)
+          std::vector<unsigned char> b(frameBytes);
+          unsigned char *p = b.data();
+          packSamples(decoded.y(), bytes, lumaDepth, false, true, p); p += decoded.y().num_elements() * bytes;
+          packSamples(decoded.c1(), bytes, chromaDepth, false, true, p); p += decoded.c1().num_elements() * bytes;
+          packSamples(decoded.c2(), bytes, chromaDepth, false, true, p);
+          out->write((const char *)b.data(), (std::streamsize)b.size());
+        } else { // PSNR
+          *out << "Frame " << frame << endl << std::fixed << std::setprecision(2) << mean << " " << stdDev << endl;
+          *out << std::fixed << std::setprecision(4) << yp << " " << up << " " << vp << endl;
+        }
+      }
+    }
+    if (output == STREAM) { du.clear(); writeParseInfo(du, END_OF_SEQUENCE, 0, prev_parse_offset); out->write((const char *)du.data(), (std::streamsize)du.size()); }
+    out->flush();
+  } catch (const std::exception &ex) {
+    cout << "Error: " << ex.what() << endl; // the reference reports on standard output (EncodeStream.cpp:782-785)
+    return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,102 @@
+// hosttest -- CPU-only unit tests of the host layer, written after the reference's own gtest files
+// (/root/reference/tests/Arrays.cpp, DataUnit.cpp, Utils.cpp): same known answers, same exception strings.
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "Arrays.h"
+#include "DataUnit.h"
+#include "Utils.h"
+#include "VLC.h"
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+static std::string thrown(void (*f)()) { try { f(); } catch (const std::logic_error &e) { return e.what(); } return "<no exception>"; }
+
+int main() {
+  { // tests/Arrays.cpp:6-16
+    Array2D a(3, 7);
+    EXPECT(a.shape()[0] == 3 && a.shape()[1] == 7 && a.num_elements() == 21);
+    a[2][6] = 5;
+    Shape2D s = {{2, 9}};
+    a.resize(s);
+    EXPECT(a.shape()[0] == 2 && a.shape()[1] == 9 && a[1][8] == 0);
+  }
+  { // tests/DataUnit.cpp:18-53: parse-info known answers
+    struct { unsigned type, next, prev; DataUnitType want; } cases[] = {
+        {0x00, 0, 0, SEQUENCE_HEADER}, {0x10, 20, 20, END_OF_SEQUENCE}, {0x20, 128, 0, AUXILIARY_DATA},
+        {0x30, 0, 3245, PADDING_DATA}, {0xC8, 23, 0, LD_PICTURE}, {0xE8, 13, 13, HQ_PICTURE},
+        {0xCC, 13, 13, LD_FRAGMENT}, {0xEC, 13, 0, HQ_FRAGMENT}};
+    for (auto &c : cases) {
+      unsigned char b[13] = {'B', 'B', 'C', 'D', (unsigned char)c.type};
+      for (int i = 0; i < 4; ++i) { b[5 + i] = (unsigned char)(c.next >> (24 - 8 * i)); b[9 + i] = (unsigned char)(c.prev >> (24 - 8 * i)); }
+      const DataUnit du = readParseInfo(b);
+      EXPECT(du.type == c.want && du.next_parse_offset == c.next && du.prev_parse_offset == c.prev);
+      EXPECT(du.length() == (int)c.next - 13);
+    }
+    EXPECT(thrown([] { const unsigned char b[13] = {'A', 'B', 'C', 'D'}; readParseInfo(b); }) ==
+           "Read bytes do not match expected parse_info_header.");
+    EXPECT(thrown([] { const unsigned char b[13] = {'B', 'B', 'C', 'D', 0xFF}; readParseInfo(b); }) ==
+           "Stream Error: Unknown data unit type.");
+    // writer is the inverse
+    std::vector<unsigned char> w;
+    writeParseInfo(w, HQ_PICTURE, 0x01020304, 17);
+    const DataUnit du = readParseInfo(w.data());
+    EXPECT(w.size() == 13 && du.type == HQ_PICTURE && du.next_parse_offset == 0x01020304 && du.prev_parse_offset == 17);
+  }
+  { // tests/DataUnit.cpp:93-102
+    const SequenceHeader t = getDefaultSourceParameters(4);
+    EXPECT(t.width == 352 && t.height == 288 && t.chromaFormat == CF420 && t.frameRate == FR25_2 && t.bitdepth == 8);
+  }
+  { // tests/Utils.cpp:11-56
+    EXPECT(utils::getPictureNumber(0, 0, 1) == 0 && utils::getPictureNumber(1, 0, 1) == 1 && utils::getPictureNumber(2, 0, 2) == 2);
+    EXPECT(utils::getPictureNumber(1, 1, 1) == 2 && utils::getPictureNumber(2, 1, 2) == 4 && utils::getPictureNumber(1, 2, 2) == 5);
+    EXPECT(utils::getPictureNumber(0, (1ULL << 32) - 1, 1) == (1ULL << 32) - 1 && utils::getPictureNumber(0, 1ULL << 32, 1) == 0);
+    EXPECT(thrown([] { utils::getPictureNumber(-5, 0, 1); }) == "field number should be positive");
+    EXPECT(thrown([] { utils::getPictureNumber(2, 0, 1); }) == "field number exceeds number of fields per frame");
+    EXPECT(thrown([] { utils::getPictureNumber(0, 0, 3); }) == "number of fields per frame should be 1 (progressive) or 2 (interlaced)");
+    EXPECT(utils::intlog2(1) == 0 && utils::intlog2(2) == 1 && utils::intlog2(3) == 2 && utils::intlog2(993) == 10);
+    EXPECT(utils::rationalise(8294400, 16200).numerator == 512 && utils::rationalise(8294400, 16200).denominator == 1);
+  }
+  { // sequence header write -> parse round trip over formats that hit every branch of the matcher
+    struct { int h, w; ColourFormat cf; FrameRate fr; int bd; } fm[] = {
+        {1080, 1920, CF422, FR25, 10}, {2160, 3840, CF422, FR25, 10}, {2160, 3840, CF422, FR50, 10},
+        {4320, 7680, CF444, FR25, 12}, {288, 352, CF420, FR25_2, 8}, {1080, 2048, CF444, FR48, 12},
+        {100, 174, CF420, FR30, 8}, {1080, 1920, CF422, FR120, 10}, {720, 1280, CF422, FR50, 16}};
+    for (auto &f : fm) {
+      const SequenceHeader in(PROFILE_HQ, f.h, f.w, f.cf, false, f.fr, true, f.bd);
+      int major = 0;
+      const std::vector<unsigned char> b = writeSequenceHeader(in, false, &major);
+      std::size_t used = 0;
+      const SequenceHeader out = readSequenceHeader(b.data(), b.size(), &used);
+      EXPECT(used == b.size());
+      EXPECT(out.height == f.h && out.width == f.w && out.chromaFormat == f.cf && out.bitdepth == f.bd);
+      EXPECT(out.frameRate == f.fr && !out.interlace && out.profile == PROFILE_HQ && out.major_version == major);
+    }
+    // cfg 1 of the benchmark: 4 coded bytes, base format 12 + custom scan format
+    int major = 0;
+    const std::vector<unsigned char> b = writeSequenceHeader(SequenceHeader(PROFILE_HQ, 1080, 1920, CF422, false, FR25, true, 10), false, &major);
+    EXPECT(b.size() == 4 && major == 2);
+  }
+  { // picture header round trip, v2 and v3
+    for (int major = 2; major <= 3; ++major) {
+      const std::vector<unsigned char> b = writePictureHeaderHQ(0xDEADBEEF, DD97, 4, 120, 135, 2, 3, major);
+      unsigned long pn; PicturePreamble pre;
+      const std::size_t used = readPictureHeader(b.data(), b.size(), false, major, &pn, &pre);
+      EXPECT(used == b.size() && pn == 0xDEADBEEF && pre.wavelet_kernel == DD97 && pre.depth == 4);
+      EXPECT(pre.slices_x == 120 && pre.slices_y == 135 && pre.slice_prefix == 2 && pre.slice_size_scalar == 3);
+    }
+  }
+  { // exp-Golomb header fields
+    BitWriter w;
+    for (unsigned v : {0u, 1u, 2u, 7u, 1920u, 65535u}) w.putUnsignedVLC(v);
+    w.align();
+    BitReader r(w.bytes().data(), w.bytes().size());
+    for (unsigned v : {0u, 1u, 2u, 7u, 1920u, 65535u}) EXPECT(r.getUnsignedVLC() == v);
+  }
+  if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
+  std::printf("all host tests passed\n");
+  return 0;
+}
