@@ -57,10 +57,10 @@ def test_stream_roundtrip_matches_oracle(tools, oracle, tmp_path, kernel):
 def test_cbr_stream_and_8bit(tools, oracle, tmp_path):
     w, h = 256, 128
     raw = synth(w, h, "420", 8, 52, frames=2, word_bytes=1)
-    p = make_params(w, h, "420", 8, "LeGall", 3, 1, 2, mode="HQ_CBR", s=20000, scalar=2, word_bytes=1)
+    p = make_params(w, h, "420", 8, "LeGall", 3, 2, 2, mode="HQ_CBR", s=20000, scalar=2, word_bytes=1)
     want = oracle.encode_stream(p, raw, 2)
     (tmp_path / "in.raw").write_bytes(raw)
-    run("EncodeStream", *enc_args(w, h, "420", 8, "LeGall", 3, 1, 2, mode="HQ_CBR", s=20000, scalar=2, n=1), tmp_path / "in.raw", tmp_path / "o.vc2")
+    run("EncodeStream", *enc_args(w, h, "420", 8, "LeGall", 3, 2, 2, mode="HQ_CBR", s=20000, scalar=2, n=1), tmp_path / "in.raw", tmp_path / "o.vc2")
     assert (tmp_path / "o.vc2").read_bytes() == want
     run("DecodeStream", tmp_path / "o.vc2", tmp_path / "d.raw")
     assert (tmp_path / "d.raw").read_bytes() == oracle.decode_stream(p, want, 2)[0]
@@ -91,10 +91,10 @@ def test_diagnostic_outputs_match_oracle(tools, oracle, tmp_path):
     got = _planes_be4((tmp_path / "t.bin").read_bytes(), [a.shape for a in t])
     assert all(np.array_equal(a, b) for a, b in zip(got, t))
     qm = oracle.quant_matrix(k, depth)
-    sb = oracle.slice_bytes(8, 4, 6000, 1)
+    sb = oracle.slice_bytes(8, 8, 6000, 1)
     qi = oracle.cbr_qindices(t[0], t[1], t[2], depth, qm, sb, 1)
     run("EncodeStream", *base, "-o", "Indices", tmp_path / "in.raw", tmp_path / "i.bin")
-    assert np.array_equal(np.frombuffer((tmp_path / "i.bin").read_bytes(), np.uint8).reshape(8, 4), qi)
+    assert np.array_equal(np.frombuffer((tmp_path / "i.bin").read_bytes(), np.uint8).reshape(8, 8), qi)
     q = [oracle.quantise_np(a, depth, qi, qm) for a in t]
     run("EncodeStream", *base, "-o", "Quantised", tmp_path / "in.raw", tmp_path / "q.bin")
     got = _planes_be4((tmp_path / "q.bin").read_bytes(), [a.shape for a in q])
@@ -106,7 +106,7 @@ def test_diagnostic_outputs_match_oracle(tools, oracle, tmp_path):
     got = _planes_be4((tmp_path / "dq.bin").read_bytes(), [a.shape for a in q])
     assert all(np.array_equal(a, b) for a, b in zip(got, q))
     run("DecodeStream", "-o", "Indices", tmp_path / "s.vc2", tmp_path / "di.bin")
-    assert np.array_equal(np.frombuffer((tmp_path / "di.bin").read_bytes(), np.uint8).reshape(8, 4), qi)
+    assert np.array_equal(np.frombuffer((tmp_path / "di.bin").read_bytes(), np.uint8).reshape(8, 8), qi)
     run("DecodeStream", "-o", "Transform", tmp_path / "s.vc2", tmp_path / "dt.bin")
     want = [oracle.dequantise_np(a, depth, qi, qm) for a in q]
     got = _planes_be4((tmp_path / "dt.bin").read_bytes(), [a.shape for a in want])
