@@ -26,17 +26,20 @@ void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s) {
 // scalar helpers
 // ------------------------------------------------------------------------------------------
 // Quantisation.cpp:69-76
-__device__ __forceinline__ int quant_dev(int v, int aq) {
-  const int qf = c_qs.qf[aq];
+// |v| << 2 divided by qf: exact reciprocal multiply inside the reference's domain (qf > 0, no int
+// overflow); outside it the literal int division.  The slow branch is taken wave-uniformly so that
+// the 25-instruction division sequence is not if-converted into the common path.
+__device__ __forceinline__ int quant_core(int v, int qf, unsigned mg, int sh) {
   const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-  int a = (int)(mag << 2);
-  if (qf > 1 && a >= 0) { // exact reciprocal multiply (the reference's domain); else the literal int division
-    const unsigned n = (unsigned)a, t = __umulhi(c_qs.magic[aq], n);
-    a = (int)((t + ((n - t) >> 1)) >> c_qs.shift[aq]);
-  } else {
-    a /= qf;
-  }
-  return v < 0 ? (int)(0u - (unsigned)a) : a;
+  const int a = (int)(mag << 2);
+  const unsigned t = __umulhi(mg, (unsigned)a);
+  int q = (int)((t + (((unsigned)a - t) >> 1)) >> sh);
+  const bool slow = !(qf > 1 && a >= 0);
+  if (__any(slow)) { if (slow) q = a / qf; }
+  return v < 0 ? (int)(0u - (unsigned)q) : q;
+}
+__device__ __forceinline__ int quant_dev(int v, int aq) {
+  return quant_core(v, c_qs.qf[aq], c_qs.magic[aq], c_qs.shift[aq]);
 }
 // band index of coefficient j when n0 is (usually) a power of two: no integer division
 __device__ __forceinline__ int band_of_index_fast(int j, int n0, int n0_shift) {
@@ -163,14 +166,19 @@ __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, con
 // merges their codes in registers and ORs whole words into the image.
 // ------------------------------------------------------------------------------------------
 struct Coef8 {
-  int v[8], nb[8];
+  unsigned code[8]; // exp-Golomb code of each coefficient (right aligned)
+  int nb[8];        // its length in bits (0: past the end of the component)
   int sum, last_end;
 };
+// (code << 6 | length) of the signed exp-Golomb code of +m for m < 256, built per workgroup in LDS
+__device__ __forceinline__ void build_vlc_lut(unsigned *lut) {
+  for (int m = threadIdx.x; m < 256; m += blockDim.x) lut[m] = (svlc_code(m) << 6) | (unsigned)svlc_bits(m);
+}
 
 // load (and quantise) the 8 coefficients [j0, j0+8) of a component record
 template <bool QUANT>
 __device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int n, int n0, int n0_shift, int q,
-                                      const int *qm, unsigned *err) {
+                                      const int *qm, unsigned *err, const unsigned *lut) {
   c.sum = 0;
   c.last_end = 0;
   int raw[8];
@@ -194,14 +202,7 @@ __device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int 
         const int qf = c_qs.qf[aq], sh = c_qs.shift[aq];
         const unsigned mg = c_qs.magic[aq];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int v = raw[k];
-          const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-          int a = (int)(mag << 2);
-          if (qf > 1 && a >= 0) { const unsigned t = __umulhi(mg, (unsigned)a); a = (int)((t + (((unsigned)a - t) >> 1)) >> sh); }
-          else a /= qf;
-          raw[k] = v < 0 ? (int)(0u - (unsigned)a) : a;
-        }
+        for (int k = 0; k < 8; ++k) raw[k] = quant_core(raw[k], qf, mg, sh);
       }
     } else {
 #pragma unroll
@@ -213,17 +214,34 @@ __device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int 
       }
     }
   }
+  bool big = false;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    int nb = 0;
-    if (j0 + k < n) {
-      nb = svlc_bits(raw[k]);
-      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); raw[k] = 0; nb = 1; }
+    const int v = raw[k];
+    const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    const unsigned e = lut[mag & 255u];           // positive code; a negative value sets the sign (last) bit
+    c.code[k] = (e >> 6) | (v < 0 ? 1u : 0u);
+    c.nb[k] = j0 + k < n ? (int)(e & 63u) : 0;
+    big |= mag > 255u;
+  }
+  if (__any(big)) { // rare: coefficients beyond the table
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int v = raw[k];
+      const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+      if (mag > 255u && j0 + k < n) {
+        int nb = svlc_bits(v);
+        unsigned code = svlc_code(v);
+        if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; code = 1; raw[k] = 0; }
+        c.nb[k] = nb;
+        c.code[k] = code;
+      }
     }
-    c.v[k] = raw[k];
-    c.nb[k] = nb;
-    c.sum += nb;
-    if (raw[k] != 0) c.last_end = c.sum;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    c.sum += c.nb[k];
+    if (raw[k] != 0 && c.nb[k]) c.last_end = c.sum;
   }
 }
 
@@ -236,7 +254,7 @@ __device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const 
   for (int k = 0; k < 8; ++k) {
     const int nb = c.nb[k];
     if (nb != 0 && pos + nb <= limit) { // once one code is past the limit, every later one is too
-      acc |= (unsigned long long)svlc_code(c.v[k]) << (64 - fill - nb);
+      acc |= (unsigned long long)c.code[k] << (64 - fill - nb);
       fill += nb;
       if (fill >= 32) {
         atomicOr(&img[wi], (unsigned)(acc >> 32));
@@ -263,8 +281,10 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
   unsigned *img = lds_u + wave * img_words;
+  unsigned *lut = lds_u + 4 * img_words;
   const bool active = slice < p.n_slices;
   for (int i = lane; i < img_words; i += 64) img[i] = 0;
+  build_vlc_lut(lut);
   __syncthreads();
 
   int bytes[3] = {0, 0, 0};
@@ -293,8 +313,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       { // luma: one round
         const int n = p.comp_n[0], n0 = p.comp_n0[0];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        if (p.quantise) load8<true>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
-        else load8<false>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+        if (p.quantise) load8<true>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
         const int incl = wave_incl_scan(c.sum, lane);
         const int count = wave_max(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
@@ -306,8 +326,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int n = p.comp_n[1], n0 = p.comp_n0[1];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
         const int half = lane >> 5, cc = 1 + half;
-        if (p.quantise) load8<true>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err);
-        else load8<false>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err);
+        if (p.quantise) load8<true>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
         const int incl = wave_incl_scan(c.sum, lane);
         const int total_u = __shfl(incl, 31);
         const int rel = incl - c.sum - (half ? total_u : 0);
@@ -327,8 +347,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         Coef8 c;
         int run = 0, count = 0;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
-          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           count = max(count, wave_max(c.last_end ? run + incl - c.sum + c.last_end : 0));
           run += __shfl(incl, 63);
@@ -337,8 +357,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         if (cc == 2) bytes[2] = cbr_v(bytes[2]);
         run = 0;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
-          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err);
+          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           write8(img, 8 * (base + 1) + run + incl - c.sum, 8 * (base + 1 + bytes[cc]), c);
           run += __shfl(incl, 63);
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
 
 void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s) {
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
-  const size_t lds = (size_t)4 * img_words * 4;
+  const size_t lds = (size_t)4 * img_words * 4 + 256 * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   vc2_prof_begin(L, "hq_pack", s);
