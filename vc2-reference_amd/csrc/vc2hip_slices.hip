@@ -661,7 +661,8 @@ __device__ __forceinline__ unsigned compact_even32(unsigned x) {
   return x;
 }
 
-constexpr int UNP_PITCH = 20; // ints per staging row: 16 coefficients, 16-byte aligned rows
+constexpr int UNP_N = 32;     // coefficients staged per lane and round: 128-byte runs = whole cache lines
+constexpr int UNP_PITCH = 36; // ints per staging row, 16-byte aligned rows
 
 __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
@@ -697,13 +698,11 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     outp[wave][lane] = (unsigned long long)out;
     if (active) br.init(data, (int)len); else br.init_ones();
   }
-  for (int base = 0; base < n; base += 16) {
-    const int room = min(16, n - base);
+  for (int base = 0; base < n; base += UNP_N) {
+    const int room = min(UNP_N, n - base);
     // zero coefficients are the common case: clear the row, then only non-zero values are stored
-    *(int4 *)(st) = make_int4(0, 0, 0, 0);
-    *(int4 *)(st + 4) = make_int4(0, 0, 0, 0);
-    *(int4 *)(st + 8) = make_int4(0, 0, 0, 0);
-    *(int4 *)(st + 12) = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < UNP_N; k += 4) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
     int cnt = 0;
     while (cnt < room) {
       const unsigned long long win = br.peek();
@@ -744,8 +743,8 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     __syncthreads();
     const int *sw = stage[wave];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 16 + (lane >> 2), c = (lane & 3) * 4;
+    for (int j = 0; j < 8; ++j) { // 8 lanes x 16 bytes = one 128-byte line of one component per instruction
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
       int32_t *dst = (int32_t *)outp[wave][r];
       if (dst && c < room) *(int4 *)(dst + base + c) = *(const int4 *)(sw + r * UNP_PITCH + c);
     }
