@@ -14,6 +14,7 @@
 void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s);
 int vc2_halo_x(int kernel);
 int vc2_halo_y(int kernel);
+bool vc2_slice_index_supported(int prefix, int scalar);
 void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
 bool vc2_fast_level_applicable(LevelParams &p);
 int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, hipStream_t s);
@@ -88,6 +89,7 @@ struct vc2hip_ctx {
   // cached CBR / LD slice-size tables (re-uploaded only when the parameters change)
   int cbr_key[5] = {-1, -1, -1, -1, -1};
   uint64_t cbr_total = 0;
+  int debug_skip = 0;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
 };
 
@@ -215,6 +217,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   vc2hip_ctx *c = new vc2hip_ctx;
   c->device = device;
   { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
+  { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
   c->stream = stream;
@@ -434,6 +437,7 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
       p.sample_offset = 1 << (f->bit_depth - 1);
     }
     LevelParams pf = p;
+    pf.debug_skip = c->debug_skip;
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
       int rc = vc2_launch_forward_fast(c->L, kernel, first, pf, n, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -471,6 +475,7 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, int32_t 
       p.clip_hi = (1 << (f->bit_depth - 1)) - 1;
     }
     LevelParams pf = p;
+    pf.debug_skip = c->debug_skip;
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
       int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -734,6 +739,8 @@ extern "C" int vc2hip_hq_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u,
 static int build_index(vc2hip_ctx *c, const uint8_t *d_pay, long long stride, const unsigned long long *d_lens, int n, int ns,
                        int prefix, int scalar, uint32_t **d_offs_out) {
   uint32_t *d_offs; void *ws;
+  if (!vc2_slice_index_supported(prefix, scalar))
+    return set_err(c, VC2HIP_EINVAL, "slice prefix / size scalar too large for the device slice index (prefix + 765 * scalar must be < 8188)");
   NEED(c, B_OFFS, (size_t)n * ns * 4, d_offs);
   const size_t wsb = vc2_slice_index_workspace(n, (size_t)stride, prefix, scalar);
   NEED(c, B_INDEX, wsb, ws);

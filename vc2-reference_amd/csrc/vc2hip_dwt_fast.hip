@@ -231,6 +231,7 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
       const int r = id / (WX / 8), ch = id - r * (WX / 8);
       const int gy = y0 - HY + r, gx0 = x0 - HX + 8 * ch;
       if (gy < 0 || gy >= in_h || gx0 + 8 <= 0 || gx0 >= in_w) continue;
+      if (p.debug_skip & 1) continue;
       int s[8];
       if constexpr (FIRST) {
         const int sy = min(gy, pic_h - 1);
@@ -281,8 +282,10 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
     // window rows gy in [0,in_h): stack index rr = rp*WYP + i, row r = 2*i + rp.  Rows outside the
     // plane are skipped (the vertical pass replicates across the plane edge itself).
     constexpr int NITH = (2 * C::WYP * 16 + NT - 1) / NT;
+    if (!(p.debug_skip & 2)) {
     h_pass<K, false, NITH>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
     v_pass<K, false, 1>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+    }
   }
 
   // ---- write the four bands of the core
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
   const int s_y0 = y0 / fh, s_x0 = x0 / fw;
   int32_t *store = p.store + (size_t)pic * p.store_stride;
   const int *core = lds + (HY / 2) * WXP + HX / 2;
+  if (p.debug_skip & 4) return;
 #pragma unroll 1
   for (int band = 0; band < 4; ++band) {
     const int *src = core + band * C::PLANE;

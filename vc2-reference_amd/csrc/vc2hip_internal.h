@@ -101,6 +101,7 @@ struct LevelParams {
   int ll_to_store;            // forward, last level: LL goes to store band 0
   int dequant;                // inverse: apply scale() to store values
   unsigned *err;              // device error flags
+  int debug_skip;             // timing experiments only (VC2HIP_DEBUG_SKIP): 1 no loads, 2 no lifting, 4 no stores
   int qmatrix[VC2_MAX_BANDS];
 };
 
