@@ -663,8 +663,9 @@ __device__ __forceinline__ unsigned compact_even32(unsigned x) {
   return x;
 }
 
-constexpr int UNP_N = 32;     // coefficients staged per lane and round: 128-byte runs = whole cache lines
-constexpr int UNP_PITCH = 36; // ints per staging row, 16-byte aligned rows
+constexpr int UNP_N = 16;     // coefficients staged per lane and round (64-byte runs; 32 = whole 128-byte lines
+                              // halves the read-for-ownership traffic but costs occupancy: measured slower)
+constexpr int UNP_PITCH = 20; // ints per staging row, 16-byte aligned rows
 
 __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
@@ -744,9 +745,10 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     // flush: 4 lanes x 16 bytes per component run (trip counts are uniform across the workgroup)
     __syncthreads();
     const int *sw = stage[wave];
+    constexpr int LPR = UNP_N / 4; // lanes per component run
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { // 8 lanes x 16 bytes = one 128-byte line of one component per instruction
-      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
+    for (int j = 0; j < LPR; ++j) {
+      const int r = j * (64 / LPR) + lane / LPR, c = (lane % LPR) * 4;
       int32_t *dst = (int32_t *)outp[wave][r];
       if (dst && c < room) *(int4 *)(dst + base + c) = *(const int4 *)(sw + r * UNP_PITCH + c);
     }
