@@ -663,11 +663,11 @@ __device__ __forceinline__ unsigned compact_even32(unsigned x) {
   return x;
 }
 
-constexpr int UNP_N = 16;     // coefficients staged per lane and round (64-byte runs; 32 = whole 128-byte lines
-                              // halves the read-for-ownership traffic but costs occupancy: measured slower)
-constexpr int UNP_PITCH = 20; // ints per staging row, 16-byte aligned rows
-
+// UNP_N coefficients are staged per lane and round: 16 = 64-byte runs, 32 = whole 128-byte lines (no
+// read-for-ownership of the other half line, but twice the LDS).
+template <int UNP_N>
 __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
+  constexpr int UNP_PITCH = UNP_N + 4; // ints per staging row, 16-byte aligned rows
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
   __shared__ unsigned long long outp[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -758,7 +758,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "hq_unpack", s);
-  hipLaunchKernelGGL(k_hq_unpack, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 0; }(); // A/B on MI355X: 64-byte runs 0.75 ms, 128-byte 0.80 ms per 16 pictures
+  if (wide) hipLaunchKernelGGL(k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_hq_unpack<16>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
 
