@@ -14,6 +14,7 @@
 void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s);
 int vc2_halo_x(int kernel);
 int vc2_halo_y(int kernel);
+void vc2_upload_vlc_lut(hipStream_t s);
 bool vc2_slice_index_supported(int prefix, int scalar);
 void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
 bool vc2_fast_level_applicable(LevelParams &p);
@@ -230,6 +231,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   vc2_upload_tables(t, c->stream);
   vc2_upload_tables_slices(t, c->stream);
   vc2_upload_tables_fast(t, c->stream);
+  vc2_upload_vlc_lut(c->stream);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   *out = c;
   return VC2HIP_OK;

@@ -124,6 +124,7 @@ struct PackParams {
   long long payload_stride;
   unsigned *err;
   int quantise;               // 0: store already holds quantised values (fine-grained API)
+  int debug_skip;             // timing experiments only (VC2HIP_DEBUG_PACK): 1 no code writes, 2 no copy-out
 };
 
 struct UnpackParams {

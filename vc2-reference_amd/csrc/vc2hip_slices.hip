@@ -172,10 +172,32 @@ struct Coef8 {
   int nb[8];        // its length in bits (0: past the end of the component)
   int sum, last_end;
 };
-// (code << 6 | length) of the signed exp-Golomb code of +m for m < 256, built per workgroup in LDS
+// (code << 6 | length) of the signed exp-Golomb code of +m for m < VLC_LUT_N: computed once on the
+// host, kept in device memory, copied into LDS by every pack workgroup (16 KiB).  Larger magnitudes
+// (up to the reference's 65534 limit) take the arithmetic path.
+constexpr int VLC_LUT_N = 4096;
+__device__ unsigned g_vlc_lut[VLC_LUT_N];
 __device__ __forceinline__ void build_vlc_lut(unsigned *lut) {
-  for (int m = threadIdx.x; m < 256; m += blockDim.x) lut[m] = (svlc_code(m) << 6) | (unsigned)svlc_bits(m);
+  for (int m = threadIdx.x * 4; m < VLC_LUT_N; m += blockDim.x * 4) *(uint4 *)(lut + m) = *(const uint4 *)(g_vlc_lut + m);
 }
+void vc2_upload_vlc_lut(hipStream_t s) {
+  static unsigned host[VLC_LUT_N];
+  for (unsigned m = 0; m < (unsigned)VLC_LUT_N; ++m) {
+    unsigned code = 1, nb = 1;
+    if (m) {
+      const unsigned v = m + 1;
+      int k = 31;
+      while (!((v >> k) & 1u)) --k;
+      code = 0;
+      for (int b = k - 1; b >= 0; --b) code = (code << 2) | ((v >> b) & 1u);
+      code = ((code << 1) | 1u) << 1; // terminator, then sign bit 0
+      nb = 2 * (unsigned)k + 2;
+    }
+    host[m] = (code << 6) | nb;
+  }
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_vlc_lut), host, sizeof host, 0, hipMemcpyHostToDevice, s);
+}
+__device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, unsigned *err, const unsigned *lut);
 
 // load (and quantise) the 8 coefficients [j0, j0+8) of a component record
 template <bool QUANT>
@@ -216,22 +238,27 @@ __device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int 
       }
     }
   }
+  codes8(c, raw, j0, n, err, lut);
+}
+
+// exp-Golomb codes + lengths of eight quantised values (table for |v| < 256, computed beyond)
+__device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, unsigned *err, const unsigned *lut) {
   bool big = false;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int v = raw[k];
     const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-    const unsigned e = lut[mag & 255u];           // positive code; a negative value sets the sign (last) bit
+    const unsigned e = lut[mag & (VLC_LUT_N - 1)]; // positive code; a negative value sets the sign (last) bit
     c.code[k] = (e >> 6) | (v < 0 ? 1u : 0u);
     c.nb[k] = j0 + k < n ? (int)(e & 63u) : 0;
-    big |= mag > 255u;
+    big |= mag >= (unsigned)VLC_LUT_N;
   }
   if (__any(big)) { // rare: coefficients beyond the table
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int v = raw[k];
       const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-      if (mag > 255u && j0 + k < n) {
+      if (mag >= (unsigned)VLC_LUT_N && j0 + k < n) {
         int nb = svlc_bits(v);
         unsigned code = svlc_code(v);
         if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; code = 1; raw[k] = 0; }
@@ -247,9 +274,39 @@ __device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int 
   }
 }
 
+// Table-driven variant for the common geometry (component <= 512 coefficients): the subband of every
+// coefficient index comes from a per-workgroup byte table, the quantiser constants of every subband
+// from a per-slice table, both in LDS -- no per-coefficient band arithmetic, no divergence between
+// lanes whose eight coefficients straddle subbands and lanes whose do not.
+__device__ __forceinline__ void load8_tab(Coef8 &c, const int32_t *src, int j0, int n, const unsigned char *band_lut,
+                                          const uint4 *qtab, unsigned *err, const unsigned *lut) {
+  c.sum = 0;
+  c.last_end = 0;
+  int raw[8];
+  if (j0 + 8 <= n) {
+    const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
+    raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w;
+    const uint2 bands = *(const uint2 *)(band_lut + j0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned b = ((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu;
+      const uint4 t = qtab[b];
+      raw[k] = quant_core(raw[k], (int)t.z, t.x, (int)t.y);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      raw[k] = 0;
+      if (j0 + k < n) { const uint4 t = qtab[band_lut[j0 + k]]; raw[k] = quant_core(src[j0 + k], (int)t.z, t.x, (int)t.y); }
+    }
+  }
+  codes8(c, raw, j0, n, err, lut);
+}
+
 // merge the lane's codes and OR them into the image at absolute bit position pos (codes that
 // would cross `limit` are dropped: by construction they are trailing '1's, VLC.cpp:151-156)
-__device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const Coef8 &c) {
+__device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const Coef8 &c, bool skip = false) {
+  if (skip) return;
   int wi = pos >> 5, fill = pos & 31;
   unsigned long long acc = 0;
 #pragma unroll
@@ -284,9 +341,23 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
   unsigned *img = lds_u + wave * img_words;
   unsigned *lut = lds_u + 4 * img_words;
+  unsigned char *band_y = (unsigned char *)(lut + VLC_LUT_N), *band_c = band_y + 512;
+  uint4 *qtab = (uint4 *)(band_c + 256) + wave * 32;
   const bool active = slice < p.n_slices;
+  const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2];
   for (int i = lane; i < img_words; i += 64) img[i] = 0;
   build_vlc_lut(lut);
+  if (fast && p.quantise) {
+    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
+    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
+    for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
+    for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+    if (active && lane < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
+      const int aq = max(p.qidx[(size_t)pic * p.n_slices + slice] - p.qmatrix[lane], 0);
+      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[lane] = make_uint4(0u, 0u, 0x40000000u, 0u); }
+      else qtab[lane] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], 0u);
+    }
+  }
   __syncthreads();
 
   int bytes[3] = {0, 0, 0};
@@ -309,18 +380,17 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       return vb;
     };
     int base = p.prefix + 1; // byte offset of the next component's length byte
-    const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2];
     if (fast) {
       Coef8 c;
       { // luma: one round
         const int n = p.comp_n[0], n0 = p.comp_n0[0];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        if (p.quantise) load8<true>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        if (p.quantise) load8_tab(c, rec + p.comp_off[0], lane * 8, n, band_y, qtab, p.err, lut);
         else load8<false>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
         const int incl = wave_incl_scan(c.sum, lane);
         const int count = wave_max(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
-        write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c);
+        write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, p.debug_skip & 1);
         if (lane == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
         base += 1 + bytes[0];
       }
@@ -328,7 +398,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int n = p.comp_n[1], n0 = p.comp_n0[1];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
         const int half = lane >> 5, cc = 1 + half;
-        if (p.quantise) load8<true>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        if (p.quantise) load8_tab(c, rec + p.comp_off[cc], (lane & 31) * 8, n, band_c, qtab, p.err, lut);
         else load8<false>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
         const int incl = wave_incl_scan(c.sum, lane);
         const int total_u = __shfl(incl, 31);
@@ -337,7 +407,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         bytes[1] = comp_len(__shfl(cnt, 0));
         bytes[2] = cbr_v(comp_len(__shfl(cnt, 32)));
         const int base_c = half ? base + 1 + bytes[1] : base;
-        write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c);
+        write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, p.debug_skip & 1);
         if (lane == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
         if (lane == 32) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
       }
@@ -372,7 +442,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     if (lane == 0) put_byte(img, p.prefix, (unsigned)q & 0xFF);
   }
   __syncthreads();
-  if (!active) return;
+  if (!active || (p.debug_skip & 2)) return;
 
   const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
   if (p.cbr_bytes) {
@@ -386,9 +456,11 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   }
 }
 
-void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s) {
+void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
+  PackParams p = p0;
+  { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
-  const size_t lds = (size_t)4 * img_words * 4 + 256 * 4;
+  const size_t lds = (size_t)4 * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * 32 * 16;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   vc2_prof_begin(L, "hq_pack", s);
