@@ -223,23 +223,51 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
   const int in_h = p.in_h[comp], in_w = p.in_w[comp];
   const int y0 = min(tile_y * TY, in_h - TY), x0 = min(tile_x * TX, in_w - TX);
 
-  // ---- stage tile + halo: 8 samples per item, split into even / odd column planes
+  // ---- stage tile + halo: 8 samples per item, split into even / odd column planes.
+  // All 16-byte loads of a thread are issued first (NLD in flight), then converted: one memory
+  // latency per tile instead of one per item.
   {
     const int pic_h = p.pic_h[comp], pic_w = p.pic_w[comp];
     const bool vec_ok = FIRST ? (p.word_bytes == 2 && (pic_w & 7) == 0) : ((in_w & 3) == 0);
-    for (int id = threadIdx.x; id < WY * (WX / 8); id += NT) {
+    constexpr int NLD = (WY * (WX / 8) + NT - 1) / NT;
+    uint4 va[NLD], vb[NLD]; // FIRST: va = 8 samples; else va, vb = 4 + 4 coefficients
+    int kind[NLD];          // 0 skip, 1 vector data loaded, 2 element-wise path
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int id = it * NT + threadIdx.x;
+      kind[it] = 0;
+      va[it] = make_uint4(0, 0, 0, 0);
+      vb[it] = make_uint4(0, 0, 0, 0);
+      if (id >= WY * (WX / 8) || (p.debug_skip & 1)) continue;
       const int r = id / (WX / 8), ch = id - r * (WX / 8);
       const int gy = y0 - HY + r, gx0 = x0 - HX + 8 * ch;
       if (gy < 0 || gy >= in_h || gx0 + 8 <= 0 || gx0 >= in_w) continue;
-      if (p.debug_skip & 1) continue;
+      if constexpr (FIRST) {
+        if (vec_ok && gx0 >= 0 && gx0 + 8 <= pic_w) {
+          const uint8_t *row = (const uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] +
+                               (size_t)min(gy, pic_h - 1) * pic_w * 2;
+          va[it] = *(const uint4 *)(row + (size_t)gx0 * 2);
+          kind[it] = 1;
+        } else kind[it] = 2;
+      } else {
+        if (vec_ok && gx0 >= 0 && gx0 + 8 <= in_w) {
+          const int32_t *row = (const int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w;
+          va[it] = *(const uint4 *)(row + gx0);
+          vb[it] = *(const uint4 *)(row + gx0 + 4);
+          kind[it] = 1;
+        } else kind[it] = 2;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      if (kind[it] == 0) continue;
+      const int id = it * NT + threadIdx.x;
+      const int r = id / (WX / 8), ch = id - r * (WX / 8);
+      const int gy = y0 - HY + r, gx0 = x0 - HX + 8 * ch;
       int s[8];
       if constexpr (FIRST) {
-        const int sy = min(gy, pic_h - 1);
-        const uint8_t *row = (const uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] +
-                             (size_t)sy * pic_w * p.word_bytes;
-        if (vec_ok && gx0 >= 0 && gx0 + 8 <= pic_w) {
-          const uint4 v = *(const uint4 *)(row + (size_t)gx0 * 2);
-          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+        if (kind[it] == 1) {
+          const unsigned wv[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const unsigned b = __builtin_bswap32(wv[k]);
@@ -247,6 +275,8 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
             s[2 * k + 1] = (int)(b & 0xFFFFu);
           }
         } else {
+          const uint8_t *row = (const uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] +
+                               (size_t)min(gy, pic_h - 1) * pic_w * p.word_bytes;
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const int sx = min(max(gx0 + k, 0), pic_w - 1);
@@ -259,11 +289,11 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) s[k] = (int)((unsigned)((int)((unsigned)s[k] >> p.sample_shift) - p.sample_offset) << ACC);
       } else {
-        const int32_t *row = (const int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w;
-        if (vec_ok && gx0 >= 0 && gx0 + 8 <= in_w) {
-          const int4 a = *(const int4 *)(row + gx0), b = *(const int4 *)(row + gx0 + 4);
-          s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+        if (kind[it] == 1) {
+          s[0] = (int)va[it].x; s[1] = (int)va[it].y; s[2] = (int)va[it].z; s[3] = (int)va[it].w;
+          s[4] = (int)vb[it].x; s[5] = (int)vb[it].y; s[6] = (int)vb[it].z; s[7] = (int)vb[it].w;
         } else {
+          const int32_t *row = (const int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w;
 #pragma unroll
           for (int k = 0; k < 8; ++k) s[k] = row[min(max(gx0 + k, 0), in_w - 1)];
         }
@@ -357,40 +387,67 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   const int32_t *store = p.store + (size_t)pic * p.store_stride;
   const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * p.xs : nullptr;
 
-  // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in
-#pragma unroll 1
-  for (int band = 0; band < 4; ++band) {
-    int *dst = lds + band * C::PLANE;
-    const bool from_plane = (band == 0 && !p.ll_from_store);
-    const int off = p.coef_off[comp] + (band == 0 ? 0 : p.band_off[comp] * band);
-    const int qm = band == 0 ? p.qmatrix[0] : p.qmatrix[p.band + band - 1];
+  // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in.
+  // Every 16-byte load of the thread (and the slice's quantiser index beside it) is issued before
+  // the first one is consumed.
+  {
+    constexpr int NQI = (WYP * (WXP / 4) + NT - 1) / NT;
+    int4 val[4][NQI];
+    int qv[4][NQI], kind[4][NQI]; // kind: 0 skip, 1 vector loaded, 2 element-wise path
     const int32_t *llp = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
-    const bool vec = from_plane ? ((npx & 3) == 0) : (lbsw >= 2);
-    for (int id = threadIdx.x; id < WYP * (WXP / 4); id += NT) {
-      const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
-      const int by = ky_base + i, bx0 = kx_base + 4 * jq;
-      if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
-      I4 v;
-      if (from_plane) {
-        const int32_t *row = llp + (size_t)by * npx;
-        if (vec && bx0 >= 0 && bx0 + 4 <= npx) { const int4 t = *(const int4 *)(row + bx0); v = {t.x, t.y, t.z, t.w}; }
-        else v = {row[min(max(bx0, 0), npx - 1)], row[min(max(bx0 + 1, 0), npx - 1)],
-                  row[min(max(bx0 + 2, 0), npx - 1)], row[min(max(bx0 + 3, 0), npx - 1)]};
-      } else {
-        const int sv = by >> lbsh, r = by & (bsh - 1);
-        int e[4];
-        if (vec && bx0 >= 0 && bx0 + 4 <= npx) {
-          const int sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
-          const int4 t = *(const int4 *)(store + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c);
-          e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w;
-          if (p.dequant) {
-            const int aq = max(qidx[sv * p.xs + sh] - qm, 0);
+#pragma unroll
+    for (int band = 0; band < 4; ++band) {
+      const bool from_plane = (band == 0 && !p.ll_from_store);
+      const int off = p.coef_off[comp] + (band == 0 ? 0 : p.band_off[comp] * band);
+      const bool vec = from_plane ? ((npx & 3) == 0) : (lbsw >= 2);
+#pragma unroll
+      for (int it = 0; it < NQI; ++it) {
+        const int id = it * NT + threadIdx.x;
+        kind[band][it] = 0;
+        qv[band][it] = 0;
+        val[band][it] = make_int4(0, 0, 0, 0);
+        if (id >= WYP * (WXP / 4)) continue;
+        const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
+        const int by = ky_base + i, bx0 = kx_base + 4 * jq;
+        if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
+        const bool inside = vec && bx0 >= 0 && bx0 + 4 <= npx;
+        kind[band][it] = inside ? 1 : 2;
+        if (!inside) continue;
+        if (from_plane) val[band][it] = *(const int4 *)(llp + (size_t)by * npx + bx0);
+        else {
+          const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
+          val[band][it] = *(const int4 *)(store + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c);
+          if (p.dequant) qv[band][it] = qidx[sv * p.xs + sh];
+        }
+      }
+    }
+#pragma unroll
+    for (int band = 0; band < 4; ++band) {
+      int *dst = lds + band * C::PLANE;
+      const bool from_plane = (band == 0 && !p.ll_from_store);
+      const int off = p.coef_off[comp] + (band == 0 ? 0 : p.band_off[comp] * band);
+      const int qm = band == 0 ? p.qmatrix[0] : p.qmatrix[p.band + band - 1];
+#pragma unroll
+      for (int it = 0; it < NQI; ++it) {
+        if (kind[band][it] == 0) continue;
+        const int id = it * NT + threadIdx.x;
+        const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
+        const int by = ky_base + i, bx0 = kx_base + 4 * jq;
+        int e[4] = {val[band][it].x, val[band][it].y, val[band][it].z, val[band][it].w};
+        if (kind[band][it] == 1) {
+          if (!from_plane && p.dequant) {
+            const int aq = max(qv[band][it] - qm, 0);
             if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
             const int qf = c_qd.qf[min(aq, 119)], qo = c_qd.off[min(aq, 119)];
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
           }
+        } else if (from_plane) {
+          const int32_t *row = llp + (size_t)by * npx;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = row[min(max(bx0 + k, 0), npx - 1)];
         } else {
+          const int sv = by >> lbsh, r = by & (bsh - 1);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int bx = min(max(bx0 + k, 0), npx - 1);
@@ -404,9 +461,8 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
             e[k] = t;
           }
         }
-        v = {e[0], e[1], e[2], e[3]};
+        lds_st4(dst + i * WXP + 4 * jq, {e[0], e[1], e[2], e[3]});
       }
-      lds_st4(dst + i * WXP + 4 * jq, v);
     }
   }
   __syncthreads();
