@@ -33,6 +33,8 @@ struct ProfEntry {
 };
 struct Launcher {
   bool on = false;
+  const char *last_name = nullptr;
+  std::string launch_error;
   std::vector<ProfEntry> entries;
   struct Pending { int entry; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -55,6 +57,7 @@ struct Launcher {
   }
 };
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
+  L.last_name = name;
   if (!L.on) return;
   int idx = -1;
   for (size_t i = 0; i < L.entries.size(); ++i) if (L.entries[i].name == name) { idx = (int)i; break; }
@@ -64,6 +67,10 @@ void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
   L.pending.push_back(p);
 }
 void vc2_prof_end(Launcher &L, hipStream_t s) {
+  // every launcher calls this right after hipLaunchKernelGGL: catch launch failures (bad grid / LDS size)
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess && L.launch_error.empty())
+    L.launch_error = std::string("kernel launch failed (") + (L.last_name ? L.last_name : "?") + "): " + hipGetErrorString(le);
   if (!L.on) return;
   (void)hipEventRecord(L.pending.back().b, s);
 }
@@ -91,6 +98,11 @@ struct vc2hip_ctx {
   int cbr_key[5] = {-1, -1, -1, -1, -1};
   uint64_t cbr_total = 0;
   int debug_skip = 0;
+  // VBR payload assembly.  Default: fixed-stride slots + scan + compaction (three launches).
+  // VC2HIP_SINGLE_PASS_VBR=1: decoupled look-back inside the pack kernel -- measured 2x SLOWER on
+  // MI355X (1.28 vs 0.62 + 0.20 ms per 16 UHD pictures: the look-back sits on every workgroup's
+  // critical path and the kernel is latency-bound), kept as a tested alternative.
+  bool two_pass_vbr = true;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
 };
 
@@ -219,6 +231,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   c->device = device;
   { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
   { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
+  { const char *e = getenv("VC2HIP_SINGLE_PASS_VBR"); c->two_pass_vbr = !(e && e[0] == '1'); }
   if (hipSetDevice(device) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
   c->stream = stream;
@@ -267,6 +280,11 @@ extern "C" int vc2hip_sync(vc2hip_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->L.collect();
+  if (!c->L.launch_error.empty()) {
+    const std::string m = c->L.launch_error;
+    c->L.launch_error.clear();
+    return set_err(c, VC2HIP_EHIP, m.c_str());
+  }
   return err_from_flags(c, *c->h_err);
 }
 
@@ -513,6 +531,15 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const int32_t *store, c
     p.cbr_bytes = d_cbr_bytes; p.cbr_offsets = d_cbr_offs;
     vc2_launch_pack(c->L, p, n, c->stream);
     vc2_launch_fill_u64(c->L, d_lens, cbr_total, (size_t)n, c->stream);
+    return VC2HIP_OK;
+  }
+  if (!c->two_pass_vbr) { // single pass: slice offsets by decoupled look-back inside the pack kernel
+    const long long lb_stride = (long long)((ns + 3) / 4) + 8;
+    unsigned long long *lb;
+    NEED(c, B_SIZES, (size_t)n * lb_stride * 8, lb);
+    HIPCHK(c, hipMemsetAsync(lb, 0, (size_t)n * lb_stride * 8, c->stream));
+    p.lookback = lb; p.lookback_stride = lb_stride; p.lens = d_lens;
+    vc2_launch_pack(c->L, p, n, c->stream);
     return VC2HIP_OK;
   }
   const int slot = (int)((max_slice_bytes(prefix, scalar) + 15) & ~(size_t)15);

@@ -125,6 +125,11 @@ struct PackParams {
   unsigned *err;
   int quantise;               // 0: store already holds quantised values (fine-grained API)
   int debug_skip;             // timing experiments only (VC2HIP_DEBUG_PACK): 1 no code writes, 2 no copy-out
+  // single-pass VBR: slice offsets by decoupled look-back over workgroup tiles (4 slices each).
+  // lookback: per picture [0] = tile ticket, [1 + t] = status of tile t: flag (2 bits) << 62 | bytes
+  unsigned long long *lookback;
+  long long lookback_stride;  // u64 words per picture
+  unsigned long long *lens;   // per picture payload length (written by the last tile)
 };
 
 struct UnpackParams {

@@ -336,8 +336,17 @@ __device__ __forceinline__ int half_max(int v) { // max within each 32-lane half
 
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   extern __shared__ unsigned lds_u[];
+  __shared__ unsigned long long s_base; // byte offset of this tile inside the picture payload
+  __shared__ int s_tile, s_tot[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  const int pic = blockIdx.y;
+  int tile = blockIdx.x;
+  if (p.lookback) { // tiles are numbered in the order workgroups start, so a predecessor is always running
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(p.lookback + (size_t)pic * p.lookback_stride, 1ull);
+    __syncthreads();
+    tile = s_tile;
+  }
+  const int slice = tile * 4 + wave;
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
   unsigned *img = lds_u + wave * img_words;
   unsigned *lut = lds_u + 4 * img_words;
@@ -441,10 +450,68 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     }
     if (lane == 0) put_byte(img, p.prefix, (unsigned)q & 0xFF);
   }
+  const int total = active ? p.prefix + 4 + bytes[0] + bytes[1] + bytes[2] : 0;
+  if (p.lookback && lane == 0) s_tot[wave] = total;
   __syncthreads();
+  if (p.lookback) {
+    // decoupled look-back: publish this tile's byte count, add up the predecessors' counts until one
+    // of them carries an inclusive prefix, publish ours.  One 8-byte agent-scope word per tile holds
+    // flag and value together, so no other ordering is needed.
+    if (wave == 0) { // the whole first wavefront looks back, 64 predecessor tiles per step
+      unsigned long long *st = p.lookback + (size_t)pic * p.lookback_stride + 1;
+      const unsigned long long agg = (unsigned long long)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]);
+      const unsigned long long M62 = (1ull << 62) - 1;
+      unsigned long long run = 0;
+      if (tile > 0) {
+        if (lane == 0) __hip_atomic_store(&st[tile], (1ull << 62) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool done = false;
+        for (int base = tile - 1; !done; base -= 64) {
+          const int t = base - lane;
+          for (int spins = 0;; ++spins) {
+            // tiles before the first one count as an inclusive prefix of zero
+            const unsigned long long v = t >= 0 ? __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+            const unsigned flag = (unsigned)(v >> 62);
+            const unsigned long long m2 = __ballot(flag == 2), m0 = __ballot(flag == 0);
+            const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;
+            const unsigned long long need = first2 >= 63 ? ~0ull : ((2ull << first2) - 1);
+            if ((m0 & need) == 0) { // every tile up to the first inclusive prefix has published
+              run += (unsigned long long)wave_sum64((long long)(lane <= first2 ? (v & M62) : 0ull));
+              done = first2 < 64;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            if (spins > (1 << 22)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_STREAM); done = true; break; }
+          }
+        }
+      }
+      if (lane == 0) {
+        __hip_atomic_store(&st[tile], (2ull << 62) | (run + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base = run;
+        if (tile == (p.n_slices + 3) / 4 - 1) p.lens[pic] = run + agg;
+      }
+    }
+    __syncthreads();
+  }
   if (!active || (p.debug_skip & 2)) return;
 
-  const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
+  if (p.lookback) {
+    unsigned long long off = s_base;
+    for (int w2 = 0; w2 < wave; ++w2) off += (unsigned long long)s_tot[w2];
+    uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + off;
+    // bytes of the image in stream order: byte i = img[i >> 2] >> (24 - 8 * (i & 3)); dword stores for the
+    // 4-byte aligned middle of the destination, byte stores for its ragged head and tail
+    const int head = min((int)((4 - ((size_t)dst & 3)) & 3), total);
+    const int nw = (total - head) >> 2, tail0 = head + 4 * nw;
+    if (lane < head) dst[lane] = (uint8_t)(img[lane >> 2] >> (24 - 8 * (lane & 3)));
+    if (lane < total - tail0) { const int i = tail0 + lane; dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3))); }
+    unsigned *d4 = (unsigned *)(dst + head);
+    for (int w = lane; w < nw; w += 64) {
+      const int i0 = head + 4 * w;
+      const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
+      d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
+    }
+    return;
+  }
   if (p.cbr_bytes) {
     if (bad_cbr) return;
     uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
@@ -462,7 +529,7 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
   const size_t lds = (size_t)4 * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * 32 * 16;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr = true; }
   vc2_prof_begin(L, "hq_pack", s);
   hipLaunchKernelGGL(k_hq_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), lds, s, p);
   vc2_prof_end(L, s);
