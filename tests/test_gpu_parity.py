@@ -129,6 +129,21 @@ def test_hq_pack_vbr_matches_oracle(hip, oracle, prefix, scalar):
     assert bytes(got) == bytes(want)
 
 
+def test_hq_pack_single_pass_option(oracle):
+    # VC2HIP_SINGLE_PASS_VBR=1: slice offsets by decoupled look-back inside the pack kernel
+    import vc2hip_py
+    os.environ["VC2HIP_SINGLE_PASS_VBR"] = "1"
+    try:
+        h2 = vc2hip_py.Vc2Hip(0)
+    finally:
+        del os.environ["VC2HIP_SINGLE_PASS_VBR"]
+    depth, ys, xs = 3, 9, 7
+    (y, u, v), qidx, _ = _quantised_planes(oracle, 26, (ys * 8, xs * 16), (ys * 8, xs * 8), depth, ys, xs, "DD97", 8)
+    for prefix, scalar in ((0, 1), (3, 2)):
+        assert bytes(h2.hq_pack(y, u, v, depth, qidx, prefix, scalar)) == bytes(oracle.hq_pack(y, u, v, depth, qidx, prefix, scalar))
+    h2.close()
+
+
 def test_hq_pack_empty_and_dense_slices(hip, oracle):
     depth, ys, xs = 2, 3, 4
     rng = np.random.default_rng(22)

@@ -574,10 +574,21 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_
   const int lane = threadIdx.x & 63, slice = blockIdx.x * 4 + (threadIdx.x >> 6), pic = blockIdx.y;
   if (slice >= n) return;
   const size_t si = (size_t)pic * n + slice;
-  const uint8_t *src = slots + si * slot_bytes;
+  const uint8_t *src = slots + si * slot_bytes; // 16-byte aligned
   uint8_t *dst = payload + (size_t)pic * payload_stride + offsets[si];
   const int size = (int)sizes[si];
-  for (int i = lane; i < size; i += 64) dst[i] = src[i];
+  // dword stores for the 4-byte aligned middle of the destination (each built from two aligned source
+  // dwords), byte stores for its ragged head and tail
+  const int head = min((int)((4 - ((size_t)dst & 3)) & 3), size);
+  const int nw = (size - head) >> 2, tail0 = head + 4 * nw;
+  if (lane < head) dst[lane] = src[lane];
+  if (lane < size - tail0) dst[tail0 + lane] = src[tail0 + lane];
+  const unsigned *s4 = (const unsigned *)src;
+  unsigned *d4 = (unsigned *)(dst + head);
+  for (int w = lane; w < nw; w += 64) {
+    const int i0 = head + 4 * w;
+    d4[w] = __builtin_amdgcn_alignbyte(s4[(i0 >> 2) + 1], s4[i0 >> 2], (unsigned)(i0 & 3));
+  }
 }
 
 void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const uint32_t *sizes,
