@@ -1063,18 +1063,58 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables(const uint8_t *pay
   }
 }
 
-__global__ void k_index_chain(const unsigned long long *lens, const uint2 *tables, uint2 *entries,
-                              int n_chunks, int E, int n_pictures) {
-  const int pic = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pic >= n_pictures) return;
+// The chain through the chunk functions is followed in two levels so that only n_chunks / IDX_GROUP +
+// IDX_GROUP dependent table reads are serial instead of n_chunks:
+//   group  : compose the functions of IDX_GROUP consecutive chunks, for every entry offset (parallel)
+//   chain  : per picture, follow entry -> exit through the group functions, then expand every group
+static constexpr int IDX_GROUP = 16;
+
+__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, const uint2 *tables,
+                                                     uint2 *groups, int n_chunks, int n_groups, int E) {
+  const int g = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = lens[pic];
-  unsigned entry = 0, base = 0;
-  for (int c = 0; c < n_chunks; ++c) {
-    entries[(size_t)pic * n_chunks + c] = make_uint2(entry, base);
-    if ((unsigned long long)c * IDX_CH >= plen) continue;
-    const uint2 t = tables[((size_t)pic * n_chunks + c) * E + entry];
-    entry = t.x;
-    base += t.y;
+  if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) return;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    unsigned x = (unsigned)e, cnt = 0;
+    for (int k = 0; k < IDX_GROUP; ++k) {
+      const int c = g * IDX_GROUP + k;
+      if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
+      const uint2 t = tables[((size_t)pic * n_chunks + c) * E + x];
+      x = t.x;
+      cnt += t.y;
+    }
+    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(x, cnt);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *lens, const uint2 *tables,
+                                                    const uint2 *groups, uint2 *entries, int n_chunks,
+                                                    int n_groups, int E) {
+  __shared__ uint2 g_entry[64 * 16];
+  const int pic = blockIdx.x;
+  const unsigned long long plen = lens[pic];
+  if (threadIdx.x == 0) {
+    unsigned entry = 0, base = 0;
+    for (int g = 0; g < n_groups; ++g) {
+      g_entry[g] = make_uint2(entry, base);
+      if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) continue;
+      const uint2 t = groups[((size_t)pic * n_groups + g) * E + entry];
+      entry = t.x;
+      base += t.y;
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+    unsigned entry = g_entry[g].x, base = g_entry[g].y;
+    for (int k = 0; k < IDX_GROUP; ++k) {
+      const int c = g * IDX_GROUP + k;
+      if (c >= n_chunks) break;
+      entries[(size_t)pic * n_chunks + c] = make_uint2(entry, base);
+      if ((unsigned long long)c * IDX_CH >= plen) continue;
+      const uint2 t = tables[((size_t)pic * n_chunks + c) * E + entry];
+      entry = t.x;
+      base += t.y;
+    }
   }
 }
 
@@ -1110,7 +1150,8 @@ bool vc2_slice_index_supported(int prefix, int scalar) { return idx_entries(pref
 size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix, int scalar) {
   const size_t n_chunks = (max_payload + IDX_CH - 1) / IDX_CH + 1;
   const size_t E = idx_entries(prefix, scalar);
-  return (size_t)n_pictures * n_chunks * (E + 1) * sizeof(uint2) + 256;
+  const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
+  return (size_t)n_pictures * (n_chunks * (E + 1) + n_groups * E) * sizeof(uint2) + 256;
 }
 
 void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
@@ -1140,8 +1181,11 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     hipLaunchKernelGGL((k_index_tables<1>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), idx_tables_lds(E, 1), s,
                        payload, payload_stride, lens, tables, n_chunks, E, prefix, scalar, dbg);
   vc2_prof_end(L, s);
+  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 512 MiB
+  uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
-  hipLaunchKernelGGL(k_index_chain, dim3((n_pictures + 63) / 64), dim3(64), 0, s, lens, tables, entries, n_chunks, E, n_pictures);
+  hipLaunchKernelGGL(k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, tables, groups, n_chunks, n_groups, E);
+  hipLaunchKernelGGL(k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, tables, groups, entries, n_chunks, n_groups, E);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
   hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(256), (size_t)((IDX_CH + E + 16 + 15) & ~15), s, payload,
