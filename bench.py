@@ -176,6 +176,15 @@ def main():
         dom_avg_s = dom_ms / dom_launches / 1e3
         achieved = alg_dir * B / dom_avg_s / 1e9
         path_achieved = 2 * alg_dir * B * args.steps / (total_ms / 1e3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE in separate runs, gfx950 correction applied; see profiles/r01_pmc_traffic.json)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc.get("pictures_per_launch") == B and dom in pmc["kernels"]:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "Mpixels/s encode+decode, UHD-1 10-bit HQ_ConstQ",
             "value": round(value, 1),
@@ -193,7 +202,7 @@ def main():
                        "pictures_per_gpu_per_step": B, "coded_bytes_per_picture": coded,
                        "parallelism": f"frame-parallel x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": dom, "kernel_avg_ms": round(dom_ms / dom_launches, 4),
                          "algorithmic_bytes_per_launch": alg_dir * B,
                          "path_achieved_GBs": round(path_achieved, 1),

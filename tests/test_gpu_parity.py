@@ -346,3 +346,33 @@ def test_cfg2_uhd_batch_device_resident(hip, oracle):
         pos -= lens[k]
         pos = stream.rfind(b"BBCD", 0, pos)
     assert hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest() == g["decoded"]["sha256"]
+
+
+def test_cfg3_uhd_cbr_reference_digests(hip, oracle):
+    """BASELINE config 3 (UHD-1 HQ_CBR, -s 8294400 -S 2) at full size: per-slice quantiser search + CBR
+    packing on the GPU; stream and decoded picture digests of reference output."""
+    g = GOLD["cfg3"]
+    raw = synth(3840, 2160, "422", 10, 1234, frames=1)
+    fmt, cp = _fmt_cp(hip, 3840, 2160, "422", 10, "DD97", 4, 1, 2, mode="HQ_CBR", s=8294400, scalar=2)
+    payload, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert set(np.unique(qidx).tolist()) <= {17, 18, 19}          # SURVEY section 8(d), cfg 3
+    # reference stream = sequence header + picture header (oracle writer, pinned by the digest) + payload
+    p = make_params(3840, 2160, "422", 10, "DD97", 4, 1, 2, mode="HQ_CBR", s=8294400, scalar=2)
+    import ctypes as C
+    from vc2lib import Params
+    hdr = np.zeros(64, np.uint8); n = C.c_size_t(); major = C.c_int()
+    oracle.lib.vc2o_write_sequence_header_payload(C.byref(p), hdr.ctypes.data_as(C.c_void_p), 64, C.byref(n), C.byref(major))
+    seq = bytes(hdr[:n.value])
+    ph = np.zeros(64, np.uint8); m = C.c_size_t()
+    oracle.lib.vc2o_write_hq_picture_header(0, 0, 4, cp.x_slices, cp.y_slices, 0, 2, major.value, ph.ctypes.data_as(C.c_void_p), 64, C.byref(m))
+    pich = bytes(ph[:m.value])
+
+    def pi(code, nxt, prev):
+        return b"BBCD" + bytes([code]) + nxt.to_bytes(4, "big") + prev.to_bytes(4, "big")
+    n1 = 13 + len(seq)
+    n2 = 13 + len(pich) + len(payload)
+    stream = pi(0x00, n1, 0) + seq + pi(0xE8, n2, n1) + pich + payload + pi(0x10, 0, n2)
+    assert len(stream) == g["stream"]["bytes"]
+    assert hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"]
+    dec = hip.decode_picture(payload, fmt, cp)
+    assert hashlib.sha256(dec).hexdigest() == g["decoded"]["sha256"]
