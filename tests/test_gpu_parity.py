@@ -376,3 +376,58 @@ def test_cfg3_uhd_cbr_reference_digests(hip, oracle):
     assert hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"]
     dec = hip.decode_picture(payload, fmt, cp)
     assert hashlib.sha256(dec).hexdigest() == g["decoded"]["sha256"]
+
+
+def _hq_stream(oracle, p, cp, depth, scalar, payloads):
+    """Reference stream syntax (oracle header writers, pinned by the cfg 1-4 digests) around GPU payloads."""
+    import ctypes as C
+    hdr = np.zeros(64, np.uint8); n = C.c_size_t(); major = C.c_int()
+    oracle.lib.vc2o_write_sequence_header_payload(C.byref(p), hdr.ctypes.data_as(C.c_void_p), 64, C.byref(n), C.byref(major))
+    seq = bytes(hdr[:n.value])
+
+    def pi(code, nxt, prev):
+        return b"BBCD" + bytes([code]) + nxt.to_bytes(4, "big") + prev.to_bytes(4, "big")
+    out = [pi(0x00, 13 + len(seq), 0), seq]
+    prev = 13 + len(seq)
+    for k, payload in enumerate(payloads):
+        ph = np.zeros(64, np.uint8); m = C.c_size_t()
+        oracle.lib.vc2o_write_hq_picture_header(k, p.kernel, depth, cp.x_slices, cp.y_slices, 0, scalar, major.value,
+                                                ph.ctypes.data_as(C.c_void_p), 64, C.byref(m))
+        nxt = 13 + m.value + len(payload)
+        out += [pi(0xE8, nxt, prev), bytes(ph[:m.value]), payload]
+        prev = nxt
+    out.append(pi(0x10, 0, prev))
+    return b"".join(out)
+
+
+def test_cfg4_uhd2_fidelity_reference_digests(hip, oracle):
+    """BASELINE config 4 (UHD-2 7680x4320 4:4:4 12-bit, Fidelity depth 5, -u 1 -a 1 -q 40 -S 8) at full
+    size on the GPU; input, stream and decoded digests are those of reference output.
+    The oracle only writes the 3 headers here (its own cfg 4 run is the opt-in VC2_SLOW CPU test)."""
+    g = GOLD["cfg4"]
+    raw = synth(7680, 4320, "444", 12, 1234, frames=1)
+    assert hashlib.sha256(raw).hexdigest() == g["input"]["sha256"]
+    fmt, cp = _fmt_cp(hip, 7680, 4320, "444", 12, "Fidelity", 5, 1, 1, q=40, scalar=8)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    p = make_params(7680, 4320, "444", 12, "Fidelity", 5, 1, 1, q=40, scalar=8)
+    stream = _hq_stream(oracle, p, cp, 5, 8, [payload])
+    assert len(stream) == g["stream"]["bytes"]
+    assert hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"]
+    dec = hip.decode_picture(payload, fmt, cp)
+    assert hashlib.sha256(dec).hexdigest() == g["decoded"]["sha256"]
+
+
+def test_cfg5_ld_1080p_decode_matches_oracle(hip, oracle):
+    """BASELINE config 5 at full size: 1920x1080 4:2:2 8-bit LD stream (LeGall depth 3, -u 1 -a 2,
+    -s 1036800) made by the oracle, decoded on the GPU, equal to the oracle's decode byte for byte."""
+    w, h, depth, s = 1920, 1080, 3, 1036800
+    raw = synth(w, h, "422", 8, 1234, word_bytes=1)
+    p = make_params(w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=s, word_bytes=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, n = oracle.decode_stream(p, stream, 1)
+    assert n == 1
+    fmt, cp = _fmt_cp(hip, w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=s, word_bytes=1)
+    sb = oracle.slice_bytes(cp.y_slices, cp.x_slices, s, 1)
+    assert int(sb.sum()) == s
+    payload = stream[-13 - s:-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
