@@ -93,6 +93,10 @@ int vc2hip_dequantise_np(vc2hip_ctx *ctx, const int32_t *q, int ph, int pw, int 
 int vc2hip_dequantise_ld(vc2hip_ctx *ctx, const int32_t *q, int ph, int pw, int depth,
                          const int32_t *qidx, int ys, int xs, const int32_t *qmatrix, int32_t *out);
 
+/* quantise_transform (LD, DC-predicted LL band), Quantisation.cpp:358-367 over :213-234 */
+int vc2hip_quantise_ld(vc2hip_ctx *ctx, const int32_t *coef, int ph, int pw, int depth,
+                       const int32_t *qidx, int ys, int xs, const int32_t *qmatrix, int32_t *out);
+
 /* geometry of the three quantised planes handed to the slice coders */
 typedef struct {
   int luma_h, luma_w;     /* padded */
@@ -115,6 +119,16 @@ int vc2hip_hq_unpack(vc2hip_ctx *ctx, const uint8_t *in, size_t len, const vc2hi
 int vc2hip_ld_unpack(vc2hip_ctx *ctx, const uint8_t *in, size_t len, const vc2hip_geom *g,
                      const int32_t *slice_bytes, int32_t *y, int32_t *u, int32_t *v,
                      int32_t *qidx, size_t *consumed);
+/* operator<<(ostream&, const Slices&) under sliceio::lowDelay(bytes), Slices.cpp:645-660 over
+ * :195-244.  y,u,v: QUANTISED planes, LL band as DC-prediction residuals (vc2hip_quantise_ld). */
+int vc2hip_ld_pack(vc2hip_ctx *ctx, const int32_t *y, const int32_t *u, const int32_t *v,
+                   const vc2hip_geom *g, const int32_t *qidx, const int32_t *slice_bytes,
+                   uint8_t *out, size_t cap, size_t *out_len);
+/* quantIndicesLD(coefficients, qMatrix, sliceBytes), EncodeStream.cpp:141-245 (per-slice search with
+ * the DC-prediction state machine of SliceQuantiserRef).  y,u,v: TRANSFORM planes. */
+int vc2hip_ld_qindices(vc2hip_ctx *ctx, const int32_t *y, const int32_t *u, const int32_t *v,
+                       const vc2hip_geom *g, const int32_t *qmatrix, const int32_t *slice_bytes,
+                       int32_t *qidx);
 /* quantIndicesCBR(coefficients, qMatrix, sliceBytes, scalar), EncodeStream.cpp:73-125.
  * y,u,v: TRANSFORM (unquantised) planes. */
 int vc2hip_cbr_qindices(vc2hip_ctx *ctx, const int32_t *y, const int32_t *u, const int32_t *v,
@@ -150,6 +164,11 @@ size_t vc2hip_max_payload_bytes(const vc2hip_picture_format *fmt, const vc2hip_c
 /* host buffers: H2D, kernels, D2H, synchronous.  payload = the slice bytes that follow the
  * transform parameters inside an HQ picture data unit.  qidx_out (ys*xs) may be NULL. */
 int vc2hip_encode_picture_hq(vc2hip_ctx *ctx, const void *raw, const vc2hip_picture_format *fmt,
+                             const vc2hip_coding_params *cp, uint8_t *payload, size_t cap,
+                             size_t *len, int32_t *qidx_out);
+/* LD: payload = the slice bytes of an LD picture data unit (cp->mode == VC2HIP_LD,
+ * cp->compressed_bytes = -s), EncodeStream.cpp:482-647 in LD mode */
+int vc2hip_encode_picture_ld(vc2hip_ctx *ctx, const void *raw, const vc2hip_picture_format *fmt,
                              const vc2hip_coding_params *cp, uint8_t *payload, size_t cap,
                              size_t *len, int32_t *qidx_out);
 int vc2hip_decode_picture_hq(vc2hip_ctx *ctx, const uint8_t *payload, size_t len,

@@ -924,19 +924,31 @@ static int check_match(const seq_fmt *f, int i) {
  * for the SequenceHeader EncodeStream.cpp:443-450 builds: optional fields unset. */
 int vc2o_write_sequence_header_payload(const vc2o_params *p, uint8_t *out, size_t cap, size_t *len,
                                        int *major_version_out) {
-  const seq_fmt f = {p->width, p->height, p->cf, 0, p->frame_rate, 1, p->bit_depth};
+  const seq_fmt f = {p->width, p->height, p->cf, p->interlaced ? 1 : 0, p->frame_rate, p->bottom_field_first ? 0 : 1, p->bit_depth};
   const int profile_hq = (p->mode != 2);
   int major = profile_hq ? 2 : 1; /* DataUnit.cpp:417-426 */
   if (f.fr > 11 /* MAX_V2_FRAMERATE = FR48 */ || f.bd > 12) major = 3;
+  if (p->fragment_length > 0 && p->mode != 0 && major < 3) major = 3; /* DataUnit.cpp:1065-1067 */
   int base = 0, level = 0;
   int custom_dims = 0, custom_cf = 0, custom_scan = 0, source_sampling = 0, custom_fr = 0, fr = 0;
   int custom_clean = 0, custom_range = 0, range_index = 0;
+  int fw = 0, fh = 0, cfv = 0;
 
+  if (f.interlace) { /* DataUnit.cpp:612-632 */
+    if (matches_index(&f, 7)) { base = 7; level = 2; }
+    else if (matches_index(&f, 8)) { base = 8; level = 2; }
+    else if (matches_index(&f, 22)) { base = 22; level = 2; }
+    else if (f.cf == 1 && f.width == 720 && f.height >= 480 && f.height <= 486 && f.fr == 4 && f.bd == 10) {
+      base = 7; level = 2; custom_dims = 1; fw = f.width; fh = f.height;
+    }
+    else if (matches_index(&f, 11)) { base = 11; level = 3; }
+    else if (matches_index(&f, 12)) { base = 12; level = 3; }
+  }
   /* progressive branch of DataUnit.cpp:633-675 */
   static const int simple[] = {1, 2, 3, 4, 5, 6};
-  for (unsigned i = 0; i < 6 && !base; ++i)
+  for (unsigned i = 0; i < 6 && !base && !f.interlace; ++i)
     if (matches_index(&f, simple[i])) { base = simple[i]; level = 1; }
-  if (!base) {
+  if (!base && !f.interlace) {
     if (matches_explicit(&f, 720, 480, 1, 4, 10, 0)) { base = 7; level = 2; custom_scan = 1; }
     else if (matches_explicit(&f, 720, 576, 1, 3, 10, 1)) { base = 8; level = 2; custom_scan = 1; }
     else if (matches_explicit(&f, 720, 486, 1, 4, 10, 0)) { base = 22; level = 2; custom_scan = 1; }
@@ -955,9 +967,9 @@ int vc2o_write_sequence_header_payload(const vc2o_params *p, uint8_t *out, size_
     else if (matches_index(&f, 19)) { base = 19; level = 7; }
     else if (matches_index(&f, 20)) { base = 20; level = 7; }
   }
-  int fw = 0, fh = 0, cfv = 0;
   if (!base) { /* DataUnit.cpp:677-783: closest base format + custom flags */
     level = 0;
+    custom_dims = 0;
     int best = 999;
     for (int i = 1; i <= 22; ++i) {
       const int n = check_match(&f, i);
@@ -1049,26 +1061,50 @@ static int make_geom(const vc2o_params *p, vc2o_geom *g, int decoder_side) {
   return 0;
 }
 
-/* EncodeStream.cpp:247-788, -o Stream, progressive */
+/* Frame.cpp:40-88: the rows of one field of a plane (top = even rows) */
+static void take_field(const int32_t *plane, int h, int w, int first, int32_t *field) {
+  for (int y = first, r = 0; y < h; y += 2, ++r) memcpy(field + (size_t)r * w, plane + (size_t)y * w, sizeof(int32_t) * w);
+}
+
+/* bytes of one HQ slice as serialised (Slices.cpp:305-382 / :469-533): prefix, index, 3 x (length byte + data) */
+static size_t hq_slice_size(const uint8_t *s, size_t avail, int prefix, int scalar) {
+  size_t q = (size_t)prefix + 1;
+  for (int c = 0; c < 3; ++c) {
+    if (q >= avail) return 0;
+    q += 1 + (size_t)s[q] * (size_t)scalar;
+  }
+  return q <= avail ? q : 0;
+}
+
+static void put_be(uint8_t *d, int n, uint32_t v) { for (int i = 0; i < n; ++i) d[i] = (uint8_t)(v >> (8 * (n - 1 - i))); }
+
+/* EncodeStream.cpp:247-788, -o Stream (progressive or interlaced, whole pictures or fragments) */
 int vc2o_encode_stream(const vc2o_params *p, const uint8_t *raw, int n_frames, uint8_t *out,
                        size_t cap, size_t *out_len) {
+  const int frame_pics = p->interlaced ? 2 : 1; /* EncodeStream.cpp:431 */
+  vc2o_params pp = *p;                           /* the coded picture: a frame or one field, :367-368 */
+  if (p->interlaced) pp.height = p->height / 2;
   vc2o_geom g;
-  make_geom(p, &g, 0);
-  int ch, cw;
-  vc2o_chroma_dims(p->height, p->width, p->cf, &ch, &cw);
-  g.y_slices = vc2o_slice_size_is_valid(p->depth, p->height, ch, p->y_size);
-  g.x_slices = vc2o_slice_size_is_valid(p->depth, p->width, cw, p->x_size);
+  make_geom(&pp, &g, 0);
+  int ch, cw, fch, fcw;
+  vc2o_chroma_dims(pp.height, pp.width, pp.cf, &ch, &cw);    /* picture chroma */
+  vc2o_chroma_dims(p->height, p->width, p->cf, &fch, &fcw);  /* frame chroma */
+  g.y_slices = vc2o_slice_size_is_valid(p->depth, pp.height, ch, p->y_size);
+  g.x_slices = vc2o_slice_size_is_valid(p->depth, pp.width, cw, p->x_size);
   if (!g.y_slices || !g.x_slices)
     return fail(VC2O_EINVAL, "The given waveletDepth, hSlice, and vSlice parameters cannot encode this input. See above for suggested parameters.");
   const int n_slices = g.y_slices * g.x_slices;
+  const int picture_bytes = p->interlaced ? p->compressed_bytes / 2 : p->compressed_bytes; /* :378 */
+  const int fragmented = p->fragment_length > 0 && p->mode != 0;                            /* :444-445 */
   int32_t qm[3 * 31 + 1];
   int rc = vc2o_quant_matrix(p->kernel, p->depth, qm);
   if (rc) return rc;
 
-  const size_t ln = (size_t)p->height * p->width, cn = (size_t)ch * cw;
+  const size_t fln = (size_t)p->height * p->width, fcn = (size_t)fch * fcw;
   const size_t pln = (size_t)g.luma_h * g.luma_w, pcn = (size_t)g.chroma_h * g.chroma_w;
-  const size_t frame_bytes = (ln + 2 * cn) * p->word_bytes;
-  int32_t *in = (int32_t *)malloc(sizeof(int32_t) * (ln > cn ? ln : cn));
+  const size_t frame_bytes = (fln + 2 * fcn) * p->word_bytes;
+  int32_t *in = (int32_t *)malloc(sizeof(int32_t) * (fln > fcn ? fln : fcn));
+  int32_t *fld = (int32_t *)malloc(sizeof(int32_t) * (fln > fcn ? fln : fcn));
   int32_t *tr[3], *qc[3];
   for (int c = 0; c < 3; ++c) {
     tr[c] = (int32_t *)malloc(sizeof(int32_t) * (c ? pcn : pln));
@@ -1076,6 +1112,8 @@ int vc2o_encode_stream(const vc2o_params *p, const uint8_t *raw, int n_frames, u
   }
   int32_t *qidx = (int32_t *)malloc(sizeof(int32_t) * n_slices);
   int32_t *sbytes = (int32_t *)malloc(sizeof(int32_t) * n_slices);
+  uint8_t *slices = NULL; /* fragmented pictures: the slice bytes before they are cut into fragments */
+  size_t slices_cap = 0;
 
   size_t pos = 0;
   uint32_t prev = 0;
@@ -1090,23 +1128,29 @@ int vc2o_encode_stream(const vc2o_params *p, const uint8_t *raw, int n_frames, u
     pos += plen;
     prev = (uint32_t)plen + 13;
   }
-  for (int frame = 0; frame < n_frames; ++frame) {
+  for (int frame = 0; frame < n_frames; ++frame)
+   for (int pic = 0; pic < frame_pics; ++pic) {
     const uint8_t *src = raw + (size_t)frame * frame_bytes;
+    /* Frame.cpp:90-104: first field = top field unless bottom field first */
+    const int first_row = p->interlaced ? ((pic == 0) == !p->bottom_field_first ? 0 : 1) : 0;
     for (int c = 0; c < 3; ++c) {
-      const int h = c ? ch : p->height, w = c ? cw : p->width;
+      const int fh = c ? fch : p->height, w = c ? fcw : p->width;
+      const int h = c ? ch : pp.height;
       const int ph = c ? g.chroma_h : g.luma_h, pw = c ? g.chroma_w : g.luma_w;
-      vc2o_ingest(src, p->word_bytes, p->bit_depth, (size_t)h * w, in);
-      src += (size_t)h * w * p->word_bytes;
-      vc2o_pad(in, h, w, tr[c], ph, pw);
+      vc2o_ingest(src, p->word_bytes, p->bit_depth, (size_t)fh * w, in);
+      src += (size_t)fh * w * p->word_bytes;
+      const int32_t *plane = in;
+      if (p->interlaced) { take_field(in, fh, w, first_row, fld); plane = fld; }
+      vc2o_pad(plane, h, w, tr[c], ph, pw);
       if ((rc = vc2o_dwt_forward(tr[c], ph, pw, p->kernel, p->depth))) goto done;
     }
     if (p->mode == 1) { /* HQ_CBR, EncodeStream.cpp:501-507 */
-      vc2o_slice_bytes(g.y_slices, g.x_slices, p->compressed_bytes, p->scalar, sbytes);
+      vc2o_slice_bytes(g.y_slices, g.x_slices, picture_bytes, p->scalar, sbytes);
       if ((rc = vc2o_cbr_qindices(tr[0], tr[1], tr[2], &g, qm, sbytes, p->scalar, qidx))) goto done;
     } else if (p->mode == 0) {
       for (int i = 0; i < n_slices; ++i) qidx[i] = p->q_index;
     } else { /* LD, EncodeStream.cpp:511-517 */
-      vc2o_slice_bytes(g.y_slices, g.x_slices, p->compressed_bytes, 1, sbytes);
+      vc2o_slice_bytes(g.y_slices, g.x_slices, picture_bytes, 1, sbytes);
       if ((rc = vc2o_ld_qindices(tr[0], tr[1], tr[2], &g, qm, sbytes, qidx))) goto done;
     }
     for (int c = 0; c < 3; ++c) {
@@ -1114,64 +1158,129 @@ int vc2o_encode_stream(const vc2o_params *p, const uint8_t *raw, int n_frames, u
       rc = (p->mode == 2 ? vc2o_quantise_ld : vc2o_quantise_np)(tr[c], ph, pw, p->depth, qidx, g.y_slices, g.x_slices, qm, qc[c]);
       if (rc) goto done;
     }
-    /* picture data unit: DataUnit.cpp:236-266 (HQ) / :125-153 (LD) */
-    if (pos + 13 + 64 > cap) { rc = fail(VC2O_ECAP, "output buffer too small"); goto done; }
-    uint8_t *du = out + pos;
-    size_t hlen, dlen;
-    if (p->mode == 2) {
-      bitw w = {du + 13, 64, 0, 0, 0, 0, 0, 0};
-      int num = p->compressed_bytes, den = n_slices;
-      const int gg = gcd_i(num, den);
-      num /= gg; den /= gg;
-      put_bytes(&w, 4, (uint32_t)frame);
+    const uint32_t picture_number = (uint32_t)(pic + frame * frame_pics); /* Utils.cpp:52-63 */
+    int num = picture_bytes, den = n_slices; /* utils::rationalise(pictureBytes, slices), EncodeStream.cpp:633 */
+    { const int gg = gcd_i(num, den); if (gg) { num /= gg; den /= gg; } }
+    /* transform parameters, DataUnit.cpp:130-148 / :241-259 (whole picture: v3 flags by version;
+     * fragments: always, :164-165 / :275-276) */
+    uint8_t params[64];
+    size_t params_len;
+    {
+      bitw w = {params, sizeof params, 0, 0, 0, 0, 0, 0};
       put_uvlc(&w, (uint32_t)p->kernel);
       put_uvlc(&w, (uint32_t)p->depth);
-      if (major >= 3) { put_bit(&w, 0); put_bit(&w, 0); }
+      if (fragmented || major >= 3) { put_bit(&w, 0); put_bit(&w, 0); }
       put_uvlc(&w, (uint32_t)g.x_slices);
       put_uvlc(&w, (uint32_t)g.y_slices);
-      put_uvlc(&w, (uint32_t)num);
-      put_uvlc(&w, (uint32_t)den);
+      put_uvlc(&w, (uint32_t)(p->mode == 2 ? num : p->prefix));
+      put_uvlc(&w, (uint32_t)(p->mode == 2 ? den : p->scalar));
       put_bit(&w, 0);
       w_align(&w);
-      hlen = w.pos;
-      rc = vc2o_ld_pack(qc[0], qc[1], qc[2], &g, qidx, sbytes, du + 13 + hlen, cap - pos - 13 - hlen, &dlen);
-    } else {
-      if ((rc = vc2o_write_hq_picture_header((uint32_t)frame, p->kernel, p->depth, g.x_slices, g.y_slices, p->prefix, p->scalar, major, du + 13, 64, &hlen))) goto done;
-      rc = vc2o_hq_pack(qc[0], qc[1], qc[2], &g, qidx, p->prefix, p->scalar, p->mode == 1 ? sbytes : NULL, du + 13 + hlen, cap - pos - 13 - hlen, &dlen);
+      params_len = w.pos;
     }
+    if (!fragmented) {
+      /* picture data unit: DataUnit.cpp:236-266 (HQ) / :125-153 (LD) */
+      if (pos + 13 + 4 + params_len > cap) { rc = fail(VC2O_ECAP, "output buffer too small"); goto done; }
+      uint8_t *du = out + pos;
+      put_be(du + 13, 4, picture_number);
+      memcpy(du + 17, params, params_len);
+      const size_t hlen = 4 + params_len;
+      size_t dlen;
+      if (p->mode == 2) rc = vc2o_ld_pack(qc[0], qc[1], qc[2], &g, qidx, sbytes, du + 13 + hlen, cap - pos - 13 - hlen, &dlen);
+      else rc = vc2o_hq_pack(qc[0], qc[1], qc[2], &g, qidx, p->prefix, p->scalar, p->mode == 1 ? sbytes : NULL, du + 13 + hlen, cap - pos - 13 - hlen, &dlen);
+      if (rc) goto done;
+      const uint32_t next = (uint32_t)(hlen + dlen) + 13;
+      vc2o_write_parse_info(du, p->mode == 2 ? 0xC8 : 0xE8, next, prev);
+      prev = next;
+      pos += next;
+      continue;
+    }
+    /* fragments: DataUnit.cpp:156-232 (LD) / :267-342 (HQ) */
+    const int code = p->mode == 2 ? 0xCC : 0xEC;
+    const size_t need = (size_t)picture_bytes + (size_t)n_slices * ((size_t)p->prefix + p->scalar + 8) + 64;
+    if (need > slices_cap) { slices = (uint8_t *)realloc(slices, need); slices_cap = need; }
+    size_t dlen;
+    if (p->mode == 2) rc = vc2o_ld_pack(qc[0], qc[1], qc[2], &g, qidx, sbytes, slices, slices_cap, &dlen);
+    else rc = vc2o_hq_pack(qc[0], qc[1], qc[2], &g, qidx, p->prefix, p->scalar, sbytes, slices, slices_cap, &dlen);
     if (rc) goto done;
-    const uint32_t next = (uint32_t)(hlen + dlen) + 13;
-    vc2o_write_parse_info(du, p->mode == 2 ? 0xC8 : 0xE8, next, prev);
-    prev = next;
-    pos += next;
+    if (pos + 13 + 8 + params_len > cap) { rc = fail(VC2O_ECAP, "output buffer too small"); goto done; }
+    { /* first fragment: the transform parameters, slice count 0 */
+      uint8_t *du = out + pos;
+      const uint32_t next = (uint32_t)params_len + 8 + 13;
+      vc2o_write_parse_info(du, code, next, prev);
+      put_be(du + 13, 4, picture_number);
+      put_be(du + 17, 2, (uint32_t)params_len);
+      put_be(du + 19, 2, 0);
+      memcpy(du + 21, params, params_len);
+      prev = next;
+      pos += next;
+    }
+    size_t spos = 0, frag_start = 0, frag_bytes = 0;
+    int nslices = 0, ox = 0, oy = 0;
+    for (int i = 0; i <= n_slices; ++i) {
+      size_t ssize = 0;
+      if (i < n_slices) {
+        ssize = p->mode == 2 ? (size_t)sbytes[i] : hq_slice_size(slices + spos, dlen - spos, p->prefix, p->scalar);
+        if (!ssize || spos + ssize > dlen) { rc = fail(VC2O_ESTREAM, "oracle: packed slices are inconsistent"); goto done; }
+      }
+      if (i == n_slices || (nslices > 0 && (long)(frag_bytes + ssize) > (long)p->fragment_length)) {
+        if (pos + 13 + 12 + frag_bytes > cap) { rc = fail(VC2O_ECAP, "output buffer too small"); goto done; }
+        uint8_t *du = out + pos;
+        const uint32_t next = (uint32_t)frag_bytes + 12 + 13;
+        vc2o_write_parse_info(du, code, next, prev);
+        put_be(du + 13, 4, picture_number);
+        put_be(du + 17, 2, (uint32_t)frag_bytes);
+        put_be(du + 19, 2, (uint32_t)nslices);
+        put_be(du + 21, 2, (uint32_t)ox);
+        put_be(du + 23, 2, (uint32_t)oy);
+        memcpy(du + 25, slices + frag_start, frag_bytes);
+        prev = next;
+        pos += next;
+        ox = i % g.x_slices; oy = i / g.x_slices;
+        nslices = 0; frag_start = spos; frag_bytes = 0;
+      }
+      frag_bytes += ssize;
+      spos += ssize;
+      ++nslices;
+    }
   }
   if (pos + 13 > cap) { rc = fail(VC2O_ECAP, "output buffer too small"); goto done; }
   pos += vc2o_write_parse_info(out + pos, 0x10, 0, prev); /* DataUnit.cpp:366-370 */
   *out_len = pos;
 done:
-  free(in); free(qidx); free(sbytes);
+  free(in); free(fld); free(qidx); free(sbytes); free(slices);
   for (int c = 0; c < 3; ++c) { free(tr[c]); free(qc[c]); }
   return rc;
 }
 
-/* DecodeStream.cpp:103-992, -o Decoded, progressive, whole pictures only.  The
- * sequence header is not interpreted (video parameters come from `p`); only its
- * major version is read, for the v3 transform-parameter flags. */
+/* DecodeStream.cpp:103-992, -o Decoded: whole pictures and fragments, progressive and interlaced.
+ * The sequence header is not interpreted (video parameters, including interlace and field order,
+ * come from `p`); only its major version is read, for the v3 transform-parameter flags. */
 int vc2o_decode_stream(const vc2o_params *p, const uint8_t *s, size_t len, uint8_t *raw_out,
                        size_t cap, int *n_frames_out) {
+  vc2o_params pp = *p; /* the coded picture: a frame or one field (DecodeStream.cpp:318) */
+  if (p->interlaced) pp.height = p->height / 2;
   vc2o_geom g;
-  make_geom(p, &g, 1);
-  int ch, cw;
-  vc2o_chroma_dims(p->height, p->width, p->cf, &ch, &cw);
+  make_geom(&pp, &g, 1);
+  int ch, cw, fch, fcw;
+  vc2o_chroma_dims(pp.height, pp.width, pp.cf, &ch, &cw);
+  vc2o_chroma_dims(p->height, p->width, p->cf, &fch, &fcw);
   const size_t pln = (size_t)g.luma_h * g.luma_w, pcn = (size_t)g.chroma_h * g.chroma_w;
-  const size_t frame_bytes = ((size_t)p->height * p->width + 2 * (size_t)ch * cw) * p->word_bytes;
+  const size_t frame_bytes = ((size_t)p->height * p->width + 2 * (size_t)fch * fcw) * p->word_bytes;
   int32_t *q[3], *t[3];
   for (int c = 0; c < 3; ++c) {
     q[c] = (int32_t *)malloc(sizeof(int32_t) * (c ? pcn : pln));
     t[c] = (int32_t *)malloc(sizeof(int32_t) * (c ? pcn : pln));
   }
-  int32_t *qidx = NULL, *sbytes = NULL, *crop = (int32_t *)malloc(sizeof(int32_t) * (size_t)p->height * p->width);
-  int rc = 0, frames = 0, major = 2;
+  int32_t *qidx = NULL, *sbytes = NULL, *crop = (int32_t *)malloc(sizeof(int32_t) * (size_t)pp.height * pp.width);
+  uint8_t *field = (uint8_t *)malloc((size_t)pp.height * pp.width * p->word_bytes);
+  /* fragment reassembly (one picture at a time is enough for streams in coding order) */
+  uint32_t fr_picture = 0;
+  int fr_open = 0, fr_ld = 0, fr_kernel = 0, fr_depth = 0, fr_a = 0, fr_b = 0, fr_decoded = 0, fr_slices = 0;
+  const uint8_t **fr_ptr = NULL;
+  size_t *fr_len = NULL;
+  uint8_t *fr_payload = NULL;
+  int rc = 0, frames = 0, major = 2, pic = 0;
   size_t pos = 0;
   while (pos + 13 <= len) {
     if (memcmp(s + pos, "BBCD", 4)) { rc = fail(VC2O_ESTREAM, "Read bytes do not match expected parse_info_header"); break; }
@@ -1179,54 +1288,120 @@ int vc2o_decode_stream(const vc2o_params *p, const uint8_t *s, size_t len, uint8
     const uint32_t next = ((uint32_t)s[pos + 5] << 24) | ((uint32_t)s[pos + 6] << 16) | ((uint32_t)s[pos + 7] << 8) | s[pos + 8];
     const uint8_t *body = s + pos + 13;
     const size_t body_len = (next ? next : 13) - 13;
+    /* a complete picture's slice bytes, once found */
+    const uint8_t *data = NULL;
+    size_t data_len = 0;
+    int ld = 0, kernel = 0, depth = 0, a = 0, b = 0;
     if (code == 0x00) {
       bitr r = {body, body_len, 0, 0, 0, 0, 0, 0};
       major = (int)get_uvlc(&r);
     } else if (code == 0xE8 || code == 0xC8) {
       bitr r = {body, len - pos - 13, 0, 0, 0, 0, 0, 0};
       get_bytes(&r, 4);
-      const int kernel = (int)get_uvlc(&r), depth = (int)get_uvlc(&r);
+      kernel = (int)get_uvlc(&r); depth = (int)get_uvlc(&r);
       if (major >= 3) { get_bit(&r); get_bit(&r); }
       g.x_slices = (int)get_uvlc(&r);
       g.y_slices = (int)get_uvlc(&r);
-      const int a = (int)get_uvlc(&r), b = (int)get_uvlc(&r); /* prefix,scalar | numer,denom */
+      a = (int)get_uvlc(&r); b = (int)get_uvlc(&r); /* prefix,scalar | numer,denom */
       get_bit(&r);
       r_align(&r);
+      ld = code == 0xC8;
+      data = body + r.pos;
+      data_len = len - pos - 13 - r.pos;
+    } else if (code == 0xEC || code == 0xCC) { /* DecodeStream.cpp:614-797 / :799-977 */
+      bitr r = {body, len - pos - 13, 0, 0, 0, 0, 0, 0};
+      const uint32_t picnum = get_bytes(&r, 4);
+      get_bytes(&r, 2);
+      const int count = (int)get_bytes(&r, 2);
+      if (count == 0) {
+        fr_kernel = (int)get_uvlc(&r); fr_depth = (int)get_uvlc(&r);
+        if (major >= 3) { get_bit(&r); get_bit(&r); }
+        g.x_slices = (int)get_uvlc(&r);
+        g.y_slices = (int)get_uvlc(&r);
+        fr_a = (int)get_uvlc(&r); fr_b = (int)get_uvlc(&r);
+        get_bit(&r);
+        r_align(&r);
+        fr_open = 1; fr_ld = code == 0xCC; fr_picture = picnum; fr_decoded = 0;
+        fr_slices = g.x_slices * g.y_slices;
+        fr_ptr = (const uint8_t **)realloc((void *)fr_ptr, sizeof(*fr_ptr) * fr_slices);
+        fr_len = (size_t *)realloc(fr_len, sizeof(size_t) * fr_slices);
+        memset(fr_len, 0, sizeof(size_t) * fr_slices);
+        if (fr_ld) { /* DecodeStream.cpp:641, :664-665 */
+          sbytes = (int32_t *)realloc(sbytes, sizeof(int32_t) * fr_slices);
+          const int compressed = (fr_a * fr_slices) / fr_b;
+          vc2o_slice_bytes(g.y_slices, g.x_slices, p->interlaced ? compressed / 2 : compressed, 1, sbytes);
+        }
+      } else if (fr_open && picnum == fr_picture) {
+        const int ox = (int)get_bytes(&r, 2), oy = (int)get_bytes(&r, 2);
+        const uint8_t *sp = body + r.pos;
+        size_t left = body_len > r.pos ? body_len - r.pos : 0;
+        int si = oy * g.x_slices + ox;
+        for (int k = 0; k < count && si < fr_slices; ++k, ++si) { /* Slices.cpp:662-694 */
+          const size_t sz = fr_ld ? (size_t)sbytes[si] : hq_slice_size(sp, left, fr_a, fr_b);
+          if (!sz || sz > left) { rc = fail(VC2O_ESTREAM, "oracle: fragment does not hold its slices"); break; }
+          fr_ptr[si] = sp; fr_len[si] = sz;
+          sp += sz; left -= sz;
+        }
+        if (rc) break;
+        fr_decoded += count;
+        if (fr_decoded >= fr_slices) {
+          size_t total = 0;
+          for (int i = 0; i < fr_slices; ++i) total += fr_len[i];
+          fr_payload = (uint8_t *)realloc(fr_payload, total + 1);
+          total = 0;
+          for (int i = 0; i < fr_slices; ++i) { memcpy(fr_payload + total, fr_ptr[i], fr_len[i]); total += fr_len[i]; }
+          data = fr_payload; data_len = total;
+          ld = fr_ld; kernel = fr_kernel; depth = fr_depth; a = fr_a; b = fr_b;
+          fr_open = 0;
+        }
+      }
+    }
+    if (data) {
       if (depth != p->depth) { rc = fail(VC2O_ESTREAM, "oracle: stream depth differs from params"); break; }
       const int n_slices = g.x_slices * g.y_slices;
       qidx = (int32_t *)realloc(qidx, sizeof(int32_t) * n_slices);
       int32_t qm[3 * 31 + 1];
       if ((rc = vc2o_quant_matrix(kernel, depth, qm))) break;
       size_t used;
-      if (code == 0xE8) {
-        rc = vc2o_hq_unpack(body + r.pos, len - pos - 13 - r.pos, &g, a, b, q[0], q[1], q[2], qidx, &used);
-      } else { /* DecodeStream.cpp:312, :331-333 */
+      if (!ld) {
+        rc = vc2o_hq_unpack(data, data_len, &g, a, b, q[0], q[1], q[2], qidx, &used);
+      } else { /* DecodeStream.cpp:312, :331-333: the reference halves the budget again for interlaced streams */
         sbytes = (int32_t *)realloc(sbytes, sizeof(int32_t) * n_slices);
         const int compressed = (a * g.y_slices * g.x_slices) / b;
-        vc2o_slice_bytes(g.y_slices, g.x_slices, compressed, 1, sbytes);
-        rc = vc2o_ld_unpack(body + r.pos, len - pos - 13 - r.pos, &g, sbytes, q[0], q[1], q[2], qidx, &used);
+        vc2o_slice_bytes(g.y_slices, g.x_slices, p->interlaced ? compressed / 2 : compressed, 1, sbytes);
+        rc = vc2o_ld_unpack(data, data_len, &g, sbytes, q[0], q[1], q[2], qidx, &used);
       }
       if (rc) break;
       if ((size_t)(frames + 1) * frame_bytes > cap) { rc = fail(VC2O_ECAP, "output buffer too small"); break; }
       uint8_t *dst = raw_out + (size_t)frames * frame_bytes;
+      /* DecodeStream.cpp:417-428: first field, second field, then the frame is complete */
+      const int first_row = p->interlaced ? ((pic == 0) == !p->bottom_field_first ? 0 : 1) : 0;
       for (int c = 0; c < 3 && !rc; ++c) {
         const int ph = c ? g.chroma_h : g.luma_h, pw = c ? g.chroma_w : g.luma_w;
-        const int h = c ? ch : p->height, w = c ? cw : p->width;
-        rc = (code == 0xC8 ? vc2o_dequantise_ld : vc2o_dequantise_np)(q[c], ph, pw, depth, qidx, g.y_slices, g.x_slices, qm, t[c]);
+        const int h = c ? ch : pp.height, w = c ? cw : pp.width;
+        const int fh = c ? fch : p->height;
+        rc = (ld ? vc2o_dequantise_ld : vc2o_dequantise_np)(q[c], ph, pw, depth, qidx, g.y_slices, g.x_slices, qm, t[c]);
         if (rc) break;
         if ((rc = vc2o_dwt_inverse(t[c], ph, pw, kernel, depth))) break;
         for (int y = 0; y < h; ++y) memcpy(crop + (size_t)y * w, t[c] + (size_t)y * pw, sizeof(int32_t) * w);
-        vc2o_clip_emit(crop, (size_t)h * w, p->word_bytes, p->bit_depth, dst);
-        dst += (size_t)h * w * p->word_bytes;
+        const size_t row = (size_t)w * p->word_bytes;
+        if (p->interlaced) {
+          vc2o_clip_emit(crop, (size_t)h * w, p->word_bytes, p->bit_depth, field);
+          for (int y = first_row, r = 0; y < fh && r < h; y += 2, ++r) memcpy(dst + (size_t)y * row, field + (size_t)r * row, row);
+        } else {
+          vc2o_clip_emit(crop, (size_t)h * w, p->word_bytes, p->bit_depth, dst);
+        }
+        dst += (size_t)fh * row;
       }
       if (rc) break;
-      ++frames;
+      if (p->interlaced && pic == 0) pic = 1;
+      else { pic = 0; ++frames; }
     }
     if (code == 0x10 || next == 0) break;
     pos += next;
   }
   *n_frames_out = frames;
   for (int c = 0; c < 3; ++c) { free(q[c]); free(t[c]); }
-  free(qidx); free(sbytes); free(crop);
+  free(qidx); free(sbytes); free(crop); free(field); free((void *)fr_ptr); free(fr_len); free(fr_payload);
   return rc;
 }

@@ -118,6 +118,9 @@ typedef struct {
   int compressed_bytes;      /* -s */
   int scalar, prefix;        /* -S -P */
   int frame_rate;            /* -r (default 3) */
+  int interlaced;            /* -i: every frame is coded as two field pictures (EncodeStream.cpp:431, :468-475) */
+  int bottom_field_first;    /* -b (default top field first, EncodeParams.cpp:124) */
+  int fragment_length;       /* -F: >0 writes HQ_CBR / LD pictures as fragments (EncodeStream.cpp:444-445) */
 } vc2o_params;
 
 /* returns bytes written to `out` via *out_len; n_frames pictures are read from raw */

@@ -32,7 +32,9 @@ def run(tool, *args):
 
 def enc_args(w, h, cf, bits, kernel, depth, u, a, mode="HQ_ConstQ", q=None, s=None, scalar=1, prefix=0, n=2):
     args = ["-m", mode, "-k", kernel, "-d", depth, "-u", u, "-a", a, "-f", {"444": "4:4:4", "422": "4:2:2", "420": "4:2:0"}[cf],
-            "-x", w, "-y", h, "-l", bits, "-n", n, "-S", scalar, "-P", prefix]
+            "-x", w, "-y", h, "-l", bits, "-n", n]
+    if mode != "LD":
+        args += ["-S", scalar, "-P", prefix]
     if q is not None:
         args += ["-q", q]
     if s is not None:
@@ -142,3 +144,68 @@ def test_cfg1_full_size_against_reference_digests(tools, tmp_path):
     assert len(s) == g["stream"]["bytes"] and hashlib.sha256(s).hexdigest() == g["stream"]["sha256"]
     run("DecodeStream", tmp_path / "o.vc2", tmp_path / "d.raw")
     assert hashlib.sha256((tmp_path / "d.raw").read_bytes()).hexdigest() == g["decoded"]["sha256"]
+
+
+# ---- SURVEY 8(f)3/4 through the tools: LD encode, interlace, picture fragments
+def _roundtrip(tools, oracle, tmp_path, w, h, cf, bits, kernel, depth, u, a, frames, extra, n=2, **kw):
+    raw = synth(w, h, cf, bits, 55, frames=frames, word_bytes=n)
+    p = make_params(w, h, cf, bits, kernel, depth, u, a, word_bytes=n, **kw)
+    want = oracle.encode_stream(p, raw, frames)
+    (tmp_path / "in.raw").write_bytes(raw)
+    cli = {k: v for k, v in kw.items() if k in ("mode", "q", "s", "scalar", "prefix")}
+    run("EncodeStream", *enc_args(w, h, cf, bits, kernel, depth, u, a, n=n, **cli), *extra, tmp_path / "in.raw", tmp_path / "o.vc2")
+    got = (tmp_path / "o.vc2").read_bytes()
+    assert got == want
+    run("DecodeStream", tmp_path / "o.vc2", tmp_path / "d.raw")
+    dec = (tmp_path / "d.raw").read_bytes()
+    assert dec == oracle.decode_stream(p, want, frames)[0]
+    return raw, dec
+
+
+def test_ld_encode_stream(tools, oracle, tmp_path):
+    _roundtrip(tools, oracle, tmp_path, 256, 120, "422", 8, "LeGall", 3, 1, 2, 2, [], n=1, mode="LD", s=12000)
+
+
+@pytest.mark.parametrize("bff", [False, True])
+def test_interlaced_streams(tools, oracle, tmp_path, bff):
+    flags = ["-i", "-b"] if bff else ["-i"]
+    raw, dec = _roundtrip(tools, oracle, tmp_path, 128, 96, "420", 8, "Haar0", 2, 2, 2, 3, flags, n=1, q=0, scalar=4,
+                          interlaced=True, bottom_field_first=bff)
+    assert dec == raw          # index 0 + integer lifting: lossless, so the fields went back to their rows
+    _roundtrip(tools, oracle, tmp_path, 128, 96, "422", 10, "DD97", 2, 1, 2, 2, flags, mode="HQ_CBR", s=9000, scalar=1,
+               interlaced=True, bottom_field_first=bff)
+
+
+@pytest.mark.parametrize("mode,kw", [("HQ_CBR", dict(s=9000, scalar=2, prefix=1)), ("LD", dict(s=7000))])
+@pytest.mark.parametrize("flen", [1, 700, 60000])
+def test_fragmented_streams(tools, oracle, tmp_path, mode, kw, flen):
+    _roundtrip(tools, oracle, tmp_path, 128, 64, "422", 10, "LeGall", 2, 2, 2, 2, ["-F", flen], mode=mode, fragment_length=flen, **kw)
+
+
+def test_interlaced_fragmented_cbr(tools, oracle, tmp_path):
+    _roundtrip(tools, oracle, tmp_path, 128, 64, "444", 12, "Fidelity", 2, 1, 1, 2, ["-i", "-F", 400], mode="HQ_CBR", s=16000,
+               scalar=2, interlaced=True, fragment_length=400)
+
+
+def test_ld_diagnostic_outputs(tools, oracle, tmp_path):
+    # LD mode through -o Indices / Quantised / Packaged: quantIndicesLD, quantise_transform (DC-predicted), LDSliceIO
+    w, h, depth, kernel, s = 128, 64, 2, "LeGall", 5000
+    raw = synth(w, h, "422", 8, 56, word_bytes=1)
+    (tmp_path / "in.raw").write_bytes(raw)
+    k = KERNELS[kernel]
+    y = oracle.ingest(raw[:w * h], 1, 8, (h, w))
+    u = oracle.ingest(raw[w * h:w * h * 3 // 2], 1, 8, (h, w // 2))
+    v = oracle.ingest(raw[w * h * 3 // 2:], 1, 8, (h, w // 2))
+    t = [oracle.dwt_forward(pl, k, depth) for pl in (y, u, v)]
+    qm = oracle.quant_matrix(k, depth)
+    sb = oracle.slice_bytes(8, 16, s, 1)
+    qi = oracle.ld_qindices(t[0], t[1], t[2], depth, qm, sb)
+    base = enc_args(w, h, "422", 8, kernel, depth, 2, 2, mode="LD", s=s, n=1)
+    run("EncodeStream", *base, "-o", "Indices", tmp_path / "in.raw", tmp_path / "i.bin")
+    assert np.array_equal(np.frombuffer((tmp_path / "i.bin").read_bytes(), np.uint8).reshape(8, 16), qi)
+    q = [oracle.quantise_ld(a, depth, qi, qm) for a in t]
+    run("EncodeStream", *base, "-o", "Quantised", tmp_path / "in.raw", tmp_path / "q.bin")
+    got = _planes_be4((tmp_path / "q.bin").read_bytes(), [a.shape for a in q])
+    assert all(np.array_equal(a, b) for a, b in zip(got, q))
+    run("EncodeStream", *base, "-o", "Packaged", tmp_path / "in.raw", tmp_path / "p.bin")
+    assert (tmp_path / "p.bin").read_bytes() == bytes(oracle.ld_pack(q[0], q[1], q[2], depth, qi, sb))

@@ -431,3 +431,75 @@ def test_cfg5_ld_1080p_decode_matches_oracle(hip, oracle):
     assert int(sb.sum()) == s
     payload = stream[-13 - s:-13]
     assert hip.decode_picture(payload, fmt, cp) == dec
+    # and the LD encoder at the same size
+    got, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert got == payload
+
+
+# ---- LD encode: quantIndicesLD, quantise_transform with DC prediction, LDSliceIO out
+LD_CASES = [  # w, h, cf, bits, word_bytes, kernel, depth, u, a, bytes
+    (256, 120, "422", 8, 1, "LeGall", 3, 1, 2, 12000),
+    (128, 64, "444", 10, 2, "DD97", 2, 2, 2, 9000),
+    (256, 128, "420", 8, 1, "Haar1", 3, 2, 2, 6000),
+    (192, 96, "422", 12, 2, "Fidelity", 2, 4, 4, 5000),
+]
+
+
+@pytest.mark.parametrize("case", LD_CASES, ids=lambda c: f"{c[5]}_{c[2]}_{c[0]}x{c[1]}")
+def test_ld_encode_matches_oracle(hip, oracle, case):
+    w, h, cf, bits, wb, kernel, depth, u, a, nbytes = case
+    raw = synth(w, h, cf, bits, 47, word_bytes=wb)
+    p = make_params(w, h, cf, bits, kernel, depth, u, a, mode="LD", s=nbytes, word_bytes=wb)
+    stream = oracle.encode_stream(p, raw, 1)
+    fmt, cp = _fmt_cp(hip, w, h, cf, bits, kernel, depth, u, a, mode="LD", s=nbytes, word_bytes=wb)
+    payload, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert len(payload) == nbytes
+    assert payload == stream[-13 - nbytes:-13]
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+def test_ld_fine_grained_entry_points(hip, oracle):
+    """vc2hip_ld_qindices / vc2hip_quantise_ld / vc2hip_ld_pack against the oracle's restatements of
+    quantIndicesLD (EncodeStream.cpp:141-245), quantise_transform (Quantisation.cpp:213-234, :358-367)
+    and LDSliceIO (Slices.cpp:195-244)."""
+    rng = np.random.default_rng(48)
+    depth, ys, xs = 3, 6, 5
+    lshape, cshape = (ys * 16, xs * 32), (ys * 16, xs * 16)
+    planes = [np.rint(rng.normal(0, 300, s)).astype(np.int32) for s in (lshape, cshape, cshape)]
+    tr = [oracle.dwt_forward(pl, KERNELS["LeGall"], depth) for pl in planes]
+    qm = oracle.quant_matrix(KERNELS["LeGall"], depth)
+    sb = oracle.slice_bytes(ys, xs, ys * xs * 90 + 7, 1)
+    q_want = oracle.ld_qindices(tr[0], tr[1], tr[2], depth, qm, sb)
+    q_got = hip.ld_qindices(tr[0], tr[1], tr[2], depth, qm, sb)
+    assert np.array_equal(q_got, q_want)
+    assert q_want.min() < q_want.max()
+    qp_want = [oracle.quantise_ld(t, depth, q_want, qm) for t in tr]
+    qp_got = [hip.quantise_ld(t, depth, q_want, qm) for t in tr]
+    for a, b in zip(qp_got, qp_want):
+        assert np.array_equal(a, b)
+    want = oracle.ld_pack(qp_want[0], qp_want[1], qp_want[2], depth, q_want, sb)
+    got = hip.ld_pack(qp_want[0], qp_want[1], qp_want[2], depth, q_want, sb)
+    assert np.array_equal(got, want)
+
+
+def test_ld_encode_errors(hip, oracle):
+    # smallest budget the syntax allows (4 bytes per slice): every slice ends at a high index, no throw
+    w, h = 128, 64
+    raw = noise_frame(w, h, "422", 10, seed=49)
+    p = make_params(w, h, "422", 10, "LeGall", 2, 1, 2, mode="LD", s=16 * 16 * 4, word_bytes=2)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "LeGall", 2, 1, 2, mode="LD", s=16 * 16 * 4, word_bytes=2)
+    payload, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == oracle.encode_stream(p, raw, 1)[-13 - 1024:-13]
+    assert qidx.min() > 40
+    # LD pack with a luma slice that leaves no room for chroma
+    depth, ys, xs = 2, 2, 2
+    rng = np.random.default_rng(50)
+    y = rng.integers(-200, 200, (16, 32)).astype(np.int32)
+    u = rng.integers(-200, 200, (16, 16)).astype(np.int32)
+    sb = np.full((ys, xs), 40, np.int32)
+    q = np.zeros((ys, xs), np.int32)
+    with pytest.raises(Exception, match="Too many bytes for the U and V slices"):
+        hip.ld_pack(y, u, u, depth, q, sb)
+    with pytest.raises(Exception):
+        oracle.ld_pack(y, u, u, depth, q, sb)

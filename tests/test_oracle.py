@@ -138,3 +138,90 @@ def test_ld_roundtrip_selfconsistent(oracle):
     a = np.frombuffer(raw, np.uint8).astype(int)
     b = np.frombuffer(dec, np.uint8).astype(int)
     assert np.abs(a - b).mean() < 4.0
+
+
+# ---- stream-level features added for SURVEY 8(f)3: interlace and picture fragments.  No reference output exists
+# ---- for them in this container ("parity unpinned"); these are the invariants the syntax itself gives.
+def _units(stream):
+    pos, out = 0, []
+    while pos < len(stream):
+        assert stream[pos:pos + 4] == b"BBCD"
+        code = stream[pos + 4]
+        nxt = int.from_bytes(stream[pos + 5:pos + 9], "big")
+        prev = int.from_bytes(stream[pos + 9:pos + 13], "big")
+        size = nxt if nxt else 13
+        out.append((code, nxt, prev, stream[pos + 13:pos + size]))
+        pos += size
+    return out
+
+
+@pytest.mark.parametrize("bff", [False, True])
+def test_interlaced_lossless_round_trip(oracle, bff):
+    from synth import synth
+    from vc2lib import make_params
+    w, h = 64, 64
+    raw = synth(w, h, "420", 8, 61, frames=2, word_bytes=1)
+    p = make_params(w, h, "420", 8, "Haar0", 2, 2, 2, q=0, scalar=4, word_bytes=1, interlaced=True, bottom_field_first=bff)
+    stream = oracle.encode_stream(p, raw, 2)
+    units = _units(stream)
+    assert [u[0] for u in units] == [0x00, 0xE8, 0xE8, 0xE8, 0xE8, 0x10]
+    # picture numbers count fields (Utils.cpp:52-63); parse offsets chain
+    assert [int.from_bytes(u[3][:4], "big") for u in units[1:5]] == [0, 1, 2, 3]
+    for a, b in zip(units, units[1:]):
+        assert b[2] == a[1]
+    dec, n = oracle.decode_stream(p, stream, 2)
+    assert n == 2 and dec == raw
+    # the field order decides which rows a picture carries
+    q = make_params(w, h, "420", 8, "Haar0", 2, 2, 2, q=0, scalar=4, word_bytes=1, interlaced=True, bottom_field_first=not bff)
+    assert oracle.encode_stream(q, raw, 2) != stream
+
+
+@pytest.mark.parametrize("mode,kw", [("HQ_CBR", dict(s=5000, scalar=2, prefix=1)), ("LD", dict(s=4000))])
+@pytest.mark.parametrize("flen", [1, 300, 100000])
+def test_fragmented_stream_carries_the_same_slices(oracle, mode, kw, flen):
+    from synth import synth
+    from vc2lib import make_params
+    w, h = 128, 64
+    raw = synth(w, h, "422", 10, 62)
+    whole = make_params(w, h, "422", 10, "LeGall", 2, 2, 2, mode=mode, **kw)
+    frag = make_params(w, h, "422", 10, "LeGall", 2, 2, 2, mode=mode, fragment_length=flen, **kw)
+    s0, s1 = oracle.encode_stream(whole, raw, 1), oracle.encode_stream(frag, raw, 1)
+    u0, u1 = _units(s0), _units(s1)
+    code = 0xEC if mode == "HQ_CBR" else 0xCC
+    assert [u[0] for u in u1] == [0x00] + [code] * (len(u1) - 2) + [0x10]
+    assert u1[0][3][0] & 0x80 == 0 and u0[0][3] != u1[0][3]        # fragments force major version 3 (DataUnit.cpp:1065)
+    first, rest = u1[1][3], [u[3] for u in u1[2:-1]]
+    assert int.from_bytes(first[6:8], "big") == 0                    # parameters fragment: slice count 0
+    slices, count, nxt = b"", 0, 0
+    for body in rest:
+        n = int.from_bytes(body[6:8], "big")
+        assert int.from_bytes(body[4:6], "big") == len(body) - 12
+        assert int.from_bytes(body[10:12], "big") * 16 + int.from_bytes(body[8:10], "big") == nxt   # slice offset (x, y)
+        if flen > 1 and n > 1:
+            assert len(body) - 12 <= flen
+        slices += body[12:]
+        count += n
+        nxt += n
+    assert count == 128
+    if flen == 1:
+        assert len(rest) == 128          # never an empty fragment: one slice each
+    if flen == 100000:
+        assert len(rest) == 1
+    # same slice bytes as the unfragmented picture (whose transform parameters lack the v3 flags)
+    assert s0[:-13].endswith(slices)
+    assert oracle.decode_stream(frag, s1, 1) == oracle.decode_stream(whole, s0, 1)
+
+
+def test_interlaced_fragmented_ld_stream_shape(oracle):
+    from synth import synth
+    from vc2lib import make_params
+    w, h = 128, 64
+    raw = synth(w, h, "422", 8, 63, word_bytes=1)
+    p = make_params(w, h, "422", 8, "LeGall", 2, 2, 2, mode="LD", s=8000, word_bytes=1, interlaced=True, fragment_length=500)
+    units = _units(oracle.encode_stream(p, raw, 1))
+    params = [u for u in units if u[0] == 0xCC and int.from_bytes(u[3][6:8], "big") == 0]
+    assert [int.from_bytes(u[3][:4], "big") for u in params] == [0, 1]
+    # each field gets half the frame budget (EncodeStream.cpp:378)
+    for k in (0, 1):
+        total = sum(len(u[3]) - 12 for u in units if u[0] == 0xCC and int.from_bytes(u[3][:4], "big") == k and int.from_bytes(u[3][6:8], "big"))
+        assert total == 4000

@@ -30,13 +30,16 @@ class Params(C.Structure):
                 ("bit_depth", C.c_int), ("word_bytes", C.c_int), ("kernel", C.c_int),
                 ("depth", C.c_int), ("y_size", C.c_int), ("x_size", C.c_int),
                 ("mode", C.c_int), ("q_index", C.c_int), ("compressed_bytes", C.c_int),
-                ("scalar", C.c_int), ("prefix", C.c_int), ("frame_rate", C.c_int)]
+                ("scalar", C.c_int), ("prefix", C.c_int), ("frame_rate", C.c_int),
+                ("interlaced", C.c_int), ("bottom_field_first", C.c_int), ("fragment_length", C.c_int)]
 
 
 def make_params(width, height, cf, bits, kernel, depth, u, a, mode="HQ_ConstQ", q=0, s=0,
-                scalar=1, prefix=0, word_bytes=2, frame_rate=3):
+                scalar=1, prefix=0, word_bytes=2, frame_rate=3, interlaced=False, bottom_field_first=False,
+                fragment_length=0):
     return Params(width, height, CF[cf], bits, word_bytes, KERNELS[kernel], depth, u, a,
-                  MODES[mode], q, s, scalar, prefix, frame_rate)
+                  MODES[mode], q, s, scalar, prefix, frame_rate, int(interlaced), int(bottom_field_first),
+                  fragment_length)
 
 
 class OracleError(RuntimeError):

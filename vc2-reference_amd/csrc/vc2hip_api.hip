@@ -891,6 +891,118 @@ extern "C" int vc2hip_ld_unpack(vc2hip_ctx *c, const uint8_t *in, size_t len, co
 }
 
 // ------------------------------------------------------------------------------------------
+// LD encode
+// ------------------------------------------------------------------------------------------
+static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_store, int32_t *d_q, const int32_t *qm,
+                       const LLPlanes &ll, const int32_t *d_sb, const uint32_t *d_so, int max_slice, uint8_t *d_pay,
+                       long long stride) {
+  memset(&p, 0, sizeof p);
+  const int ns = g.ys * g.xs;
+  p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
+  p.slice_bytes = d_sb; p.offsets = d_so;
+  for (int k = 0; k < 3; ++k) {
+    p.restored[k] = ll.p[g.depth][k]; p.restored_stride[k] = ll.stride[g.depth][k];
+    p.ll_w[k] = g.c[k].pw >> g.depth;
+    p.bh[k] = (g.c[k].ph >> g.depth) / g.ys; p.bw[k] = (g.c[k].pw >> g.depth) / g.xs;
+  }
+  p.ys = g.ys; p.xs = g.xs; p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
+  for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
+  p.img_words = (max_slice + 3) / 4 + 2;
+  p.payload = d_pay; p.payload_stride = stride; p.err = c->d_err;
+  if ((size_t)g.slice_coefs * 32 > 160 * 1024 || (size_t)p.img_words * 16 > 160 * 1024)
+    return set_err(c, VC2HIP_EINVAL, "slice too large for the LD encode kernels");
+  return VC2HIP_OK;
+}
+
+/* quantise_transform (LD, DC-predicted LL band), Quantisation.cpp:358-367 over :213-234 */
+extern "C" int vc2hip_quantise_ld(vc2hip_ctx *c, const int32_t *coef, int ph, int pw, int depth, const int32_t *qidx,
+                                  int ys, int xs, const int32_t *qm, int32_t *out) {
+  if (!c || !coef || !out || !qidx || !qm) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = one_plane_geom(g, ph, pw, depth, ys, xs);
+  if (rc) return set_err(c, rc);
+  const size_t pb = (size_t)ph * pw * 4;
+  const int ns = ys * xs;
+  int32_t *d_plane, *d_store, *d_q, *d_ll;
+  NEED(c, B_PLANE, pb, d_plane);
+  NEED(c, B_STORE, pb, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  NEED(c, B_LL0, ll_bytes(g, 1) + 16, d_ll);
+  LLPlanes ll;
+  ll_layout(g, 1, d_ll, ll);
+  HIPCHK(c, hipMemcpyAsync(d_plane, coef, pb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_q, qidx, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  vc2_launch_plane_to_store(c->L, d_plane, ph, pw, depth, ys, xs, d_store, g.slice_coefs, 0, c->stream);
+  LdEncParams p;
+  if ((rc = fill_ld_enc(c, p, g, d_store, d_q, qm, ll, nullptr, nullptr, 0, nullptr, 0))) return rc;
+  p.search = 0;
+  vc2_launch_ld_quantise(c->L, p, 1, c->stream);
+  vc2_launch_store_to_plane(c->L, d_store, g.slice_coefs, 0, d_plane, ph, pw, depth, ys, xs, nullptr, nullptr, 0, c->d_err, c->stream);
+  HIPCHK(c, hipMemcpyAsync(out, d_plane, pb, hipMemcpyDeviceToHost, c->stream));
+  return vc2hip_sync(c);
+}
+
+/* quantIndicesLD(coefficients, qMatrix, sliceBytes), EncodeStream.cpp:141-245.  y,u,v: TRANSFORM planes */
+extern "C" int vc2hip_ld_qindices(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
+                                  const int32_t *qm, const int32_t *slice_bytes, int32_t *qidx) {
+  if (!c || !y || !u || !v || !ga || !qm || !slice_bytes || !qidx) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = geom_from_abi(g, ga);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int32_t *d_store, *d_q, *d_sb, *d_ll; uint32_t *d_so; uint64_t total;
+  NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  NEED(c, B_LL0, ll_bytes(g, 1) + 16, d_ll);
+  LLPlanes ll;
+  ll_layout(g, 1, d_ll, ll);
+  const int32_t *pl[3] = {y, u, v};
+  if ((rc = planes_to_store(c, g, pl, d_store))) return rc;
+  if ((rc = ld_offsets_upload(c, slice_bytes, ns, &d_sb, &d_so, &total))) return rc;
+  LdEncParams p;
+  if ((rc = fill_ld_enc(c, p, g, d_store, d_q, qm, ll, d_sb, d_so, 0, nullptr, 0))) return rc;
+  p.search = 1;
+  vc2_launch_ld_quantise(c->L, p, 1, c->stream);
+  HIPCHK(c, hipMemcpyAsync(qidx, d_q, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+  return vc2hip_sync(c);
+}
+
+/* operator<<(ostream&, const Slices&) under sliceio::lowDelay(bytes), Slices.cpp:645-660 over :195-244.
+ * y,u,v: QUANTISED planes (LL band as prediction residuals). */
+extern "C" int vc2hip_ld_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
+                              const int32_t *qidx, const int32_t *slice_bytes, uint8_t *out, size_t cap, size_t *out_len) {
+  if (!c || !y || !u || !v || !ga || !qidx || !slice_bytes || !out || !out_len) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  Geom g;
+  int rc = geom_from_abi(g, ga);
+  if (rc) return set_err(c, rc);
+  const int ns = g.ys * g.xs;
+  int mx = 1;
+  for (int i = 0; i < ns; ++i) { if (slice_bytes[i] < 1) return set_err(c, VC2HIP_EINVAL); mx = std::max(mx, slice_bytes[i]); }
+  int32_t *d_store, *d_q, *d_sb; uint32_t *d_so; uint8_t *d_pay; uint64_t total;
+  NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_QIDX, (size_t)ns * 4, d_q);
+  const int32_t *pl[3] = {y, u, v};
+  if ((rc = planes_to_store(c, g, pl, d_store))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d_q, qidx, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
+  if ((rc = ld_offsets_upload(c, slice_bytes, ns, &d_sb, &d_so, &total))) return rc;
+  if (total > cap) return set_err(c, VC2HIP_ECAP);
+  NEED(c, B_PAYLOAD, total + 64, d_pay);
+  LLPlanes ll;
+  memset(&ll, 0, sizeof ll);
+  LdEncParams p;
+  if ((rc = fill_ld_enc(c, p, g, d_store, d_q, nullptr, ll, d_sb, d_so, mx, d_pay, (long long)total))) return rc;
+  vc2_launch_ld_pack(c->L, p, 1, c->stream);
+  if ((rc = vc2hip_sync(c))) return rc;
+  HIPCHK(c, hipMemcpy(out, d_pay, total, hipMemcpyDeviceToHost));
+  *out_len = (size_t)total;
+  return VC2HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // fused picture path
 // ------------------------------------------------------------------------------------------
 static void raw_planes(const vc2hip_picture_format *f, const void *base, const void *pl[3], long long stride[3]) {
@@ -907,9 +1019,9 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
                                        const vc2hip_coding_params *cp, void *d_payload, size_t payload_stride,
                                        uint64_t *d_lens) {
   if (!c || !d_raw || n < 1 || !f || !cp || !d_payload || !d_lens) return set_err(c, VC2HIP_EINVAL);
-  if (cp->mode != VC2HIP_HQ_CONSTQ && cp->mode != VC2HIP_HQ_CBR) return set_err(c, VC2HIP_EINVAL, "only HQ modes are encoded");
+  if (cp->mode != VC2HIP_HQ_CONSTQ && cp->mode != VC2HIP_HQ_CBR && cp->mode != VC2HIP_LD) return set_err(c, VC2HIP_EINVAL);
   if (cp->kernel < 0 || cp->kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
-  if (cp->scalar < 1 || cp->prefix < 0) return set_err(c, VC2HIP_EINVAL);
+  if (cp->mode != VC2HIP_LD && (cp->scalar < 1 || cp->prefix < 0)) return set_err(c, VC2HIP_EINVAL);
   HIPCHK(c, hipSetDevice(c->device));
   Geom g;
   int rc = picture_geom(g, f, cp, false);
@@ -927,6 +1039,27 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
   raw_planes(f, d_raw, src, ss);
   if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll))) return rc;
   int32_t *d_cb = nullptr; uint32_t *d_co = nullptr; uint64_t total = 0;
+  if (cp->mode == VC2HIP_LD) {
+    // EncodeStream.cpp:509-512 (slice_bytes with scalar 1), :141-245, :195-244
+    const int key[5] = {g.ys, g.xs, cp->compressed_bytes, 1, -7};
+    if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
+      std::vector<int32_t> sb(ns);
+      vc2hip_slice_bytes(g.ys, g.xs, cp->compressed_bytes, 1, sb.data());
+      if ((rc = ld_offsets_upload(c, sb.data(), ns, &d_cb, &d_co, &total))) return rc;
+      memcpy(c->cbr_key, key, sizeof key);
+      c->cbr_total = total;
+    }
+    d_cb = (int32_t *)c->buf[B_CBRB].p; d_co = (uint32_t *)c->buf[B_CBRO].p; total = c->cbr_total;
+    if (total > payload_stride) return set_err(c, VC2HIP_ECAP);
+    LdEncParams p;
+    if ((rc = fill_ld_enc(c, p, g, d_store, d_q, qm, ll, d_cb, d_co, cp->compressed_bytes / ns + 5, (uint8_t *)d_payload,
+                          (long long)payload_stride))) return rc;
+    p.search = 1;
+    vc2_launch_ld_quantise(c->L, p, n, c->stream);
+    vc2_launch_ld_pack(c->L, p, n, c->stream);
+    vc2_launch_fill_u64(c->L, (unsigned long long *)d_lens, total, (size_t)n, c->stream);
+    return VC2HIP_OK;
+  }
   if (cp->mode == VC2HIP_HQ_CBR) {
     if ((size_t)g.slice_coefs * 16 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
     const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
@@ -1042,6 +1175,13 @@ extern "C" int vc2hip_encode_picture_hq(vc2hip_ctx *c, const void *raw, const vc
   HIPCHK(c, hipMemcpy(payload, d_pay, l, hipMemcpyDeviceToHost));
   *len = (size_t)l;
   return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_encode_picture_ld(vc2hip_ctx *c, const void *raw, const vc2hip_picture_format *f,
+                                        const vc2hip_coding_params *cp, uint8_t *payload, size_t cap, size_t *len,
+                                        int32_t *qidx_out) {
+  if (!cp || cp->mode != VC2HIP_LD) return set_err(c, VC2HIP_EINVAL);
+  return vc2hip_encode_picture_hq(c, raw, f, cp, payload, cap, len, qidx_out);
 }
 
 static int decode_picture_host(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,

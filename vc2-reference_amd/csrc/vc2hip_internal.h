@@ -212,3 +212,27 @@ struct LdUnpackParams {
   unsigned *err;
 };
 void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s);
+
+// LD encode: quantiser search / DC-predicted quantisation (one launch per slice anti-diagonal) and
+// the slice writer
+struct LdEncParams {
+  int32_t *store;             // in: transform coefficients; out: quantised (LL as prediction residuals)
+  long long store_stride;
+  int32_t *qidx;              // n_pictures * n_slices; written when search != 0
+  const int32_t *slice_bytes; // per slice
+  const uint32_t *offsets;    // per slice (prefix sums of slice_bytes)
+  int32_t *restored[3];       // reconstructed LL planes (scratch), ll_h x ll_w per picture
+  long long restored_stride[3];
+  int ll_w[3];
+  int bh[3], bw[3];           // LL block of one slice
+  int ys, xs, n_slices, slice_coefs;
+  int comp_n[3], comp_off[3], comp_n0[3];
+  int qmatrix[VC2_MAX_BANDS];
+  int search;
+  int img_words;              // LDS words of one slice image (pack)
+  uint8_t *payload;
+  long long payload_stride;
+  unsigned *err;
+};
+void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s);
+void vc2_launch_ld_pack(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s);

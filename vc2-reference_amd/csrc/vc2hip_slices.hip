@@ -119,7 +119,7 @@ __device__ __forceinline__ void put_code(unsigned *buf, int pos, unsigned code, 
 // and including the last non-zero coefficient (component_slice_bytes' `count`).
 template <bool QUANT, bool WRITE, class Src>
 __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, const int *qm, int lane,
-                                              unsigned *bits, int region_bits, unsigned *err) {
+                                              unsigned *bits, int region_bits, unsigned *err, int bit0 = 0) {
   int base = 0, count = 0;
   const int n0_shift = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
   for (int r0 = 0; r0 < n; r0 += 512) {
@@ -152,7 +152,7 @@ __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, con
       int pos = lane_base;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (nb[k] && pos + nb[k] <= region_bits) put_code(bits, pos, svlc_code(v[k]), nb[k]);
+        if (nb[k] && pos + nb[k] <= region_bits) put_code(bits, bit0 + pos, svlc_code(v[k]), nb[k]);
         pos += nb[k];
       }
     }
@@ -1290,6 +1290,143 @@ void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride,
   vc2_prof_begin(L, "ld_ll_predict", s);
   hipLaunchKernelGGL(k_ld_ll, dim3(n_pictures), dim3(1024), 0, s, store, store_stride, slice_coefs, coef_off, n0,
                      llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
+  vc2_prof_end(L, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// LD encode (legacy profile): per-slice quantiser search with the DC-prediction state machine
+// (EncodeStream.cpp:141-245 quantIndicesLD + SliceQuantiserRef), DC-predicted quantisation of the
+// LL band (Quantisation.cpp:213-234) and the LD slice writer (Slices.cpp:195-244).
+//
+// A slice's LL predictions read the reconstructed LL samples of the slices above, left and
+// above-left only, so the slices of one anti-diagonal are independent: one launch per diagonal,
+// one wavefront per slice.  The last pass of a slice (at its chosen index) leaves the quantised
+// coefficients -- LL band as prediction residuals -- in the coefficient store, in coding order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, int d) {
+  extern __shared__ int lds_i[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pic = blockIdx.y;
+  const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x * 4 + wave;
+  if (sv > min(p.ys - 1, d)) return; // no workgroup barriers below
+  const int sh = d - sv, slice = sv * p.xs + sh;
+  int *co = lds_i + wave * 2 * p.slice_coefs, *qv = co + p.slice_coefs;
+  int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
+
+  // quantise the whole slice at index tq into qv; true if an adjusted index leaves the table
+  auto quantise_at = [&](int tq) -> bool {
+    bool bad = false;
+    if (lane == 0) { // LL blocks: serial raster scan, prediction from the reconstructed plane
+      const int aq = max(tq - p.qmatrix[0], 0);
+      if (aq > 119) bad = true;
+      for (int c = 0; c < 3 && !bad; ++c) {
+        if (!p.comp_n[c]) continue;
+        int32_t *res = p.restored[c] + (size_t)pic * p.restored_stride[c];
+        const int llw = p.ll_w[c], bh = p.bh[c], bw = p.bw[c];
+        for (int yy = 0; yy < bh; ++yy)
+          for (int xx = 0; xx < bw; ++xx) {
+            const int y = sv * bh + yy, x = sh * bw + xx;
+            int pred; // predictDC, Quantisation.cpp:191-208
+            if (y > 0 && x > 0) {
+              const int r = res[(size_t)(y - 1) * llw + x - 1] + res[(size_t)(y - 1) * llw + x] + res[(size_t)y * llw + x - 1];
+              pred = r >= 0 ? (r + 1) / 3 : (r - 1) / 3;
+            } else if (y > 0) pred = res[(size_t)(y - 1) * llw + x];
+            else if (x > 0) pred = res[(size_t)y * llw + x - 1];
+            else pred = 0;
+            const int v = co[p.comp_off[c] + yy * bw + xx];
+            const int qq = quant_dev((int)((unsigned)v - (unsigned)pred), aq);
+            res[(size_t)y * llw + x] = (int)((unsigned)scale_dev(qq, aq) + (unsigned)pred);
+            qv[p.comp_off[c] + yy * bw + xx] = qq;
+          }
+      }
+    }
+    for (int c = 0; c < 3; ++c) {
+      const int n = p.comp_n[c], n0 = p.comp_n0[c], off = p.comp_off[c];
+      if (!n) continue;
+      const int n0_shift = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
+      for (int j = n0 + lane; j < n; j += 64) {
+        const int aq = max(tq - p.qmatrix[band_of_index_fast(j, n0, n0_shift)], 0);
+        if (aq > 119) { bad = true; continue; }
+        qv[off + j] = quant_dev(co[off + j], aq);
+      }
+    }
+    return __any(bad);
+  };
+  // luma_slice_bits + chroma_slice_bits, Slices.cpp:51-95 (U and V coefficients alternate)
+  auto need_bits = [&]() -> int {
+    auto ly = [&](int j) -> int { return qv[p.comp_off[0] + j]; };
+    auto lc = [&](int j) -> int { return qv[p.comp_off[1 + (j & 1)] + (j >> 1)]; };
+    return component_bits<false, false>(ly, p.comp_n[0], 1, 0, nullptr, lane, nullptr, 0, p.err) +
+           component_bits<false, false>(lc, 2 * p.comp_n[1], 1, 0, nullptr, lane, nullptr, 0, p.err);
+  };
+
+  int q;
+  bool bad = false;
+  if (p.search) {
+    const int bytes = p.slice_bytes[slice];
+    const int avail = 8 * bytes - 7 - intlog2_dev(8 * bytes - 7);
+    int trial = 63, delta = 64;
+    q = 127;
+    while (delta > 0) {
+      delta >>= 1;
+      if ((bad = quantise_at(trial))) break;
+      if (need_bits() <= avail) { if (trial < q) q = trial; trial -= delta; }
+      else trial += delta;
+    }
+    if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
+  } else {
+    q = p.qidx[(size_t)pic * p.n_slices + slice];
+  }
+  if (!bad) bad = quantise_at(q);
+  if (bad) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); return; }
+  for (int i = lane; i < p.slice_coefs; i += 64) rec[i] = qv[i];
+}
+
+// LD slice writer: one wavefront per slice, image assembled in LDS as big-endian words
+__global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
+  extern __shared__ unsigned lds_u[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  if (slice >= p.n_slices) return;
+  const int size = p.slice_bytes[slice];
+  unsigned *img = lds_u + wave * p.img_words;
+  for (int i = lane; i < p.img_words; i += 64) img[i] = 0;
+  const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  auto ly = [&](int j) -> int { return rec[p.comp_off[0] + j]; };
+  auto lc = [&](int j) -> int { return rec[p.comp_off[1 + (j & 1)] + (j >> 1)]; };
+  const int ybits = component_bits<false, false>(ly, p.comp_n[0], 1, 0, nullptr, lane, nullptr, 0, p.err);
+  const int cbits = component_bits<false, false>(lc, 2 * p.comp_n[1], 1, 0, nullptr, lane, nullptr, 0, p.err);
+  const int split = intlog2_dev(8 * size - 7);
+  const int uvbits = 8 * size - 7 - split - ybits;
+  if (uvbits < cbits) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_LD_TOOBIG); return; }
+  if (lane == 0) {
+    put_code(img, 0, (unsigned)p.qidx[(size_t)pic * p.n_slices + slice] & 127u, 7);
+    if (split > 0) put_code(img, 7, (unsigned)ybits, split);
+  }
+  // bounded writes: codes wholly past the bound are 1-bits of trailing zeros and are dropped
+  // (VLC.cpp:151-172); flush pads the bound with 0 bits, which the zeroed image already holds
+  component_bits<false, true>(ly, p.comp_n[0], 1, 0, nullptr, lane, img, ybits, p.err, 7 + split);
+  component_bits<false, true>(lc, 2 * p.comp_n[1], 1, 0, nullptr, lane, img, uvbits, p.err, 7 + split + ybits);
+  uint8_t *out = p.payload + (size_t)pic * p.payload_stride + p.offsets[slice];
+  for (int k = lane; k < size; k += 64) out[k] = (uint8_t)(img[k >> 2] >> (24 - 8 * (k & 3)));
+}
+
+void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_ld_quantise_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
+  for (int d = 0; d < p.ys + p.xs - 1; ++d) {
+    const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
+    hipLaunchKernelGGL(k_ld_quantise_diag, dim3((cnt + 3) / 4, n_pictures), dim3(256), (size_t)4 * 2 * p.slice_coefs * 4, s, p, d);
+  }
+  vc2_prof_end(L, s);
+}
+void vc2_launch_ld_pack(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_ld_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_prof_begin(L, "ld_pack", s);
+  hipLaunchKernelGGL(k_ld_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), (size_t)4 * p.img_words * 4, s, p);
   vc2_prof_end(L, s);
 }
 

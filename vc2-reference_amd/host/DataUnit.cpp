@@ -356,24 +356,43 @@ SequenceHeader readSequenceHeader(const unsigned char *p, std::size_t n, std::si
   return h;
 }
 
+static void putTransformParams(BitWriter &w, WaveletKernel kernel, int depth, bool v3_flags, int slices_x, int slices_y,
+                               unsigned a, unsigned b) {
+  w.putUnsignedVLC((unsigned)kernel);
+  w.putUnsignedVLC((unsigned)depth);
+  if (v3_flags) { w.putBoolean(false); w.putBoolean(false); } // asym_transform_index_flag, asym_transform_flag
+  w.putUnsignedVLC((unsigned)slices_x); w.putUnsignedVLC((unsigned)slices_y);
+  w.putUnsignedVLC(a); w.putUnsignedVLC(b);
+  w.putBoolean(false); // custom quantisation matrix
+  w.align();
+}
+
 std::vector<unsigned char> writePictureHeaderHQ(unsigned long picture_number, WaveletKernel kernel, int depth,
                                                 int slices_x, int slices_y, int prefix, int scalar, int major_version) {
   BitWriter w;
   w.putBytes(4, picture_number);
-  w.putUnsignedVLC((unsigned)kernel);
-  w.putUnsignedVLC((unsigned)depth);
-  if (major_version >= 3) { w.putBoolean(false); w.putBoolean(false); }
-  w.putUnsignedVLC((unsigned)slices_x); w.putUnsignedVLC((unsigned)slices_y);
-  w.putUnsignedVLC((unsigned)prefix); w.putUnsignedVLC((unsigned)scalar);
-  w.putBoolean(false);
-  w.align();
+  putTransformParams(w, kernel, depth, major_version >= 3, slices_x, slices_y, (unsigned)prefix, (unsigned)scalar);
   return w.bytes();
 }
 
-std::size_t readPictureHeader(const unsigned char *p, std::size_t n, bool low_delay, int major_version,
-                              unsigned long *picture_number, PicturePreamble *pre) {
-  BitReader r(p, n);
-  *picture_number = r.getBytes(4);
+std::vector<unsigned char> writePictureHeaderLD(unsigned long picture_number, WaveletKernel kernel, int depth,
+                                                int slices_x, int slices_y, const utils::Rational &slice_bytes,
+                                                int major_version) {
+  BitWriter w;
+  w.putBytes(4, picture_number);
+  putTransformParams(w, kernel, depth, major_version >= 3, slices_x, slices_y, (unsigned)slice_bytes.numerator,
+                     (unsigned)slice_bytes.denominator);
+  return w.bytes();
+}
+
+std::vector<unsigned char> writeTransformParams(WaveletKernel kernel, int depth, bool v3_flags, int slices_x,
+                                                int slices_y, unsigned a, unsigned b) {
+  BitWriter w;
+  putTransformParams(w, kernel, depth, v3_flags, slices_x, slices_y, a, b);
+  return w.bytes();
+}
+
+static void readParams(BitReader &r, bool low_delay, int major_version, PicturePreamble *pre) {
   const unsigned wavelet_index = r.getUnsignedVLC();
   pre->depth = (int)r.getUnsignedVLC();
   pre->wavelet_kernel = wavelet_index <= 6 ? (WaveletKernel)wavelet_index : NullKernel;
@@ -388,5 +407,83 @@ std::size_t readPictureHeader(const unsigned char *p, std::size_t n, bool low_de
   else { pre->slice_prefix = a; pre->slice_size_scalar = b; pre->slice_bytes = utils::rationalise(0, 1); }
   if (r.getBoolean()) throw std::logic_error("DataUnitIO: Custom Quantisation Matrix flag not supported");
   r.align();
+}
+
+std::size_t readPictureHeader(const unsigned char *p, std::size_t n, bool low_delay, int major_version,
+                              unsigned long *picture_number, PicturePreamble *pre) {
+  BitReader r(p, n);
+  *picture_number = r.getBytes(4);
+  readParams(r, low_delay, major_version, pre);
   return r.bytePos();
+}
+
+std::size_t readTransformParams(const unsigned char *p, std::size_t n, bool low_delay, int major_version,
+                                PicturePreamble *pre) {
+  BitReader r(p, n);
+  readParams(r, low_delay, major_version, pre);
+  return r.bytePos();
+}
+
+std::size_t readFragmentHeader(const unsigned char *p, std::size_t n, Fragment *frag) {
+  BitReader r(p, n);
+  frag->picture_number = r.getBytes(4);
+  frag->length = (unsigned)r.getBytes(2);
+  frag->n_slices = (int)r.getBytes(2);
+  frag->slice_offset_x = frag->slice_offset_y = 0;
+  if (frag->n_slices != 0) {
+    frag->slice_offset_x = (int)r.getBytes(2);
+    frag->slice_offset_y = (int)r.getBytes(2);
+  }
+  return r.bytePos();
+}
+
+std::vector<std::size_t> sliceSizesHQ(const unsigned char *payload, std::size_t len, int n_slices, int prefix, int scalar) {
+  std::vector<std::size_t> sizes((std::size_t)n_slices);
+  std::size_t pos = 0;
+  for (int i = 0; i < n_slices; ++i) {
+    std::size_t q = pos + (std::size_t)prefix + 1;
+    for (int c = 0; c < 3; ++c) {
+      if (q >= len) throw std::logic_error("slice data runs past the end of the picture");
+      q += 1 + (std::size_t)payload[q] * (std::size_t)scalar;
+    }
+    if (q > len) throw std::logic_error("slice data runs past the end of the picture");
+    sizes[(std::size_t)i] = q - pos;
+    pos = q;
+  }
+  return sizes;
+}
+
+void writeFragmentedPicture(std::vector<unsigned char> &out, bool low_delay, unsigned long picture_number,
+                            const std::vector<unsigned char> &transform_params, const unsigned char *payload,
+                            const std::vector<std::size_t> &slice_sizes, int slices_x, int fragment_length,
+                            unsigned long *prev_parse_offset) {
+  const DataUnitType type = low_delay ? LD_FRAGMENT : HQ_FRAGMENT;
+  auto bytes = [&](int n, unsigned long v) { for (int i = n - 1; i >= 0; --i) out.push_back((unsigned char)(v >> (8 * i))); };
+  auto unit = [&](std::size_t data_size) {
+    writeParseInfo(out, type, (unsigned long)data_size + 13, *prev_parse_offset);
+    *prev_parse_offset = (unsigned long)data_size + 13;
+  };
+  unit(transform_params.size() + 8);
+  bytes(4, picture_number); bytes(2, (unsigned long)transform_params.size()); bytes(2, 0);
+  out.insert(out.end(), transform_params.begin(), transform_params.end());
+
+  auto fragment = [&](std::size_t first_byte, std::size_t n_bytes, int nslices, int ox, int oy) {
+    unit(n_bytes + 12);
+    bytes(4, picture_number); bytes(2, (unsigned long)n_bytes); bytes(2, (unsigned long)nslices);
+    bytes(2, (unsigned long)ox); bytes(2, (unsigned long)oy);
+    out.insert(out.end(), payload + first_byte, payload + first_byte + n_bytes);
+  };
+  std::size_t frag_start = 0, frag_bytes = 0, pos = 0;
+  int nslices = 0, ox = 0, oy = 0;
+  for (std::size_t i = 0; i < slice_sizes.size(); ++i) {
+    if (nslices > 0 && (long)(frag_bytes + slice_sizes[i]) > (long)fragment_length) {
+      fragment(frag_start, frag_bytes, nslices, ox, oy);
+      ox = (int)(i % (std::size_t)slices_x); oy = (int)(i / (std::size_t)slices_x);
+      nslices = 0; frag_start = pos; frag_bytes = 0;
+    }
+    frag_bytes += slice_sizes[i];
+    pos += slice_sizes[i];
+    ++nslices;
+  }
+  fragment(frag_start, frag_bytes, nslices, ox, oy);
 }

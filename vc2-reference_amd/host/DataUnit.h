@@ -76,6 +76,35 @@ struct PicturePreamble {
 std::vector<unsigned char> writePictureHeaderHQ(unsigned long picture_number, WaveletKernel kernel, int depth,
                                                 int slices_x, int slices_y, int prefix, int scalar,
                                                 int major_version);
+std::vector<unsigned char> writePictureHeaderLD(unsigned long picture_number, WaveletKernel kernel, int depth,
+                                                int slices_x, int slices_y, const utils::Rational &slice_bytes,
+                                                int major_version);
+// transform parameters alone, as the first fragment of a picture carries them: the two asymmetric-transform
+// flags are always present there (DataUnit.cpp:159-176 / :270-287).  a,b = prefix,scalar (HQ) or the
+// slice-bytes numerator,denominator (LD).
+std::vector<unsigned char> writeTransformParams(WaveletKernel kernel, int depth, bool v3_flags, int slices_x,
+                                                int slices_y, unsigned a, unsigned b);
+// DataUnit.cpp:1340-1410 without the picture number; returns bytes consumed
+std::size_t readTransformParams(const unsigned char *p, std::size_t n, bool low_delay, int major_version,
+                                PicturePreamble *pre);
+
+// fragment header that follows the parse info of an HQ/LD fragment (DataUnit.cpp:1146-1164 after the
+// 4-byte picture number): data length, slice count and, when the count is non-zero, the slice offset
+struct Fragment {
+  unsigned long picture_number;
+  unsigned length;
+  int n_slices, slice_offset_x, slice_offset_y;
+};
+std::size_t readFragmentHeader(const unsigned char *p, std::size_t n, Fragment *frag);
+// bytes of each slice of an HQ payload (prefix, index byte, three length-prefixed components,
+// Slices.cpp:535-612) or of an LD payload (slice_bytes table); throws if the payload is short
+std::vector<std::size_t> sliceSizesHQ(const unsigned char *payload, std::size_t len, int n_slices, int prefix, int scalar);
+// all data units of one fragmented picture (DataUnit.cpp:156-232 / :267-342): the parameter fragment, then
+// fragments of whole slices filled up to fragment_length bytes.  Chains prev_parse_offset.
+void writeFragmentedPicture(std::vector<unsigned char> &out, bool low_delay, unsigned long picture_number,
+                            const std::vector<unsigned char> &transform_params, const unsigned char *payload,
+                            const std::vector<std::size_t> &slice_sizes, int slices_x, int fragment_length,
+                            unsigned long *prev_parse_offset);
 // DataUnit.cpp:1332-1410; low_delay selects the LD field layout; returns bytes consumed
 std::size_t readPictureHeader(const unsigned char *p, std::size_t n, bool low_delay, int major_version,
                               unsigned long *picture_number, PicturePreamble *pre);

@@ -6,10 +6,12 @@
 #include <fstream>
 #include <iostream>
 #include <iterator>
+#include <map>
 #include <thread>
 
 #include "Args.h"
 #include "DataUnit.h"
+#include "Frame.h"
 #include "Hip.h"
 #include "Picture.h"
 #include "Quantisation.h"
@@ -44,10 +46,20 @@ static const char *USAGE = "DecodeStream (MI355X / libvc2hip)\nUsage: DecodeStre
 struct Job { // one picture waiting for its GPU
   bool ld;
   PicturePreamble pre;
-  const unsigned char *data;
+  const unsigned char *data; // slice bytes inside the input, or owned.data() for a reassembled picture
   std::size_t len;
-  std::vector<unsigned char> raw;
+  int compressedBytes;       // LD byte budget of the picture
+  std::vector<unsigned char> owned, raw;
   string error;
+};
+
+struct Reassembly { // slices of a fragmented picture collected so far (DecodeStream.cpp:62-101)
+  bool ld;
+  PicturePreamble pre;
+  int compressedBytes;
+  Array2D sliceBytes; // LD
+  std::vector<std::vector<unsigned char> > slices;
+  int decoded;
 };
 
 int main(int argc, char *argv[]) {
@@ -77,13 +89,18 @@ int main(int argc, char *argv[]) {
 
     bool have_seq_hdr = false;
     int height = 0, width = 0, bytes = 0, depthBits = 0, major_version = 2;
+    bool interlaced = false, topFieldFirst = true;
     ColourFormat chromaFormat = CF_UNSET;
-    int frame = 0;
+    int frame = 0, pic = 0;
     std::vector<Job> jobs;
+    std::vector<unsigned char> outFrame; // interlaced: the frame being filled field by field
+    std::map<unsigned long, Reassembly> reassembling;
 
     auto flush = [&]() { // decode the queued pictures, picture k on GPU k, and write them in order
       if (jobs.empty()) return;
-      vc2hip_picture_format pf = {width, height, (int)chromaFormat, depthBits, bytes};
+      const int pictureHeight = interlaced ? height / 2 : height;
+      const PictureFormat frameFormat(height, width, chromaFormat);
+      vc2hip_picture_format pf = {width, pictureHeight, (int)chromaFormat, depthBits, bytes};
       std::vector<std::thread> th;
       for (std::size_t g = 0; g < jobs.size(); ++g)
         th.emplace_back([&, g]() {
@@ -91,21 +108,70 @@ int main(int argc, char *argv[]) {
           try {
             vc2hip_ctx *c = hipContext((int)g);
             vc2hip_coding_params cp = {(int)j.pre.wavelet_kernel, j.pre.depth, j.pre.slices_y, j.pre.slices_x,
-                                       j.ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0,
-                                       j.ld ? (j.pre.slice_bytes.numerator * j.pre.slices_y * j.pre.slices_x) / j.pre.slice_bytes.denominator : 0,
-                                       j.pre.slice_prefix, j.pre.slice_size_scalar};
+                                       j.ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0, j.compressedBytes, j.pre.slice_prefix,
+                                       j.pre.slice_size_scalar};
+            const unsigned char *data = j.owned.empty() ? j.data : j.owned.data();
             j.raw.resize(vc2hip_raw_picture_bytes(&pf));
-            hipCheck(c, (j.ld ? vc2hip_decode_picture_ld : vc2hip_decode_picture_hq)(c, j.data, j.len, &pf, &cp, j.raw.data()));
+            hipCheck(c, (j.ld ? vc2hip_decode_picture_ld : vc2hip_decode_picture_hq)(c, data, j.len, &pf, &cp, j.raw.data()));
           } catch (const std::exception &e) { j.error = e.what(); }
         });
       for (auto &t : th) t.join();
       for (Job &j : jobs) {
         if (!j.error.empty()) throw std::logic_error(j.error);
-        if (verbose) clog << "Writing decoded output file" << endl;
-        out->write((const char *)j.raw.data(), (std::streamsize)j.raw.size());
+        if (verbose) clog << "Copy picture to output frame" << endl;
+        if (interlaced) { // DecodeStream.cpp:417-428: first field, then second field, then the frame is written
+          if (pic == 0) outFrame.assign((std::size_t)frameFormat.samples() * bytes, 0);
+          insertFieldRaw(outFrame.data(), frameFormat, bytes, (pic == 0) == topFieldFirst, j.raw.data());
+          if (pic == 0) { pic = 1; continue; }
+          pic = 0;
+          if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
+          out->write((const char *)outFrame.data(), (std::streamsize)outFrame.size());
+        } else {
+          if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
+          out->write((const char *)j.raw.data(), (std::streamsize)j.raw.size());
+        }
         ++frame;
       }
       jobs.clear();
+    };
+
+    // one complete picture's slice bytes: queue it for a GPU, or run the diagnostic outputs
+    auto handlePicture = [&](bool ld, const PicturePreamble &pre, int compressedBytes, const unsigned char *data, std::size_t dlen,
+                             std::vector<unsigned char> *owned) {
+      const int pictureHeight = interlaced ? height / 2 : height;
+      if (output == DECODED) {
+        Job j; j.ld = ld; j.pre = pre; j.data = data; j.len = dlen; j.compressedBytes = compressedBytes;
+        if (owned) j.owned.swap(*owned);
+        jobs.push_back(j);
+        if ((int)jobs.size() == gpus) flush();
+        return;
+      }
+      // diagnostic outputs through the fine-grained functions
+      const int ph = paddedSize(pictureHeight, pre.depth), pw = paddedSize(width, pre.depth);
+      const PictureFormat tf(ph, pw, chromaFormat); // DecodeStream.cpp:483-498
+      Picture q(tf);
+      Array2D qIndices(pre.slices_y, pre.slices_x);
+      if (ld) unpackSlicesLD(data, dlen, q, pre.depth, qIndices, slice_bytes(pre.slices_y, pre.slices_x, compressedBytes, 1), nullptr);
+      else unpackSlicesHQ(data, dlen, q, pre.depth, qIndices, pre.slice_prefix, pre.slice_size_scalar, nullptr);
+      if (verbose) clog << "Merge slices into full picture" << endl;
+      if (output == INDICES) {
+        clog << "Writing quantisation indices to output file" << endl;
+        for (std::size_t i = 0; i < qIndices.num_elements(); ++i) out->put((char)qIndices.data()[i]);
+      } else if (output == QUANTISED) {
+        clog << "Writing quantised transform coefficients to output file" << endl;
+        writePicture4(*out, q);
+      } else {
+        if (verbose) clog << "Inverse quantise" << endl;
+        const Array1D qm = quantMatrix(pre.wavelet_kernel, pre.depth);
+        clog << "Writing transform coefficients to output file" << endl;
+        writePicture4(*out, ld ? inverse_quantise_transform(q, qIndices, qm) : inverse_quantise_transform_np(q, qIndices, qm));
+      }
+    };
+    // LD byte budget of one picture as the reference derives it (DecodeStream.cpp:312, :331): the budget in the
+    // transform parameters is already per picture, and the reference halves it once more for interlaced streams
+    auto ldPictureBytes = [&](const PicturePreamble &pre) {
+      const int compressed = (pre.slice_bytes.numerator * pre.slices_y * pre.slices_x) / pre.slice_bytes.denominator;
+      return interlaced ? compressed / 2 : compressed;
     };
 
     while (true) {
@@ -125,7 +191,9 @@ int main(int argc, char *argv[]) {
             clog << "height        = " << h.height << endl << "width         = " << h.width << endl;
             clog << "chroma format = " << h.chromaFormat << endl << "interlaced    = " << std::boolalpha << h.interlace << endl;
           }
-          if (h.interlace) throw std::logic_error("interlaced streams are not supported by the MI355X tools yet");
+          interlaced = h.interlace; topFieldFirst = h.topFieldFirst;
+          if (interlaced && ((h.height & 1) || (PictureFormat(h.height, h.width, h.chromaFormat).chromaHeight() & 1)))
+            throw std::logic_error("interlaced coding needs even luma and chroma heights");
           height = h.height; width = h.width; chromaFormat = h.chromaFormat; depthBits = h.bitdepth;
           bytes = h.bitdepth == 8 ? 1 : 2; // DecodeStream.cpp:268-271
           major_version = h.major_version;
@@ -159,33 +227,81 @@ int main(int argc, char *argv[]) {
           const std::size_t unit = du.next_parse_offset ? (std::size_t)du.next_parse_offset - 13 : avail;
           const std::size_t dlen = (unit > hdr ? unit : hdr) - hdr;
           if (!have_seq_hdr) { clog << "Cannot decode frame, no previous sequence header!" << endl; used = unit; break; }
-          if (output == DECODED) {
-            Job j; j.ld = ld; j.pre = pre; j.data = body + hdr; j.len = dlen < avail - hdr ? dlen : avail - hdr;
-            jobs.push_back(j);
-            if ((int)jobs.size() == gpus) flush();
-          } else { // diagnostic outputs through the fine-grained functions
-            const int ph = paddedSize(height, pre.depth), pw = paddedSize(width, pre.depth);
-            const PictureFormat tf(ph, pw, chromaFormat); // DecodeStream.cpp:483-498
-            Picture q(tf);
-            Array2D qIndices(pre.slices_y, pre.slices_x);
-            if (ld) {
-              const int compressed = (pre.slice_bytes.numerator * pre.slices_y * pre.slices_x) / pre.slice_bytes.denominator;
-              unpackSlicesLD(body + hdr, dlen, q, pre.depth, qIndices, slice_bytes(pre.slices_y, pre.slices_x, compressed, 1), nullptr);
-            } else unpackSlicesHQ(body + hdr, dlen, q, pre.depth, qIndices, pre.slice_prefix, pre.slice_size_scalar, nullptr);
-            if (output == INDICES) { for (std::size_t i = 0; i < qIndices.num_elements(); ++i) out->put((char)qIndices.data()[i]); }
-            else if (output == QUANTISED) writePicture4(*out, q);
-            else {
-              const Array1D qm = quantMatrix(pre.wavelet_kernel, pre.depth);
-              writePicture4(*out, ld ? inverse_quantise_transform(q, qIndices, qm) : inverse_quantise_transform_np(q, qIndices, qm));
-            }
-            ++frame;
+          if (verbose) {
+            const Array1D qm = quantMatrix(pre.wavelet_kernel, pre.depth);
+            clog << "Quantisation matrix = " << qm[0];
+            for (std::size_t i = 1; i < qm.size(); ++i) clog << ", " << qm[i];
+            clog << endl;
+            if (interlaced) clog << "Reading compressed input field " << pic << " of frame " << frame << endl;
+            else clog << "Reading compressed input frame number " << frame << endl;
           }
+          handlePicture(ld, pre, ld ? ldPictureBytes(pre) : 0, body + hdr, dlen < avail - hdr ? dlen : avail - hdr, nullptr);
+          if (output != DECODED) ++frame;
           used = unit;
           break;
         }
         case HQ_FRAGMENT:
-        case LD_FRAGMENT:
-          throw std::logic_error("picture fragments are not supported by the MI355X tools yet");
+        case LD_FRAGMENT: {
+          // DecodeStream.cpp:614-797 (LD) / :799-977 (HQ): a parameters fragment opens the picture, slice
+          // fragments fill it; the picture is decoded once all of its slices have arrived
+          const bool ld = du.type == LD_FRAGMENT;
+          if (verbose) clog << "Parsing " << (ld ? "LD" : "HQ") << " Fragment" << endl;
+          Fragment frag;
+          const std::size_t fh = readFragmentHeader(body, avail, &frag);
+          const std::size_t unit = du.next_parse_offset ? (std::size_t)du.next_parse_offset - 13 : avail;
+          used = unit;
+          if (frag.n_slices == 0) {
+            if (verbose) clog << "Parsing Picture Header" << endl;
+            PicturePreamble pre;
+            readTransformParams(body + fh, avail - fh, ld, major_version, &pre);
+            if (verbose) {
+              clog << "Picture number      : " << frag.picture_number << endl << "Wavelet Kernel      : " << pre.wavelet_kernel << endl;
+              clog << "Transform Depth     : " << pre.depth << endl << "Slices Horizontally : " << pre.slices_x << endl;
+              clog << "Slices Verically    : " << pre.slices_y << endl;
+            }
+            if (!have_seq_hdr) { clog << "Cannot decode frame, no previous sequence header!" << endl; break; }
+            Reassembly r;
+            r.ld = ld; r.pre = pre; r.decoded = 0;
+            r.compressedBytes = ld ? ldPictureBytes(pre) : 0;
+            if (ld) r.sliceBytes = slice_bytes(pre.slices_y, pre.slices_x, r.compressedBytes, 1);
+            r.slices.assign((std::size_t)pre.slices_y * pre.slices_x, std::vector<unsigned char>());
+            reassembling[frag.picture_number] = r;
+            break;
+          }
+          std::map<unsigned long, Reassembly>::iterator it = reassembling.find(frag.picture_number);
+          if (it == reassembling.end()) {
+            clog << "Cannot decode slices as no picture header yet read for picture number " << frag.picture_number << endl;
+            break;
+          }
+          Reassembly &r = it->second;
+          if (verbose)
+            clog << "Picture " << frag.picture_number << ": Reading " << frag.n_slices << " slices, starting from ("
+                 << frag.slice_offset_x << ", " << frag.slice_offset_y << ")" << endl;
+          const int ns = r.pre.slices_x * r.pre.slices_y;
+          int si = frag.slice_offset_y * r.pre.slices_x + frag.slice_offset_x;
+          const unsigned char *p = body + fh;
+          std::size_t left = (unit > fh ? unit : fh) - fh;
+          if (left > avail - fh) left = avail - fh;
+          for (int k = 0; k < frag.n_slices && si < ns; ++k, ++si) { // Slices.cpp:662-694 with ExpectedSlicesForFragment
+            std::size_t size;
+            if (ld) size = (std::size_t)r.sliceBytes.data()[si];
+            else size = sliceSizesHQ(p, left, 1, r.pre.slice_prefix, r.pre.slice_size_scalar)[0];
+            if (size > left) throw std::logic_error("slice data runs past the end of the fragment");
+            r.slices[(std::size_t)si].assign(p, p + size);
+            p += size; left -= size;
+          }
+          r.decoded += frag.n_slices;
+          if (r.decoded >= ns) {
+            std::vector<unsigned char> payload;
+            for (const std::vector<unsigned char> &sl : r.slices) payload.insert(payload.end(), sl.begin(), sl.end());
+            const Reassembly done = r;
+            reassembling.erase(it);
+            const std::size_t plen = payload.size();
+            handlePicture(done.ld, done.pre, done.compressedBytes, payload.data(), plen, &payload);
+            if (output != DECODED) ++frame;
+          }
+          break;
+        }
         default:
           break;
       }

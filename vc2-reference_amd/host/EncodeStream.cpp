@@ -12,6 +12,7 @@
 
 #include "Args.h"
 #include "DataUnit.h"
+#include "Frame.h"
 #include "Hip.h"
 #include "Picture.h"
 #include "Quantisation.h"
@@ -69,9 +70,9 @@ static const std::vector<ArgSpec> SPECS = {
 
 static const char *USAGE =
     "EncodeStream (MI355X / libvc2hip)\n"
-    "Usage: EncodeStream -m <HQ_ConstQ|HQ_CBR> -k <kernel> -d <depth> -u <vSlice> -a <hSlice> -f <4:4:4|4:2:2|4:2:0>\n"
+    "Usage: EncodeStream -m <HQ_ConstQ|HQ_CBR|LD> -k <kernel> -d <depth> -u <vSlice> -a <hSlice> -f <4:4:4|4:2:2|4:2:0>\n"
     "       -x <width> -y <height> [-l lumaDepth] [-c chromaDepth] [-z bitDepth] [-n bytes] [-r framerate]\n"
-    "       [-q quantIndex] [-s compressedBytes] [-S scalar] [-P prefix] [-o Transform|Quantised|Indices|Packaged|\n"
+    "       [-i [-t|-b]] [-F fragmentLength] [-q quantIndex] [-s compressedBytes] [-S scalar] [-P prefix] [-o Transform|Quantised|Indices|Packaged|\n"
     "       Stream|Decoded|PSNR] [-v] [--gpus N] inFile outFile      (\"-\" = standard input / output)\n";
 
 struct Encoded { std::vector<unsigned char> payload; Array2D qidx; string error; };
@@ -82,7 +83,7 @@ int main(int argc, char *argv[]) {
     // ---- parameters: EncodeParams.cpp:80-204 ----
     string inFileName, outFileName; bool verbose; int height, width, bytes, lumaDepth, chromaDepth; ColourFormat chromaFormat;
     WaveletKernel kernel; int waveletDepth, ySize, xSize; Output output; Mode mode; int frameRate, sliceScalar, slicePrefix;
-    int fragmentLength, compressedBytes, qIndex, gpus;
+    int fragmentLength, compressedBytes, qIndex, gpus; bool interlaced, topFieldFirst;
     try {
       Args a(SPECS, argc, argv);
       if (a.isSet("help")) { cout << USAGE; return EXIT_SUCCESS; }
@@ -103,6 +104,7 @@ int main(int argc, char *argv[]) {
       sliceScalar = a.getInt("scalar", 1); slicePrefix = a.getInt("prefix", 0);
       fragmentLength = a.getInt("fragmentLength", 0); compressedBytes = a.getInt("compressedBytes", 0);
       qIndex = a.getInt("quantIndex", 0); gpus = a.getInt("gpus", 1);
+      interlaced = a.isSet("interlace"); topFieldFirst = !a.isSet("bottomFieldFirst"); // EncodeParams.cpp:123-124
       if (a.isSet("bitDepth") && (a.isSet("lumaDepth") || a.isSet("chromaDepth")))
         throw std::invalid_argument("bitDepth is incompatible with luma depth (and/or chroma depth): use one or the other");
       if (a.isSet("progressive") && a.isSet("interlace"))
@@ -136,14 +138,11 @@ int main(int argc, char *argv[]) {
       if (hq && slicePrefix < 0) throw std::invalid_argument("slice prefix must be >=0");
       if (mode != HQ_ConstQ && compressedBytes < 1) throw std::invalid_argument("number of compressed bytes must be >0");
       if (mode == HQ_ConstQ && (qIndex < 0 || qIndex > 119)) throw std::invalid_argument("quantisation index must be in the range 0 to 119");
-      if (a.isSet("interlace")) throw std::invalid_argument("interlaced coding is not supported by the MI355X tools yet (progressive only)");
       if (gpus < 1) throw std::invalid_argument("gpus must be >= 1");
     } catch (const std::exception &e) {
       cerr << "Command line error: " << e.what() << endl;
       return EXIT_FAILURE;
     }
-    if (mode == LD) throw std::logic_error("LD encoding is obsolete and not offered by the MI355X tools (LD streams are decoded)");
-    if (fragmentLength > 0) throw std::logic_error("picture fragments are not supported by the MI355X tools yet");
     if (lumaDepth != chromaDepth) throw std::logic_error("luma and chroma bit depths must be equal in the MI355X tools");
 
     // ---- streams ----
@@ -157,16 +156,21 @@ int main(int argc, char *argv[]) {
       clog << "mode= " << modeName(mode) << endl << "bytes per sample= " << bytes << endl;
       clog << "luma depth (bits) = " << lumaDepth << endl << "chroma depth (bits) = " << chromaDepth << endl;
       clog << "height = " << height << endl << "width = " << width << endl << "chroma format = " << chromaFormat << endl;
-      clog << "interlaced = false" << endl << "wavelet kernel = " << kernel << endl << "wavelet depth = " << waveletDepth << endl;
+      clog << "interlaced = " << std::boolalpha << interlaced << endl;
+      if (interlaced) clog << "top field first = " << std::boolalpha << topFieldFirst << endl;
+      clog << "wavelet kernel = " << kernel << endl << "wavelet depth = " << waveletDepth << endl;
       clog << "vertical slice size (in units of 2**(wavelet depth)) = " << ySize << endl;
       clog << "horizontal slice size (in units of 2**(wavelet depth)) = " << xSize << endl;
       clog << "compressed bytes = " << compressedBytes << endl << "output = " << outputName(output) << endl;
     }
-    const int ySlices = sliceSizeIsValid(waveletDepth, format.lumaHeight(), format.chromaHeight(), ySize);
-    const int xSlices = sliceSizeIsValid(waveletDepth, format.lumaWidth(), format.chromaWidth(), xSize);
+    // a picture is a frame or one field of it (EncodeStream.cpp:367-377)
+    const int framePics = interlaced ? 2 : 1;
+    const PictureFormat picFormat = interlaced ? fieldFormat(format) : format;
+    const int ySlices = sliceSizeIsValid(waveletDepth, picFormat.lumaHeight(), picFormat.chromaHeight(), ySize);
+    const int xSlices = sliceSizeIsValid(waveletDepth, picFormat.lumaWidth(), picFormat.chromaWidth(), xSize);
     if (ySlices == 0 || xSlices == 0)
       throw std::logic_error("The given waveletDepth, hSlice, and vSlice parameters cannot encode this input. See above for suggested parameters.");
-    const int pictureBytes = compressedBytes;
+    const int pictureBytes = interlaced ? compressedBytes / 2 : compressedBytes;
     if (verbose) {
       clog << "Vertical slices per picture          = " << ySlices << endl;
       clog << "Horizontal slices per picture        = " << xSlices << endl;
@@ -183,23 +187,28 @@ int main(int argc, char *argv[]) {
       clog << endl;
     }
 
-    vc2hip_picture_format pf = {width, height, (int)chromaFormat, lumaDepth, bytes};
-    vc2hip_coding_params cp = {(int)kernel, waveletDepth, ySlices, xSlices, mode == HQ_CBR ? VC2HIP_HQ_CBR : VC2HIP_HQ_CONSTQ,
+    vc2hip_picture_format pf = {width, picFormat.lumaHeight(), (int)chromaFormat, lumaDepth, bytes};
+    vc2hip_coding_params cp = {(int)kernel, waveletDepth, ySlices, xSlices,
+                               mode == HQ_CBR ? VC2HIP_HQ_CBR : (mode == LD ? VC2HIP_LD : VC2HIP_HQ_CONSTQ),
                                qIndex, pictureBytes, slicePrefix, sliceScalar};
     const std::size_t frameBytes = (std::size_t)format.samples() * bytes;
+    const std::size_t picBytes = (std::size_t)picFormat.samples() * bytes;
+    const bool fragmented = (mode == HQ_CBR || mode == LD) && fragmentLength > 0; // EncodeStream.cpp:444-445
 
     std::vector<unsigned char> du; // output staging of the ordered writer
     unsigned long prev_parse_offset = 0;
     int major_version = 2;
     if (output == STREAM) {
       if (verbose) clog << endl << "Writing Sequence Header" << endl << endl;
-      const SequenceHeader sh(PROFILE_HQ, height, width, chromaFormat, false, (FrameRate)frameRate, true, lumaDepth);
-      const std::vector<unsigned char> body = writeSequenceHeader(sh, false, &major_version);
+      const SequenceHeader sh(mode == LD ? PROFILE_LD : PROFILE_HQ, height, width, chromaFormat, interlaced, (FrameRate)frameRate,
+                              topFieldFirst, lumaDepth);
+      const std::vector<unsigned char> body = writeSequenceHeader(sh, fragmented, &major_version);
       writeParseInfo(du, SEQUENCE_HEADER, body.size() + 13, prev_parse_offset);
       prev_parse_offset = body.size() + 13;
       du.insert(du.end(), body.begin(), body.end());
       out->write((const char *)du.data(), (std::streamsize)du.size());
     }
+    const Array2D ldSliceBytes = mode == LD ? slice_bytes(ySlices, xSlices, pictureBytes, 1) : Array2D();
 
     unsigned long long frame = 0;
     bool done = false;
@@ -221,34 +230,61 @@ int main(int argc, char *argv[]) {
       if (got == 0) break;
 
       if (output == STREAM) {
-        // fused picture path: frame k of this group on GPU k (EncodeStream.cpp:482-647 on the device)
-        std::vector<Encoded> enc((std::size_t)got);
+        // fused picture path: frame k of this group on GPU k (EncodeStream.cpp:482-647 on the device);
+        // an interlaced frame is two pictures, first field first (Frame.cpp:90-104)
+        std::vector<Encoded> enc((std::size_t)(got * framePics));
         std::vector<std::thread> th;
         for (int g = 0; g < got; ++g)
           th.emplace_back([&, g]() {
-            try {
-              vc2hip_ctx *c = hipContext(g);
-              enc[g].payload.resize(vc2hip_max_payload_bytes(&pf, &cp) + 64);
-              enc[g].qidx = Array2D(ySlices, xSlices);
-              std::size_t len = 0;
-              hipCheck(c, vc2hip_encode_picture_hq(c, raws[g].data(), &pf, &cp, enc[g].payload.data(), enc[g].payload.size(),
-                                                   &len, enc[g].qidx.data()));
-              enc[g].payload.resize(len);
-            } catch (const std::exception &e) { enc[g].error = e.what(); }
+            std::vector<unsigned char> field;
+            for (int pic = 0; pic < framePics; ++pic) {
+              Encoded &e = enc[(std::size_t)(g * framePics + pic)];
+              try {
+                vc2hip_ctx *c = hipContext(g);
+                const unsigned char *src = raws[g].data();
+                if (interlaced) {
+                  field.resize(picBytes);
+                  extractFieldRaw(raws[g].data(), format, bytes, (pic == 0) == topFieldFirst, field.data());
+                  src = field.data();
+                }
+                e.payload.resize(vc2hip_max_payload_bytes(&pf, &cp) + 64);
+                e.qidx = Array2D(ySlices, xSlices);
+                std::size_t len = 0;
+                hipCheck(c, (mode == LD ? vc2hip_encode_picture_ld : vc2hip_encode_picture_hq)(
+                                c, src, &pf, &cp, e.payload.data(), e.payload.size(), &len, e.qidx.data()));
+                e.payload.resize(len);
+              } catch (const std::exception &ex) { e.error = ex.what(); }
+            }
           });
         for (auto &t : th) t.join();
-        for (int g = 0; g < got; ++g) { // ordered writer: parse offsets and picture numbers chain in frame order
-          if (!enc[g].error.empty()) throw std::logic_error(enc[g].error);
+        for (int k = 0; k < got * framePics; ++k) { // ordered writer: parse offsets and picture numbers chain in order
+          const Encoded &e = enc[(std::size_t)k];
+          if (!e.error.empty()) throw std::logic_error(e.error);
           if (verbose) clog << "Forward transform" << endl << "Quantise transform coefficients" << endl << "Writing compressed output to file" << endl;
-          const unsigned long picnum = utils::getPictureNumber(0, frame + g, 1);
-          const std::vector<unsigned char> hdr = writePictureHeaderHQ(picnum, kernel, waveletDepth, xSlices, ySlices, slicePrefix, sliceScalar, major_version);
+          const unsigned long picnum = utils::getPictureNumber(k % framePics, frame + (unsigned long long)(k / framePics), framePics);
+          const utils::Rational ldRatio = utils::rationalise(pictureBytes, ySlices * xSlices);
           du.clear();
-          const unsigned long next = (unsigned long)(hdr.size() + enc[g].payload.size() + 13);
-          writeParseInfo(du, HQ_PICTURE, next, prev_parse_offset);
-          prev_parse_offset = next;
-          du.insert(du.end(), hdr.begin(), hdr.end());
-          out->write((const char *)du.data(), (std::streamsize)du.size());
-          out->write((const char *)enc[g].payload.data(), (std::streamsize)enc[g].payload.size());
+          if (fragmented) {
+            // DataUnit.cpp:156-232 / :267-342: parameters fragment + fragments of whole slices
+            const std::vector<unsigned char> params =
+                mode == LD ? writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)ldRatio.numerator, (unsigned)ldRatio.denominator)
+                           : writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)slicePrefix, (unsigned)sliceScalar);
+            std::vector<std::size_t> sizes;
+            if (mode == LD) for (std::size_t i = 0; i < ldSliceBytes.num_elements(); ++i) sizes.push_back((std::size_t)ldSliceBytes.data()[i]);
+            else sizes = sliceSizesHQ(e.payload.data(), e.payload.size(), ySlices * xSlices, slicePrefix, sliceScalar);
+            writeFragmentedPicture(du, mode == LD, picnum, params, e.payload.data(), sizes, xSlices, fragmentLength, &prev_parse_offset);
+            out->write((const char *)du.data(), (std::streamsize)du.size());
+          } else {
+            const std::vector<unsigned char> hdr =
+                mode == LD ? writePictureHeaderLD(picnum, kernel, waveletDepth, xSlices, ySlices, ldRatio, major_version)
+                           : writePictureHeaderHQ(picnum, kernel, waveletDepth, xSlices, ySlices, slicePrefix, sliceScalar, major_version);
+            const unsigned long next = (unsigned long)(hdr.size() + e.payload.size() + 13);
+            writeParseInfo(du, mode == LD ? LD_PICTURE : HQ_PICTURE, next, prev_parse_offset);
+            prev_parse_offset = next;
+            du.insert(du.end(), hdr.begin(), hdr.end());
+            out->write((const char *)du.data(), (std::streamsize)du.size());
+            out->write((const char *)e.payload.data(), (std::streamsize)e.payload.size());
+          }
           if (!*out) { cerr << "Failed to write output file \"" << outFileName << "\"" << endl; return EXIT_FAILURE; }
         }
         frame += got;
@@ -257,45 +293,65 @@ int main(int argc, char *argv[]) {
 
       // diagnostic outputs: the fine-grained Library functions, one frame at a time
       for (int g = 0; g < got; ++g, ++frame) {
-        Picture picture(format);
+        Picture inFrame(format);
         { Array2D y(format.lumaShape()), u(format.chromaShape()), v(format.chromaShape());
           const unsigned char *p = raws[g].data();
           unpackSamples(p, bytes, lumaDepth, true, true, y); p += y.num_elements() * bytes;
           unpackSamples(p, bytes, chromaDepth, true, true, u); p += u.num_elements() * bytes;
           unpackSamples(p, bytes, chromaDepth, true, true, v);
-          picture.y(y); picture.c1(u); picture.c2(v); }
-        if (verbose) clog << "Forward transform" << endl;
-        const Picture transform = waveletTransform(picture, kernel, waveletDepth);
-        if (output == TRANSFORM) { clog << "Writing transform coefficients to output file" << endl; writePicture4(*out, transform); continue; }
-        Array2D qIndices(ySlices, xSlices), sliceBytes;
-        if (mode == HQ_CBR) {
-          if (verbose) clog << "Determine quantisation indices" << endl;
-          sliceBytes = slice_bytes(ySlices, xSlices, pictureBytes, sliceScalar);
-          qIndices = quantIndicesCBR(transform, qMatrix, sliceBytes, sliceScalar);
-        } else for (std::size_t i = 0; i < qIndices.num_elements(); ++i) qIndices.data()[i] = qIndex;
+          inFrame.y(y); inFrame.c1(u); inFrame.c2(v); }
+        Picture outFrame(format);
         int stats[128] = {0};
-        for (std::size_t i = 0; i < qIndices.num_elements(); ++i) ++stats[qIndices.data()[i] & 127];
-        if (output == INDICES) {
-          clog << "Writing quantisation indices to output file" << endl;
-          for (std::size_t i = 0; i < qIndices.num_elements(); ++i) out->put((char)qIndices.data()[i]);
-          continue;
+        bool finished = true; // false when the output mode stops before the decoded picture
+        for (int pic = 0; pic < framePics; ++pic) {
+          const bool top = (pic == 0) == topFieldFirst;
+          const Picture picture = interlaced ? fieldOf(inFrame, top) : inFrame;
+          if (verbose) clog << "Forward transform" << endl;
+          const Picture transform = waveletTransform(picture, kernel, waveletDepth);
+          if (output == TRANSFORM) { clog << "Writing transform coefficients to output file" << endl; writePicture4(*out, transform); finished = false; continue; }
+          Array2D qIndices(ySlices, xSlices), sliceBytes;
+          if (mode == HQ_CBR) {
+            if (verbose) clog << "Determine quantisation indices" << endl;
+            sliceBytes = slice_bytes(ySlices, xSlices, pictureBytes, sliceScalar);
+            qIndices = quantIndicesCBR(transform, qMatrix, sliceBytes, sliceScalar);
+          } else if (mode == LD) {
+            if (verbose) clog << "Determine quantisation indices" << endl;
+            sliceBytes = ldSliceBytes;
+            qIndices = quantIndicesLD(transform, qMatrix, sliceBytes);
+          } else for (std::size_t i = 0; i < qIndices.num_elements(); ++i) qIndices.data()[i] = qIndex;
+          for (std::size_t i = 0; i < qIndices.num_elements(); ++i) ++stats[qIndices.data()[i] & 127];
+          if (output == INDICES) {
+            clog << "Writing quantisation indices to output file" << endl;
+            for (std::size_t i = 0; i < qIndices.num_elements(); ++i) out->put((char)qIndices.data()[i]);
+            finished = false;
+            continue;
+          }
+          if (verbose) clog << "Quantise transform coefficients" << endl;
+          // LL (DC) subband prediction in LD mode only (EncodeStream.cpp:541-548)
+          const Picture quantised = mode == LD ? quantise_transform(transform, qIndices, qMatrix) : quantise_transform_np(transform, qIndices, qMatrix);
+          if (output == QUANTISED) { clog << "Writing quantised transform coefficients to output file" << endl; writePicture4(*out, quantised); finished = false; continue; }
+          if (output == PACKAGED) {
+            if (verbose) clog << "Split quantised coefficients into slices" << endl << "Writing compressed output to file" << endl;
+            const std::vector<unsigned char> b = mode == LD ? packSlicesLD(quantised, waveletDepth, qIndices, sliceBytes)
+                                                            : packSlicesHQ(quantised, waveletDepth, qIndices, slicePrefix, sliceScalar, mode == HQ_CBR ? &sliceBytes : nullptr);
+            out->write((const char *)b.data(), (std::streamsize)b.size());
+            finished = false;
+            continue;
+          }
+          // the reference dequantises without DC prediction here even in LD mode (EncodeStream.cpp:651)
+          if (verbose) clog << "Inverse quantise" << endl;
+          const Picture restored = inverse_quantise_transform_np(quantised, qIndices, qMatrix);
+          if (verbose) clog << "Inverse transform" << endl;
+          Picture decoded = inverseWaveletTransform(restored, kernel, waveletDepth, picture.format());
+          if (verbose) clog << "Clip decoded picture" << endl;
+          decoded = clip(decoded, -utils::pow(2, lumaDepth - 1), utils::pow(2, lumaDepth - 1) - 1, -utils::pow(2, chromaDepth - 1), utils::pow(2, chromaDepth - 1) - 1);
+          if (interlaced) setField(outFrame, decoded, top);
+          else outFrame = decoded;
         }
-        if (verbose) clog << "Quantise transform coefficients" << endl;
-        const Picture quantised = quantise_transform_np(transform, qIndices, qMatrix);
-        if (output == QUANTISED) { clog << "Writing quantised transform coefficients to output file" << endl; writePicture4(*out, quantised); continue; }
-        if (output == PACKAGED) {
-          const std::vector<unsigned char> b = packSlicesHQ(quantised, waveletDepth, qIndices, slicePrefix, sliceScalar, mode == HQ_CBR ? &sliceBytes : nullptr);
-          out->write((const char *)b.data(), (std::streamsize)b.size());
-          continue;
-        }
-        if (verbose) clog << "Inverse quantise" << endl;
-        const Picture restored = inverse_quantise_transform_np(quantised, qIndices, qMatrix);
-        if (verbose) clog << "Inverse transform" << endl;
-        Picture decoded = inverseWaveletTransform(restored, kernel, waveletDepth, format);
-        decoded = clip(decoded, -utils::pow(2, lumaDepth - 1), utils::pow(2, lumaDepth - 1) - 1, -utils::pow(2, chromaDepth - 1), utils::pow(2, chromaDepth - 1) - 1);
-        // quantiser statistics + PSNR, EncodeStream.cpp:676-753
+        if (!finished) continue;
+        // quantiser statistics + PSNR over the frame, EncodeStream.cpp:676-753
         float mean = 0, meanSquare = 0;
-        const int totalSlices = ySlices * xSlices;
+        const int totalSlices = framePics * ySlices * xSlices;
         for (int z = 0; z < 128; ++z) { mean += z * stats[z]; meanSquare += z * z * stats[z]; }
         mean /= totalSlices; meanSquare /= totalSlices;
         const float stdDev = std::sqrt(meanSquare - mean * mean);
@@ -305,17 +361,18 @@ int main(int argc, char *argv[]) {
           const float rms = std::sqrt(float(ss) / float(a.num_elements())) / utils::pow(2, depth);
           return -20 * std::log10(rms);
         };
-        const float yp = psnr(picture.y(), decoded.y(), lumaDepth), up = psnr(picture.c1(), decoded.c1(), chromaDepth), vp = psnr(picture.c2(), decoded.c2(), chromaDepth);
+        const float yp = psnr(inFrame.y(), outFrame.y(), lumaDepth), up = psnr(inFrame.c1(), outFrame.c1(), chromaDepth), vp = psnr(inFrame.c2(), outFrame.c2(), chromaDepth);
         if (verbose) {
-          clog << std::fixed << std::setprecision(2) << "Mean, Standard Deviation of quantiser index = " << mean << ", " << stdDev << endl;
+          clog << endl << std::fixed << std::setprecision(2) << "Mean, Standard Deviation of quantiser index = " << mean << ", " << stdDev << endl;
           clog << std::fixed << std::setprecision(4) << "PSNR for Y/R, U/G, V/B = " << yp << ", " << up << ", " << vp << endl;
         }
         if (output == DECODED) { // wordWidth(bytes) + offset_binary, right justified (EncodeStream.cpp:756-760)
+          if (verbose) clog << "Writing decoded output frame " << frame << endl;
           std::vector<unsigned char> b(frameBytes);
           unsigned char *p = b.data();
-          packSamples(decoded.y(), bytes, lumaDepth, false, true, p); p += decoded.y().num_elements() * bytes;
-          packSamples(decoded.c1(), bytes, chromaDepth, false, true, p); p += decoded.c1().num_elements() * bytes;
-          packSamples(decoded.c2(), bytes, chromaDepth, false, true, p);
+          packSamples(outFrame.y(), bytes, lumaDepth, false, true, p); p += outFrame.y().num_elements() * bytes;
+          packSamples(outFrame.c1(), bytes, chromaDepth, false, true, p); p += outFrame.c1().num_elements() * bytes;
+          packSamples(outFrame.c2(), bytes, chromaDepth, false, true, p);
           out->write((const char *)b.data(), (std::streamsize)b.size());
         } else { // PSNR
           *out << "Frame " << frame << endl << std::fixed << std::setprecision(2) << mean << " " << stdDev << endl;

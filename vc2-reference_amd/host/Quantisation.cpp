@@ -23,6 +23,8 @@ Picture pictureOp(PlaneOp op, const Picture &in, const Array2D &q, const Array1D
 const Array2D quantise_transform_np(const Array2D &c, const Array2D &q, const Array1D &m) { return planeOp(vc2hip_quantise_np, c, q, m); }
 const Array2D inverse_quantise_transform_np(const Array2D &c, const Array2D &q, const Array1D &m) { return planeOp(vc2hip_dequantise_np, c, q, m); }
 const Array2D inverse_quantise_transform(const Array2D &c, const Array2D &q, const Array1D &m) { return planeOp(vc2hip_dequantise_ld, c, q, m); }
+const Array2D quantise_transform(const Array2D &c, const Array2D &q, const Array1D &m) { return planeOp(vc2hip_quantise_ld, c, q, m); }
+const Picture quantise_transform(const Picture &t, const Array2D &q, const Array1D &m) { return pictureOp(vc2hip_quantise_ld, t, q, m); }
 const Picture quantise_transform_np(const Picture &t, const Array2D &q, const Array1D &m) { return pictureOp(vc2hip_quantise_np, t, q, m); }
 const Picture inverse_quantise_transform_np(const Picture &t, const Array2D &q, const Array1D &m) { return pictureOp(vc2hip_dequantise_np, t, q, m); }
 const Picture inverse_quantise_transform(const Picture &t, const Array2D &q, const Array1D &m) { return pictureOp(vc2hip_dequantise_ld, t, q, m); }

@@ -23,6 +23,27 @@ const Array2D quantIndicesCBR(const Picture &t, const Array1D &qMatrix, const Ar
   return q;
 }
 
+const Array2D quantIndicesLD(const Picture &t, const Array1D &qMatrix, const Array2D &sliceBytes) {
+  Array2D q(sliceBytes.shape());
+  const vc2hip_geom g = geomOf(t, (int)(qMatrix.size() - 1) / 3, sliceBytes);
+  vc2hip_ctx *c = hipContext();
+  hipCheck(c, vc2hip_ld_qindices(c, t.y().data(), t.c1().data(), t.c2().data(), &g, qMatrix.data(), sliceBytes.data(), q.data()));
+  return q;
+}
+
+std::vector<unsigned char> packSlicesLD(const Picture &qp, int depth, const Array2D &qIndices, const Array2D &sliceBytes) {
+  const vc2hip_geom g = geomOf(qp, depth, qIndices);
+  std::size_t cap = 0;
+  for (std::size_t i = 0; i < sliceBytes.num_elements(); ++i) cap += (std::size_t)sliceBytes.data()[i];
+  std::vector<unsigned char> out(cap + 64);
+  std::size_t len = 0;
+  vc2hip_ctx *c = hipContext();
+  hipCheck(c, vc2hip_ld_pack(c, qp.y().data(), qp.c1().data(), qp.c2().data(), &g, qIndices.data(), sliceBytes.data(),
+                             out.data(), out.size(), &len));
+  out.resize(len);
+  return out;
+}
+
 std::vector<unsigned char> packSlicesHQ(const Picture &qp, int depth, const Array2D &qIndices, int prefix, int scalar,
                                         const Array2D *sliceBytes) {
   const vc2hip_geom g = geomOf(qp, depth, qIndices);

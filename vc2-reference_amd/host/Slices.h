@@ -13,6 +13,11 @@ const Array2D slice_bytes(int ySlices, int xSlices, int totalBytes, int scalar);
 // quantIndicesCBR(coefficients, qMatrix, sliceBytes, scalar), EncodeStream.cpp:73-125
 const Array2D quantIndicesCBR(const Picture &coefficients, const Array1D &qMatrix, const Array2D &sliceBytes, int scalar);
 
+// quantIndicesLD(coefficients, qMatrix, sliceBytes), EncodeStream.cpp:141-245
+const Array2D quantIndicesLD(const Picture &coefficients, const Array1D &qMatrix, const Array2D &sliceBytes);
+// operator<<(ostream, Slices) under lowDelay(sliceBytes), Slices.cpp:645-660 over :195-244
+std::vector<unsigned char> packSlicesLD(const Picture &quantised, int waveletDepth, const Array2D &qIndices,
+                                        const Array2D &sliceBytes);
 // operator<<(ostream, Slices) under highQualityVBR / highQualityCBR: bytes of all slices of a picture.
 // sliceBytes == nullptr selects VBR.
 std::vector<unsigned char> packSlicesHQ(const Picture &quantised, int waveletDepth, const Array2D &qIndices,

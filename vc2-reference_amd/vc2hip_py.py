@@ -46,7 +46,8 @@ EXPORTS = [
     "vc2hip_error_string", "vc2hip_sync", "vc2hip_padded_size", "vc2hip_slice_size_is_valid",
     "vc2hip_quant_matrix", "vc2hip_slice_bytes", "vc2hip_dwt_forward", "vc2hip_dwt_inverse",
     "vc2hip_quantise_np", "vc2hip_dequantise_np", "vc2hip_dequantise_ld", "vc2hip_hq_pack",
-    "vc2hip_hq_unpack", "vc2hip_ld_unpack", "vc2hip_cbr_qindices", "vc2hip_raw_picture_bytes",
+    "vc2hip_hq_unpack", "vc2hip_ld_unpack", "vc2hip_cbr_qindices", "vc2hip_quantise_ld", "vc2hip_ld_pack",
+    "vc2hip_ld_qindices", "vc2hip_encode_picture_ld", "vc2hip_raw_picture_bytes",
     "vc2hip_max_payload_bytes", "vc2hip_encode_picture_hq", "vc2hip_decode_picture_hq",
     "vc2hip_decode_picture_ld", "vc2hip_encode_batch_dev", "vc2hip_decode_batch_dev",
     "vc2hip_profile_enable", "vc2hip_profile_count", "vc2hip_profile_get", "vc2hip_profile_reset",
@@ -79,7 +80,7 @@ def load_library():
     lib.vc2hip_slice_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p]
     lib.vc2hip_dwt_forward.argtypes = [vp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
     lib.vc2hip_dwt_inverse.argtypes = [vp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int]
-    for f in (lib.vc2hip_quantise_np, lib.vc2hip_dequantise_np, lib.vc2hip_dequantise_ld):
+    for f in (lib.vc2hip_quantise_np, lib.vc2hip_dequantise_np, lib.vc2hip_dequantise_ld, lib.vc2hip_quantise_ld):
         f.argtypes = [vp, i32p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, i32p, i32p]
     lib.vc2hip_hq_pack.argtypes = [vp, i32p, i32p, i32p, C.POINTER(Geom), i32p, C.c_int, C.c_int,
                                    vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -88,12 +89,16 @@ def load_library():
     lib.vc2hip_ld_unpack.argtypes = [vp, u8p, C.c_size_t, C.POINTER(Geom), i32p, i32p, i32p, i32p,
                                      i32p, C.POINTER(C.c_size_t)]
     lib.vc2hip_cbr_qindices.argtypes = [vp, i32p, i32p, i32p, C.POINTER(Geom), i32p, i32p, C.c_int, i32p]
+    lib.vc2hip_ld_qindices.argtypes = [vp, i32p, i32p, i32p, C.POINTER(Geom), i32p, i32p, i32p]
+    lib.vc2hip_ld_pack.argtypes = [vp, i32p, i32p, i32p, C.POINTER(Geom), i32p, i32p, u8p, C.c_size_t,
+                                   C.POINTER(C.c_size_t)]
     lib.vc2hip_raw_picture_bytes.argtypes = [C.POINTER(PictureFormat)]
     lib.vc2hip_raw_picture_bytes.restype = C.c_size_t
     lib.vc2hip_max_payload_bytes.argtypes = [C.POINTER(PictureFormat), C.POINTER(CodingParams)]
     lib.vc2hip_max_payload_bytes.restype = C.c_size_t
-    lib.vc2hip_encode_picture_hq.argtypes = [vp, u8p, C.POINTER(PictureFormat), C.POINTER(CodingParams),
-                                             u8p, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    for f in (lib.vc2hip_encode_picture_hq, lib.vc2hip_encode_picture_ld):
+        f.argtypes = [vp, u8p, C.POINTER(PictureFormat), C.POINTER(CodingParams), u8p, C.c_size_t,
+                      C.POINTER(C.c_size_t), vp]
     for f in (lib.vc2hip_decode_picture_hq, lib.vc2hip_decode_picture_ld):
         f.argtypes = [vp, u8p, C.c_size_t, C.POINTER(PictureFormat), C.POINTER(CodingParams), u8p]
     lib.vc2hip_encode_batch_dev.argtypes = [vp, vp, C.c_int, C.POINTER(PictureFormat),
@@ -202,6 +207,9 @@ class Vc2Hip:
     def dequantise_ld(self, plane, depth, qidx, qm):
         return self._q(self.lib.vc2hip_dequantise_ld, plane, depth, qidx, qm)
 
+    def quantise_ld(self, plane, depth, qidx, qm):
+        return self._q(self.lib.vc2hip_quantise_ld, plane, depth, qidx, qm)
+
     @staticmethod
     def geom(y, u, depth, ys, xs):
         return Geom(y.shape[0], y.shape[1], u.shape[0], u.shape[1], depth, ys, xs)
@@ -257,6 +265,26 @@ class Vc2Hip:
                                                np.ascontiguousarray(slice_bytes, np.int32), scalar, q))
         return q
 
+    def ld_qindices(self, y, u, v, depth, qm, slice_bytes):
+        y, u, v = (np.ascontiguousarray(a, np.int32) for a in (y, u, v))
+        ys, xs = slice_bytes.shape
+        g = self.geom(y, u, depth, ys, xs)
+        q = np.zeros((ys, xs), np.int32)
+        self._chk(self.lib.vc2hip_ld_qindices(self.h, y, u, v, C.byref(g), np.ascontiguousarray(qm, np.int32),
+                                              np.ascontiguousarray(slice_bytes, np.int32), q))
+        return q
+
+    def ld_pack(self, y, u, v, depth, qidx, slice_bytes):
+        y, u, v = (np.ascontiguousarray(a, np.int32) for a in (y, u, v))
+        qidx = np.ascontiguousarray(qidx, np.int32)
+        g = self.geom(y, u, depth, qidx.shape[0], qidx.shape[1])
+        cap = int(slice_bytes.sum()) + 64
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        self._chk(self.lib.vc2hip_ld_pack(self.h, y, u, v, C.byref(g), qidx,
+                                          np.ascontiguousarray(slice_bytes, np.int32), out, cap, C.byref(n)))
+        return out[:n.value].copy()
+
     # ---- fused pictures (host buffers)
     def raw_picture_bytes(self, fmt):
         return self.lib.vc2hip_raw_picture_bytes(C.byref(fmt))
@@ -270,8 +298,8 @@ class Vc2Hip:
         out = np.empty(cap, np.uint8)
         n = C.c_size_t()
         qidx = np.zeros((cp.y_slices, cp.x_slices), np.int32)
-        self._chk(self.lib.vc2hip_encode_picture_hq(self.h, raw, C.byref(fmt), C.byref(cp), out, cap,
-                                                    C.byref(n), qidx.ctypes.data_as(C.c_void_p)))
+        fn = self.lib.vc2hip_encode_picture_ld if cp.mode == MODES["LD"] else self.lib.vc2hip_encode_picture_hq
+        self._chk(fn(self.h, raw, C.byref(fmt), C.byref(cp), out, cap, C.byref(n), qidx.ctypes.data_as(C.c_void_p)))
         return out[:n.value].tobytes(), qidx
 
     def decode_picture(self, payload, fmt, cp):
