@@ -24,10 +24,10 @@ import ctypes; ctypes.CDLL(None).setenv(b"VC2HIP_DEBUG_INDEX", dbg.encode(), 1)
 for it in range(2):
     hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out.data_ptr())
 try: hip.sync()
-except Exception as e: pass
+except Exception: pass
 hip.profile_reset(); hip.profile_enable(True)
 for it in range(5):
     hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out.data_ptr())
 try: hip.sync()
-except Exception as e: pass
+except Exception: pass
 print(dbg, {k: round(v[1] / 5, 4) for k, v in hip.profile().items() if k.startswith("slice_index")})

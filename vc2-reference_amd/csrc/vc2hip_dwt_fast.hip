@@ -51,6 +51,7 @@ template <int K> struct Cfg {
   static constexpr int NWV = 4 + 2 * PADV;
   static constexpr int PLANE = WYP * WXP;    // ints per parity plane
   static constexpr size_t LDS = (size_t)4 * PLANE * 4;
+  static constexpr size_t LDS_INV = LDS + 2 * 120 * 4; // + the dequantiser table (factor, offset per index)
 };
 
 // one lifting step on a register window; E / O are the even / odd parity values of NW pairs
@@ -387,6 +388,12 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   const int32_t *store = p.store + (size_t)pic * p.store_stride;
   const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * p.xs : nullptr;
 
+  // quant_factor / quant_offset by adjusted index, copied next to the planes: the look-up that follows the
+  // slice's index load is then an LDS read instead of a second dependent trip to memory
+  int *qtab = lds + 4 * C::PLANE;
+  if (threadIdx.x < 120) { qtab[threadIdx.x] = c_qd.qf[threadIdx.x]; qtab[120 + threadIdx.x] = c_qd.off[threadIdx.x]; }
+  __syncthreads();
+
   // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in.
   // Every 16-byte load of the thread (and the slice's quantiser index beside it) is issued before
   // the first one is consumed.
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         kind[band][it] = 0;
         qv[band][it] = 0;
         val[band][it] = make_int4(0, 0, 0, 0);
-        if (id >= WYP * (WXP / 4)) continue;
+        if (id >= WYP * (WXP / 4) || (p.debug_skip & 1)) continue;
         const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
         const int by = ky_base + i, bx0 = kx_base + 4 * jq;
         if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
@@ -435,10 +442,10 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         const int by = ky_base + i, bx0 = kx_base + 4 * jq;
         int e[4] = {val[band][it].x, val[band][it].y, val[band][it].z, val[band][it].w};
         if (kind[band][it] == 1) {
-          if (!from_plane && p.dequant) {
+          if (!from_plane && p.dequant && !(p.debug_skip & 8)) {
             const int aq = max(qv[band][it] - qm, 0);
             if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
-            const int qf = c_qd.qf[min(aq, 119)], qo = c_qd.off[min(aq, 119)];
+            const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)];
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
           }
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
             if (p.dequant) {
               const int aq = max(qidx[sv * p.xs + sh] - qm, 0);
               if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
-              t = dequant_f(t, c_qd.qf[min(aq, 119)], c_qd.off[min(aq, 119)]);
+              t = dequant_f(t, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
             }
             e[k] = t;
           }
@@ -471,13 +478,16 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   {
     constexpr int NQ = WXP / 4;
     constexpr int NITV = (NQ * 2 * (TY / 8) + NT - 1) / NT;
+    if (!(p.debug_skip & 2)) {
     v_pass<K, true, NITV>(lds, 0, NQ, ky_base, npy);
     // core rows of both parities: stack rows rp*WYP + HY/2 + [0, TY/2); h_pass takes one contiguous
     // range, so run it once per row parity
     constexpr int NITH = ((TY / 2) * 16 + NT - 1) / NT;
     h_pass<K, true, NITH>(lds, HY / 2, TY / 2, kx_base, npx);
     h_pass<K, true, NITH>(lds, WYP + HY / 2, TY / 2, kx_base, npx);
+    }
   }
+  if (p.debug_skip & 4) return;
 
   // ---- interleave, round, write (FINAL: clip + offset + justify + big-endian 16-bit words)
   const int lim_h = FINAL ? p.pic_h[comp] : out_h, lim_w = FINAL ? p.pic_w[comp] : out_w;
@@ -528,7 +538,7 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
   int gx = 0, gy = 0;
   for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.tiles_x[c]); gy = std::max(gy, p.tiles_y[c]); }
   dim3 grid(gx, gy, 3 * n_pictures), block(NT);
-  const size_t lds = Cfg<K>::LDS;
+  const size_t lds = INV ? Cfg<K>::LDS_INV : Cfg<K>::LDS;
   if constexpr (INV) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_inv_fast<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }

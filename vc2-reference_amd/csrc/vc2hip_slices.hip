@@ -922,7 +922,7 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipSt
 //   2. chain  : per picture, follow entry -> exit through the chunk tables  [one lane/picture]
 //   3. emit   : per chunk, walk again from the now-known entry and write the offsets
 // ------------------------------------------------------------------------------------------
-static constexpr int IDX_CH = 32768;
+static constexpr int IDX_CH = 16384;
 
 __device__ __forceinline__ int slice_len_lds(const uint8_t *b, int pos, int prefix, int scalar) {
   int q = pos + prefix + 1;
@@ -948,118 +948,55 @@ __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long
   }
 }
 
-// Per chunk: (exit offset, slices started) for every possible entry offset e in [0, E).
-//
-// The 32 KiB chunk is cut into SUB sub-chunks that are processed concurrently (an equal share of the
-// workgroup each), which shortens the serial part -- the walk of the few surviving chains -- by SUB;
-// the sub-chunk functions are composed at the end.  Inside a sub-chunk every entry offset gets a
-// walker.  Walkers hop independently; each byte position a walker lands on is claimed in an LDS hash
-// table (32-bit compare-and-swap: position | owner).  A walker that lands on a claimed byte merges
-// into the owner and stops, so every position's outgoing hop is taken exactly once: chains of
-// pseudo-random length bytes coalesce within a few hops.  Merged walkers keep (slot, own hop count)
-// and are resolved after a barrier from the owner's hop count stored beside the claim.
 static constexpr int IDX_THREADS = 1024;
-static constexpr int IDX_SLOTS = 8192;   // hash slots per chunk (split over the sub-chunks)
-static constexpr int IDX_MAX_E = 8191;   // owner ids are 13 bits
+static constexpr int IDX_MAX_E = 8191;   // entry offsets (a slice's maximum size) must stay below the chunk size
 
-static size_t idx_tables_lds(int E, int sub) {
-  return (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)IDX_SLOTS * 6 + (size_t)sub * E * 9 + 64;
-}
-
-template <int SUB>
-__global__ __launch_bounds__(IDX_THREADS) void k_index_tables(const uint8_t *payload, long long stride,
-                                                              const unsigned long long *lens, uint2 *tables,
-                                                              int n_chunks, int E, int prefix, int scalar, int dbg) {
-  constexpr int SUBCH = IDX_CH / SUB, T = IDX_SLOTS / SUB;
+// Chunk function by table walk.  One pass fills next[i] = the position reached if a slice started at byte i
+// of the chunk, from the three length bytes behind every byte position (throughput-bound LDS work: PER
+// independent reads per thread and step).  Then every entry offset walks next[] -- one LDS read per hop
+// instead of three dependent ones -- until it leaves the chunk.
+template <int CH>
+__global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *payload, long long stride,
+                                                                 const unsigned long long *lens, uint2 *tables,
+                                                                 int n_chunks, int E, int prefix, int scalar, int dbg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
-  const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
-  uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
+  const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * CH;
   if (c0 >= plen) return;
-  const int nbytes = (IDX_CH + E + 16 + 15) & ~15;
-  unsigned *claims = (unsigned *)(lds_b + nbytes);                          // [SUB][T] (pos+1) << 13 | owner
-  unsigned short *claim_hops = (unsigned short *)(claims + IDX_SLOTS);      // owner's hop count at the claim
-  unsigned short *w_a = claim_hops + IDX_SLOTS;                             // [SUB][E] exit | claim slot | start merged into
-  unsigned short *w_b = w_a + SUB * E;                                      // [SUB][E] own hop count
-  unsigned short *r_exit = w_b + SUB * E;                                   // [SUB][E] resolved exit
-  unsigned short *r_cnt = r_exit + SUB * E;                                 // [SUB][E] resolved slice count
-  unsigned char *w_kind = (unsigned char *)(r_cnt + SUB * E);               // 0 survivor, 1 merged at a claim, 2 merged into a start
-  int *ticket = (int *)(((size_t)(w_kind + SUB * E) + 3) & ~(size_t)3);
+  const int nbytes = (CH + E + 16 + 15) & ~15;
+  unsigned short *nx = (unsigned short *)(lds_b + nbytes); // >= CH: left the chunk at offset nx - CH
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
-  for (int i = threadIdx.x; i < IDX_SLOTS; i += blockDim.x) claims[i] = 0;
-  if (threadIdx.x == 0) *ticket = 0;
   __syncthreads();
   if (dbg == 1) return;
-  const int lim_all = (int)min((unsigned long long)IDX_CH, plen - c0); // never walk the zero fill behind the payload
+  const int lim = (int)min((unsigned long long)CH, plen - c0); // never walk the zero fill behind the payload
+  constexpr int PER = CH / IDX_THREADS;
   {
-    // Walkers are handed out dynamically (LDS ticket): most walkers merge after one or two hops, a few
-    // survive to the end of their sub-chunk, so a static assignment would leave most lanes idle while
-    // the longest chain of each wave finishes.  One loop iteration = one hop of the lane's walker.
-    int pos = 0, hops = 0, e = 0, sb = 0, s0 = 0, send = 0, lim = 0;
-    bool have = false, claim = true;
-    for (;;) {
-      if (!have) {
-        const int id = atomicAdd(ticket, 1);
-        if (id >= SUB * E) break;
-        sb = id % SUB; e = id / SUB;
-        s0 = sb * SUBCH; send = s0 + SUBCH; lim = min(send, lim_all);
-        pos = s0 + e; hops = 0; claim = true; have = true;
-      }
-      int kind = -1, link = 0;
-      if (pos >= lim) kind = 0; // starts behind the payload end
-      else {
-        pos += slice_len_lds(lds_b, pos, prefix, scalar);
-        ++hops;
-        if (pos >= lim) kind = 0;
-        else if (pos - s0 < E) { kind = 2; link = pos - s0; } // walker `pos - s0` starts here with 0 hops
-        else if (claim) {
-          unsigned *cl = claims + sb * T;
-          const unsigned mine = ((unsigned)(pos - s0 + 1) << 13) | (unsigned)e;
-          unsigned h = (((unsigned)pos * 2654435761u) >> 16) & (T - 1);
-          int probes = 0;
-          for (;;) {
-            const unsigned old = atomicCAS(&cl[h], 0u, mine);
-            if (old == 0) { claim_hops[sb * T + h] = (unsigned short)hops; break; }
-            if ((old >> 13) == (unsigned)(pos - s0 + 1)) { kind = 1; link = (int)h; break; }
-            h = (h + 1) & (T - 1);
-            if (++probes >= T) { claim = false; break; } // table full: keep walking unclaimed
-          }
-        }
-      }
-      if (kind >= 0) {
-        w_kind[sb * E + e] = (unsigned char)kind;
-        w_a[sb * E + e] = (unsigned short)(kind ? link : (pos >= send ? pos - send : 0));
-        w_b[sb * E + e] = (unsigned short)hops;
-        have = false;
-      }
+    int q[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) q[k] = threadIdx.x + k * IDX_THREADS + prefix + 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int len[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) len[k] = lds_b[min(q[k], nbytes - 1)];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) q[k] += 1 + len[k] * scalar;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int n = q[k];
+      // a slice that ends behind the payload end leaves the chunk at offset 0 unless it really reaches the next chunk
+      nx[threadIdx.x + k * IDX_THREADS] = (unsigned short)(n >= lim ? (n >= CH ? n : CH) : n);
     }
   }
   __syncthreads();
   if (dbg == 2) return;
-  // resolve the merge links inside each sub-chunk: (exit, slices) per entry offset
-  for (int i = threadIdx.x; i < SUB * E; i += blockDim.x) {
-    const int sb = i / E;
-    const unsigned *cl = claims + sb * T;
-    const unsigned short *chh = claim_hops + sb * T;
-    int cur = i - sb * E, d = 0;
-    for (;;) {
-      const int kind = w_kind[sb * E + cur];
-      if (kind == 0) break;
-      const int own = w_b[sb * E + cur], link = w_a[sb * E + cur];
-      if (kind == 2) { d += own; cur = link; }
-      else { d += own - (int)chh[link]; cur = (int)(cl[link] & 0x1FFFu); }
-    }
-    r_exit[i] = w_a[sb * E + cur];
-    r_cnt[i] = (unsigned short)((int)w_b[sb * E + cur] + d);
-  }
-  __syncthreads();
-  if (dbg == 3) return;
-  // compose the sub-chunk functions
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    int x = e, cnt = 0;
-#pragma unroll
-    for (int sb = 0; sb < SUB; ++sb) { const int i = sb * E + x; cnt += r_cnt[i]; x = r_exit[i]; }
-    tab[e] = make_uint2((unsigned)x, (unsigned)cnt);
+  uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
+  for (int e = threadIdx.x; e < E; e += IDX_THREADS) {
+    int pos = e, cnt = 0;
+    if (e >= lim) pos = CH; // starts behind the payload end: no slice
+    while (pos < CH) { pos = nx[pos]; ++cnt; }
+    if (dbg != 3) tab[e] = make_uint2((unsigned)(pos - CH), (unsigned)cnt);
   }
 }
 
@@ -1166,20 +1103,19 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   (void)workspace_bytes;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void *)k_index_tables<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_index_tables<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_index_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const char *dbg_env = getenv("VC2HIP_DEBUG_INDEX");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   vc2_prof_begin(L, "slice_index_tables", s);
-  if (idx_tables_lds(E, 4) <= 150 * 1024)
-    hipLaunchKernelGGL((k_index_tables<4>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), idx_tables_lds(E, 4), s,
-                       payload, payload_stride, lens, tables, n_chunks, E, prefix, scalar, dbg);
-  else
-    hipLaunchKernelGGL((k_index_tables<1>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), idx_tables_lds(E, 1), s,
-                       payload, payload_stride, lens, tables, n_chunks, E, prefix, scalar, dbg);
+  {
+    const size_t lds = (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)IDX_CH * 2;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) { (void)hipFuncSetAttribute((const void *)k_index_tables_nx<IDX_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    hipLaunchKernelGGL((k_index_tables_nx<IDX_CH>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
+                       lens, tables, n_chunks, E, prefix, scalar, dbg);
+  }
   vc2_prof_end(L, s);
   const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 512 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
