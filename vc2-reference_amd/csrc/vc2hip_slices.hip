@@ -900,7 +900,12 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     for (int j = 0; j < LPR; ++j) {
       const int r = j * (64 / LPR) + lane / LPR, c = (lane % LPR) * 4;
       int32_t *dst = (int32_t *)outp[wave][r];
-      if (dst && c < room) *(int4 *)(dst + base + c) = *(const int4 *)(sw + r * UNP_PITCH + c);
+      if (dst && c < room) {
+        const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
+        int *d = dst + base + c;
+        __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
+        __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+      }
     }
     __syncthreads();
   }
