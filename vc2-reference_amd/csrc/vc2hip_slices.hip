@@ -892,8 +892,12 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         st[cnt++] = r;
       }
     }
-    // flush: 4 lanes x 16 bytes per component run (trip counts are uniform across the workgroup)
-    __syncthreads();
+    // flush: 4 lanes x 16 bytes per component run.  The staging rows are private to the wavefront, so only
+    // its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup barrier,
+    // the four wavefronts of the workgroup drift apart freely.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int *sw = stage[wave];
     constexpr int LPR = UNP_N / 4; // lanes per component run
 #pragma unroll
@@ -907,7 +911,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
