@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <string>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "vc2hip_internal.h"
@@ -180,6 +183,19 @@ extern "C" int vc2hip_quant_matrix(int kernel, int depth, int32_t *out) {
   for (int lv = 1; lv <= depth; ++lv) { out[i++] = qv(gh[lv]); out[i++] = qv(gh[lv]); out[i++] = qv(gd[lv]); }
   return 0;
 }
+void vc2_allow_lds(const void *kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &have = done[std::make_pair(kernel, dev)];
+  if (bytes > have) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    have = bytes;
+  }
+}
+
 static int gcd_i(int a, int b) { a = abs(a); b = abs(b); while (b) { int t = a % b; a = b; b = t; } return a; }
 extern "C" int vc2hip_slice_bytes(int ys, int xs, int total_bytes, int scalar, int32_t *out) {
   if (ys < 1 || xs < 1 || scalar < 1) return VC2HIP_EINVAL;

@@ -332,13 +332,11 @@ static void launch_level(Launcher &L, const LevelParams &p, int n_pictures, hipS
   const size_t lds = lds_bytes_k<K>(p);
   dim3 grid(gx, gy, 3 * n_pictures), block(256);
   if constexpr (INV) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_inv_level<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vc2_allow_lds((const void *)k_inv_level<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
     hipLaunchKernelGGL((k_inv_level<K, EDGE>), grid, block, lds, s, p);
   } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_fwd_level<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vc2_allow_lds((const void *)k_fwd_level<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
     hipLaunchKernelGGL((k_fwd_level<K, EDGE>), grid, block, lds, s, p);
   }

@@ -540,13 +540,11 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
   dim3 grid(gx, gy, 3 * n_pictures), block(NT);
   const size_t lds = INV ? Cfg<K>::LDS_INV : Cfg<K>::LDS;
   if constexpr (INV) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_inv_fast<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vc2_allow_lds((const void *)k_inv_fast<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
     hipLaunchKernelGGL((k_inv_fast<K, EDGE>), grid, block, lds, s, p);
   } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_fwd_fast<K, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    vc2_allow_lds((const void *)k_fwd_fast<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
     hipLaunchKernelGGL((k_fwd_fast<K, EDGE>), grid, block, lds, s, p);
   }

@@ -163,6 +163,10 @@ struct CbrParams {
 // ------------------------------------------------------------------------------------------
 struct Launcher; // profiling hook, defined in vc2hip_api.hip
 
+// Raise a kernel's dynamic-LDS limit to `bytes`, once per (kernel, device): the attribute belongs to the
+// function on the CURRENT device, and one process may drive several GPUs (the tools' --gpus N).
+void vc2_allow_lds(const void *kernel, size_t bytes);
+
 void vc2_upload_tables(const QuantTables &t, hipStream_t s);
 int vc2_launch_forward_level(Launcher &L, int kernel, bool first, const LevelParams &p, int n_pictures,
                              hipStream_t s);

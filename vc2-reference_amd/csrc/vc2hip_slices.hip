@@ -528,8 +528,7 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
   { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
   const size_t lds = (size_t)4 * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * 32 * 16;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_hq_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr = true; }
+  vc2_allow_lds((const void *)k_hq_pack, 144 * 1024);
   vc2_prof_begin(L, "hq_pack", s);
   hipLaunchKernelGGL(k_hq_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), lds, s, p);
   vc2_prof_end(L, s);
@@ -669,8 +668,7 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
 }
 
 void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_cbr_search, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_allow_lds((const void *)k_cbr_search, 160 * 1024);
   vc2_prof_begin(L, "cbr_search", s);
   hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256),
                      (size_t)4 * p.slice_coefs * 4, s, p);
@@ -1112,18 +1110,13 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   uint2 *tables = (uint2 *)workspace;
   uint2 *entries = tables + (size_t)n_pictures * n_chunks * E;
   (void)workspace_bytes;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void *)k_index_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  vc2_allow_lds((const void *)k_index_emit, 160 * 1024);
   const char *dbg_env = getenv("VC2HIP_DEBUG_INDEX");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   vc2_prof_begin(L, "slice_index_tables", s);
   {
     const size_t lds = (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)IDX_CH * 2;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) { (void)hipFuncSetAttribute((const void *)k_index_tables_nx<IDX_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_lds = lds; }
+    vc2_allow_lds((const void *)k_index_tables_nx<IDX_CH>, lds);
     hipLaunchKernelGGL((k_index_tables_nx<IDX_CH>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
                        lens, tables, n_chunks, E, prefix, scalar, dbg);
   }
@@ -1360,8 +1353,7 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
 }
 
 void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_ld_quantise_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_allow_lds((const void *)k_ld_quantise_diag, 160 * 1024);
   vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
   for (int d = 0; d < p.ys + p.xs - 1; ++d) {
     const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
@@ -1370,8 +1362,7 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
   vc2_prof_end(L, s);
 }
 void vc2_launch_ld_pack(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_ld_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  vc2_allow_lds((const void *)k_ld_pack, 160 * 1024);
   vc2_prof_begin(L, "ld_pack", s);
   hipLaunchKernelGGL(k_ld_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), (size_t)4 * p.img_words * 4, s, p);
   vc2_prof_end(L, s);
