@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="pictures per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4, help="pictures in the CPU-baseline sample")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the library cuts each batch over (vc2hip_set_streams); 1 = one launch per kernel and "
+                         "batch, which is what the roofline figures describe")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,6 +96,8 @@ def main():
     W, H, CFMT, BITS = 3840, 2160, "422", 10
     KERNEL, DEPTH, U, A, Q, SCALAR = "DD97", 4, 1, 2, 16, 2
     hip = vc2hip_py.Vc2Hip(local_rank)
+    if args.streams > 1:
+        hip.set_streams(args.streams)
     fmt = vc2hip_py.picture_format(W, H, CFMT, BITS)
     cp = vc2hip_py.coding_params(hip.lib, fmt, KERNEL, DEPTH, U, A, q=Q, scalar=SCALAR)
     B = args.batch
@@ -174,14 +179,15 @@ def main():
         dom = max(kern, key=lambda k: kern[k][1])
         dom_launches, dom_ms = kern[dom]
         dom_avg_s = dom_ms / dom_launches / 1e3
-        achieved = alg_dir * B / dom_avg_s / 1e9
+        per_launch = B / max(1, min(args.streams, B))   # pictures one launch processes
+        achieved = alg_dir * per_launch / dom_avg_s / 1e9
         path_achieved = 2 * alg_dir * B * args.steps / (total_ms / 1e3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs, gfx950 correction applied; see profiles/r01_pmc_traffic.json)
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc.get("pictures_per_launch") == B and dom in pmc["kernels"]:
+            if pmc.get("pictures_per_launch") == per_launch and dom in pmc["kernels"]:
                 traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
@@ -199,12 +205,12 @@ def main():
             "dtype": "int32",
             "data": "synthetic (SURVEY Appendix-B generator, seed 1234; 2 distinct pictures tiled over the batch)",
             "config": {"workload": "BASELINE cfg2: UHD-1 3840x2160 4:2:2 10-bit HQ_ConstQ DD97 depth 4, -u 1 -a 2 -q 16 -S 2",
-                       "pictures_per_gpu_per_step": B, "coded_bytes_per_picture": coded,
+                       "pictures_per_gpu_per_step": B, "coded_bytes_per_picture": coded, "streams": args.streams,
                        "parallelism": f"frame-parallel x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": dom, "kernel_avg_ms": round(dom_ms / dom_launches, 4),
-                         "algorithmic_bytes_per_launch": alg_dir * B,
+                         "algorithmic_bytes_per_launch": int(alg_dir * per_launch),
                          "path_achieved_GBs": round(path_achieved, 1),
                          "path_frac": round(path_achieved / HBM_PEAK_GBS, 4),
                          "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kern.items())}},

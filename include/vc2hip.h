@@ -184,6 +184,10 @@ int vc2hip_decode_picture_ld(vc2hip_ctx *ctx, const uint8_t *payload, size_t len
  *   d_lens      n uint64 payload lengths (device memory; written by encode, read by decode)
  * Nothing is allocated or synchronised inside these calls once the ctx has seen the geometry
  * (first call sizes the workspace). */
+/* Cut every device-resident batch into k contiguous sub-batches, each on its own HIP stream and workspace,
+ * forked from and joined to the context's stream (k = 1: off, the default).  The launches of the sub-batches
+ * overlap on the GPU; results are identical.  Extension, no counterpart in the reference. */
+int vc2hip_set_streams(vc2hip_ctx *ctx, int k);
 int vc2hip_encode_batch_dev(vc2hip_ctx *ctx, const void *d_raw, int n,
                             const vc2hip_picture_format *fmt, const vc2hip_coding_params *cp,
                             void *d_payload, size_t payload_stride, uint64_t *d_lens);

@@ -503,3 +503,50 @@ def test_ld_encode_errors(hip, oracle):
         hip.ld_pack(y, u, u, depth, q, sb)
     with pytest.raises(Exception):
         oracle.ld_pack(y, u, u, depth, q, sb)
+
+
+def test_multi_stream_batches_are_identical(oracle):
+    """vc2hip_set_streams: a batch cut over 3 streams / workspaces gives the same payloads, lengths and pictures
+    (5 pictures -> sub-batches of 2, 2, 1), and device-side errors of a lane surface at sync."""
+    import torch
+    import vc2hip_py
+    hip = vc2hip_py.Vc2Hip(0)
+    w, h, n = 256, 128, 5
+    raw = synth(w, h, "422", 10, 57, frames=n)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", 3, 1, 2, q=11, scalar=2)
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def run():
+        d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        hip.profile_reset(); hip.profile_enable(True)
+        hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+        hip.sync()
+        hip.profile_enable(False)
+        return d_pay.cpu().numpy(), d_len.cpu().tolist(), d_out.cpu().numpy().tobytes(), hip.profile()
+
+    pay1, len1, out1, prof1 = run()
+    hip.set_streams(3)
+    pay3, len3, out3, prof3 = run()
+    assert len1 == len3 and out1 == out3
+    for k in range(n):
+        assert np.array_equal(pay1[k * stride:k * stride + len1[k]], pay3[k * stride:k * stride + len3[k]])
+    assert prof1["hq_pack"][0] == 1 and prof3["hq_pack"][0] == 3          # one launch per lane
+    p = make_params(w, h, "422", 10, "DD97", 3, 1, 2, q=11, scalar=2)
+    assert out1 == oracle.decode_stream(p, oracle.encode_stream(p, raw, n), n)[0]
+    # an error inside one lane's sub-batch is reported by the parent's sync
+    bad = noise_frame(w, h, "422", 10, seed=58, full_scale=True)
+    d_bad = torch.frombuffer(bytearray(raw[:4 * rb] + bad), dtype=torch.uint8).to(dev)
+    fmt2, cp2 = _fmt_cp(hip, w, h, "422", 10, "DD97", 3, 1, 2, q=0, scalar=1)
+    d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    hip.encode_batch_dev(d_bad.data_ptr(), n, fmt2, cp2, d_pay.data_ptr(), stride, d_len.data_ptr())
+    with pytest.raises(Exception, match="Slice scalar is too small"):
+        hip.sync()
+    hip.set_streams(1)

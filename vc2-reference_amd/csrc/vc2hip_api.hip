@@ -107,6 +107,18 @@ struct vc2hip_ctx {
   // critical path and the kernel is latency-bound), kept as a tested alternative.
   bool two_pass_vbr = true;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
+  // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
+  // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
+  // sub-batches overlap: the tail of one launch is filled by the next stream's work.
+  std::vector<vc2hip_ctx *> lanes;    // lanes[0] is the context itself (its own stream), the others are children
+  bool in_split = false;              // the context is running its own sub-batch as lane 0
+  hipEvent_t fork_ev = nullptr;
+  std::vector<hipEvent_t> join_ev;    // end of lane i's latest sub-batch
+  bool lanes_pending = false;         // `stream` has not yet been made to wait for the lanes' latest sub-batches
+  struct Range { const uint8_t *lo, *hi; };
+  struct LaneUse { Range r[2], w[2]; bool valid = false; };
+  std::vector<LaneUse> lane_use;      // what lane i's latest sub-batch read and wrote (caller buffers)
+  std::vector<ProfEntry> merged; // profile of this context and its lanes, rebuilt by vc2hip_profile_count
 };
 
 static const char *code_text(int code) {
@@ -271,6 +283,9 @@ extern "C" void vc2hip_destroy(vc2hip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  for (vc2hip_ctx *l : c->lanes) if (l != c) vc2hip_destroy(l);
+  for (hipEvent_t e : c->join_ev) (void)hipEventDestroy(e);
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   c->L.collect();
   for (auto e : c->L.pool) (void)hipEventDestroy(e);
   for (auto &b : c->buf) if (b.p) (void)hipFree(b.p);
@@ -290,18 +305,116 @@ static int err_from_flags(vc2hip_ctx *c, unsigned f) {
   if (f & VC2_DEVERR_LD_TOOBIG) return set_err(c, VC2HIP_ELD_TOOBIG);
   return set_err(c, VC2HIP_ESTREAM);
 }
+// make the context's stream wait for whatever its lanes still have in flight
+static int join_lanes(vc2hip_ctx *c) {
+  if (!c->lanes_pending || c->in_split) return VC2HIP_OK;
+  for (size_t i = 1; i < c->lanes.size(); ++i)
+    if (c->lane_use[i].valid) HIPCHK(c, hipStreamWaitEvent(c->stream, c->join_ev[i], 0));
+  c->lanes_pending = false;
+  return VC2HIP_OK;
+}
+// every entry point that enqueues on the context's stream starts here
+static int enter(vc2hip_ctx *c) {
+  HIPCHK(c, hipSetDevice(c->device));
+  return join_lanes(c);
+}
+#define ENTER(ctx) do { int rc_ = enter(ctx); if (rc_) return rc_; } while (0)
+
+extern "C" int vc2hip_set_streams(vc2hip_ctx *c, int k) {
+  if (!c || k < 1 || k > 16) return set_err(c, VC2HIP_EINVAL);
+  ENTER(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (vc2hip_ctx *l : c->lanes) if (l != c) vc2hip_destroy(l);
+  c->lanes.clear();
+  c->lane_use.clear();
+  for (hipEvent_t e : c->join_ev) (void)hipEventDestroy(e);
+  c->join_ev.clear();
+  if (k == 1) return VC2HIP_OK;
+  if (!c->fork_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+  for (int i = 0; i < k; ++i) {
+    vc2hip_ctx *l = c;
+    if (i > 0) {
+      const int rc = vc2hip_create(c->device, &l);
+      if (rc) return set_err(c, rc);
+      l->L.on = c->L.on;
+    }
+    c->lanes.push_back(l);
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->join_ev.push_back(e);
+  }
+  c->lane_use.assign((size_t)k, vc2hip_ctx::LaneUse());
+  return VC2HIP_OK;
+}
+
+// Run fn(lane, first picture, picture count) for contiguous sub-batches on the lanes' streams.  use(first, count,
+// LaneUse&) names the caller buffers a sub-batch reads and writes.  A lane waits for the context's stream (fork)
+// and for every other lane whose previous sub-batch touched what it is about to touch; consecutive calls with the
+// same partition (encode -> decode of the same batch) therefore chain lane by lane without a barrier.  The
+// context's stream joins the lanes lazily: at the next entry point that uses it, or at once when the stream
+// belongs to the caller (vc2hip_create_on_stream).
+template <class U, class F> static int split_batch(vc2hip_ctx *c, int n, U use, F fn) {
+  const int k = std::min<int>((int)c->lanes.size(), n);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
+  std::vector<vc2hip_ctx::LaneUse> cur((size_t)c->lanes.size());
+  std::vector<int> first((size_t)k), count((size_t)k);
+  auto overlap = [](const vc2hip_ctx::Range &a, const vc2hip_ctx::Range &b) { return a.lo && b.lo && a.lo < b.hi && b.lo < a.hi; };
+  for (int i = 0, f0 = 0; i < k; ++i) {
+    count[i] = n / k + (i < n % k ? 1 : 0);
+    first[i] = f0;
+    f0 += count[i];
+    use(first[i], count[i], cur[i]);
+    cur[i].valid = true;
+  }
+  for (int i = 0; i < k; ++i) { // all waits before any join event is recorded again
+    vc2hip_ctx *l = c->lanes[i];
+    if (i > 0) HIPCHK(c, hipStreamWaitEvent(l->stream, c->fork_ev, 0));
+    for (size_t j = 0; j < c->lanes.size(); ++j) {
+      const vc2hip_ctx::LaneUse &p = c->lane_use[j];
+      if ((int)j == i || !p.valid) continue;
+      bool dep = false;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          dep |= overlap(cur[i].r[a], p.w[b]) || overlap(cur[i].w[a], p.w[b]) || overlap(cur[i].w[a], p.r[b]);
+      if (dep) HIPCHK(c, hipStreamWaitEvent(l->stream, c->join_ev[j], 0));
+    }
+  }
+  int rc = VC2HIP_OK;
+  for (int i = 0; i < k; ++i) {
+    vc2hip_ctx *l = c->lanes[i];
+    c->in_split = (i == 0);
+    const int r = fn(l, first[i], count[i]);
+    c->in_split = false;
+    if (r && !rc) rc = i ? set_err(c, r, l->err.c_str()) : r;
+    HIPCHK(c, hipEventRecord(c->join_ev[i], l->stream));
+    c->lane_use[i] = cur[i];
+  }
+  c->lanes_pending = true;
+  if (!c->own_stream) return join_lanes(c) ? VC2HIP_EHIP : rc;
+  return rc;
+}
+
 extern "C" int vc2hip_sync(vc2hip_ctx *c) {
   if (!c) return VC2HIP_EINVAL;
+  ENTER(c);
   HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->L.collect();
+  int lane_rc = VC2HIP_OK;
+  for (vc2hip_ctx *l : c->lanes) { // their work was joined into c->stream; surface their error flags too
+    if (l == c) continue;
+    const int r = vc2hip_sync(l);
+    if (r && !lane_rc) lane_rc = set_err(c, r, l->err.c_str());
+  }
   if (!c->L.launch_error.empty()) {
     const std::string m = c->L.launch_error;
     c->L.launch_error.clear();
     return set_err(c, VC2HIP_EHIP, m.c_str());
   }
-  return err_from_flags(c, *c->h_err);
+  const int rc = err_from_flags(c, *c->h_err);
+  return rc ? rc : lane_rc;
 }
 
 static int need(vc2hip_ctx *c, int which, size_t bytes, void **out) {
@@ -327,16 +440,37 @@ static int need(vc2hip_ctx *c, int which, size_t bytes, void **out) {
   } while (0)
 
 // ---- profiling ---------------------------------------------------------------------------------
-extern "C" int vc2hip_profile_enable(vc2hip_ctx *c, int on) { if (!c) return VC2HIP_EINVAL; c->L.on = on != 0; return 0; }
-extern "C" int vc2hip_profile_count(vc2hip_ctx *c) { return c ? (int)c->L.entries.size() : 0; }
-extern "C" int vc2hip_profile_get(vc2hip_ctx *c, int i, const char **name, int *launches, double *total_ms) {
-  if (!c || i < 0 || i >= (int)c->L.entries.size()) return VC2HIP_EINVAL;
-  if (name) *name = c->L.entries[i].name.c_str();
-  if (launches) *launches = c->L.entries[i].launches;
-  if (total_ms) *total_ms = c->L.entries[i].ms;
+extern "C" int vc2hip_profile_enable(vc2hip_ctx *c, int on) {
+  if (!c) return VC2HIP_EINVAL;
+  c->L.on = on != 0;
+  for (vc2hip_ctx *l : c->lanes) l->L.on = on != 0;
   return 0;
 }
-extern "C" int vc2hip_profile_reset(vc2hip_ctx *c) { if (!c) return VC2HIP_EINVAL; c->L.collect(); c->L.entries.clear(); return 0; }
+// entries of the context and of its lanes, merged by kernel name
+extern "C" int vc2hip_profile_count(vc2hip_ctx *c) {
+  if (!c) return 0;
+  c->merged = c->L.entries;
+  for (vc2hip_ctx *l : c->lanes)
+    if (l != c) for (const ProfEntry &e : l->L.entries) {
+      bool found = false;
+      for (ProfEntry &m : c->merged) if (m.name == e.name) { m.launches += e.launches; m.ms += e.ms; found = true; break; }
+      if (!found) c->merged.push_back(e);
+    }
+  return (int)c->merged.size();
+}
+extern "C" int vc2hip_profile_get(vc2hip_ctx *c, int i, const char **name, int *launches, double *total_ms) {
+  if (!c || i < 0 || i >= (int)c->merged.size()) return VC2HIP_EINVAL;
+  if (name) *name = c->merged[i].name.c_str();
+  if (launches) *launches = c->merged[i].launches;
+  if (total_ms) *total_ms = c->merged[i].ms;
+  return 0;
+}
+extern "C" int vc2hip_profile_reset(vc2hip_ctx *c) {
+  if (!c) return VC2HIP_EINVAL;
+  c->L.collect(); c->L.entries.clear(); c->merged.clear();
+  for (vc2hip_ctx *l : c->lanes) if (l != c) { l->L.collect(); l->L.entries.clear(); }
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // geometry
@@ -582,7 +716,7 @@ extern "C" int vc2hip_dwt_forward(vc2hip_ctx *c, const int32_t *in, int h, int w
                                   int32_t *out) {
   if (!c || !in || !out || h < 1 || w < 1 || depth < 1 || depth > VC2_MAX_DEPTH) return set_err(c, VC2HIP_EINVAL);
   if (kernel < 0 || kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const int ph = vc2hip_padded_size(h, depth), pw = vc2hip_padded_size(w, depth);
   Geom g;
   int rc = one_plane_geom(g, ph, pw, depth, ph >> depth, pw >> depth);
@@ -614,7 +748,7 @@ extern "C" int vc2hip_dwt_inverse(vc2hip_ctx *c, const int32_t *in, int ph, int 
   if (!c || !in || !out || depth < 1 || depth > VC2_MAX_DEPTH || h < 1 || w < 1 || h > ph || w > pw) return set_err(c, VC2HIP_EINVAL);
   if (kernel < 0 || kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
   if (ph % (1 << depth) || pw % (1 << depth)) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = one_plane_geom(g, ph, pw, depth, ph >> depth, pw >> depth);
   if (rc) return set_err(c, rc);
@@ -643,7 +777,7 @@ extern "C" int vc2hip_dwt_inverse(vc2hip_ctx *c, const int32_t *in, int ph, int 
 static int plane_quant_op(vc2hip_ctx *c, const int32_t *in, int ph, int pw, int depth, const int32_t *qidx, int ys,
                           int xs, const int32_t *qm, int32_t *out, int op /*0 quant,1 scale,2 scale+LD*/) {
   if (!c || !in || !out || !qidx || !qm) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = one_plane_geom(g, ph, pw, depth, ys, xs);
   if (rc) return set_err(c, rc);
@@ -750,7 +884,7 @@ extern "C" int vc2hip_hq_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u,
                               const int32_t *qidx, int prefix, int scalar, const int32_t *cbr, uint8_t *out, size_t cap,
                               size_t *out_len) {
   if (!c || !y || !u || !v || !ga || !qidx || !out || !out_len || prefix < 0 || scalar < 1) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
@@ -798,7 +932,7 @@ static int build_index(vc2hip_ctx *c, const uint8_t *d_pay, long long stride, co
 extern "C" int vc2hip_hq_unpack(vc2hip_ctx *c, const uint8_t *in, size_t len, const vc2hip_geom *ga, int prefix, int scalar,
                                 int32_t *y, int32_t *u, int32_t *v, int32_t *qidx, size_t *consumed) {
   if (!c || !in || !ga || !y || !u || !v || !qidx || prefix < 0 || scalar < 1) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
@@ -839,7 +973,7 @@ extern "C" int vc2hip_hq_unpack(vc2hip_ctx *c, const uint8_t *in, size_t len, co
 extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
                                    const int32_t *qm, const int32_t *slice_bytes, int scalar, int32_t *qidx) {
   if (!c || !y || !u || !v || !ga || !qm || !slice_bytes || !qidx || scalar < 1) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
@@ -884,7 +1018,7 @@ static void fill_ld_unpack(LdUnpackParams &p, const Geom &g, const uint8_t *d_pa
 extern "C" int vc2hip_ld_unpack(vc2hip_ctx *c, const uint8_t *in, size_t len, const vc2hip_geom *ga, const int32_t *slice_bytes,
                                 int32_t *y, int32_t *u, int32_t *v, int32_t *qidx, size_t *consumed) {
   if (!c || !in || !ga || !slice_bytes || !y || !u || !v || !qidx) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
@@ -935,7 +1069,7 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
 extern "C" int vc2hip_quantise_ld(vc2hip_ctx *c, const int32_t *coef, int ph, int pw, int depth, const int32_t *qidx,
                                   int ys, int xs, const int32_t *qm, int32_t *out) {
   if (!c || !coef || !out || !qidx || !qm) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = one_plane_geom(g, ph, pw, depth, ys, xs);
   if (rc) return set_err(c, rc);
@@ -964,7 +1098,7 @@ extern "C" int vc2hip_quantise_ld(vc2hip_ctx *c, const int32_t *coef, int ph, in
 extern "C" int vc2hip_ld_qindices(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
                                   const int32_t *qm, const int32_t *slice_bytes, int32_t *qidx) {
   if (!c || !y || !u || !v || !ga || !qm || !slice_bytes || !qidx) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
@@ -991,7 +1125,7 @@ extern "C" int vc2hip_ld_qindices(vc2hip_ctx *c, const int32_t *y, const int32_t
 extern "C" int vc2hip_ld_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u, const int32_t *v, const vc2hip_geom *ga,
                               const int32_t *qidx, const int32_t *slice_bytes, uint8_t *out, size_t cap, size_t *out_len) {
   if (!c || !y || !u || !v || !ga || !qidx || !slice_bytes || !out || !out_len) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
@@ -1035,10 +1169,24 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
                                        const vc2hip_coding_params *cp, void *d_payload, size_t payload_stride,
                                        uint64_t *d_lens) {
   if (!c || !d_raw || n < 1 || !f || !cp || !d_payload || !d_lens) return set_err(c, VC2HIP_EINVAL);
+  if (c->lanes.size() > 1 && n > 1 && !c->in_split) {
+    const size_t rb = vc2hip_raw_picture_bytes(f);
+    const uint8_t *raw8 = (const uint8_t *)d_raw, *pay8 = (const uint8_t *)d_payload, *len8 = (const uint8_t *)d_lens;
+    return split_batch(c, n,
+      [&](int first, int count, vc2hip_ctx::LaneUse &u) {
+        u.r[0] = {raw8 + (size_t)first * rb, raw8 + (size_t)(first + count) * rb}; u.r[1] = {nullptr, nullptr};
+        u.w[0] = {pay8 + (size_t)first * payload_stride, pay8 + (size_t)(first + count) * payload_stride};
+        u.w[1] = {len8 + (size_t)first * 8, len8 + (size_t)(first + count) * 8};
+      },
+      [&](vc2hip_ctx *l, int first, int count) {
+        return vc2hip_encode_batch_dev(l, raw8 + (size_t)first * rb, count, f, cp,
+                                       (uint8_t *)d_payload + (size_t)first * payload_stride, payload_stride, d_lens + first);
+      });
+  }
   if (cp->mode != VC2HIP_HQ_CONSTQ && cp->mode != VC2HIP_HQ_CBR && cp->mode != VC2HIP_LD) return set_err(c, VC2HIP_EINVAL);
   if (cp->kernel < 0 || cp->kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
   if (cp->mode != VC2HIP_LD && (cp->scalar < 1 || cp->prefix < 0)) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = picture_geom(g, f, cp, false);
   if (rc) return set_err(c, rc);
@@ -1109,7 +1257,7 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
                                const vc2hip_picture_format *f, const vc2hip_coding_params *cp, void *d_raw_out, bool ld) {
   if (!c || !d_payload || n < 1 || !f || !cp || !d_raw_out) return set_err(c, VC2HIP_EINVAL);
   if (cp->kernel < 0 || cp->kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   Geom g;
   int rc = picture_geom(g, f, cp, true);
   if (rc) return set_err(c, rc);
@@ -1166,6 +1314,20 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
 
 extern "C" int vc2hip_decode_batch_dev(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens,
                                        int n, const vc2hip_picture_format *f, const vc2hip_coding_params *cp, void *d_raw_out) {
+  if (c && c->lanes.size() > 1 && n > 1 && !c->in_split && d_payload && f && cp && d_raw_out) {
+    const size_t rb = vc2hip_raw_picture_bytes(f);
+    const uint8_t *out8 = (const uint8_t *)d_raw_out, *pay8 = (const uint8_t *)d_payload, *len8 = (const uint8_t *)d_lens;
+    return split_batch(c, n,
+      [&](int first, int count, vc2hip_ctx::LaneUse &u) {
+        u.r[0] = {pay8 + (size_t)first * payload_stride, pay8 + (size_t)(first + count) * payload_stride};
+        u.r[1] = {len8 ? len8 + (size_t)first * 8 : nullptr, len8 ? len8 + (size_t)(first + count) * 8 : nullptr};
+        u.w[0] = {out8 + (size_t)first * rb, out8 + (size_t)(first + count) * rb}; u.w[1] = {nullptr, nullptr};
+      },
+      [&](vc2hip_ctx *l, int first, int count) {
+        return vc2hip_decode_batch_dev(l, pay8 + (size_t)first * payload_stride, payload_stride,
+                                       d_lens ? d_lens + first : nullptr, count, f, cp, (uint8_t *)d_raw_out + (size_t)first * rb);
+      });
+  }
   return decode_batch_common(c, d_payload, payload_stride, d_lens, n, f, cp, d_raw_out, cp && cp->mode == VC2HIP_LD);
 }
 
@@ -1173,7 +1335,7 @@ extern "C" int vc2hip_encode_picture_hq(vc2hip_ctx *c, const void *raw, const vc
                                         const vc2hip_coding_params *cp, uint8_t *payload, size_t cap, size_t *len,
                                         int32_t *qidx_out) {
   if (!c || !raw || !f || !cp || !payload || !len) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const size_t rb = vc2hip_raw_picture_bytes(f), pcap = vc2hip_max_payload_bytes(f, cp);
   uint8_t *d_raw, *d_pay; unsigned long long *d_len;
   NEED(c, B_RAW, rb + 64, d_raw);
@@ -1203,7 +1365,7 @@ extern "C" int vc2hip_encode_picture_ld(vc2hip_ctx *c, const void *raw, const vc
 static int decode_picture_host(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,
                                const vc2hip_coding_params *cp, void *raw_out, bool ld) {
   if (!c || !payload || !f || !cp || !raw_out) return set_err(c, VC2HIP_EINVAL);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const size_t rb = vc2hip_raw_picture_bytes(f);
   const size_t stride = (len + 63) & ~(size_t)63;
   uint8_t *d_raw, *d_pay; unsigned long long *d_len;

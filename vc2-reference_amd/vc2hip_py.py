@@ -47,7 +47,7 @@ EXPORTS = [
     "vc2hip_quant_matrix", "vc2hip_slice_bytes", "vc2hip_dwt_forward", "vc2hip_dwt_inverse",
     "vc2hip_quantise_np", "vc2hip_dequantise_np", "vc2hip_dequantise_ld", "vc2hip_hq_pack",
     "vc2hip_hq_unpack", "vc2hip_ld_unpack", "vc2hip_cbr_qindices", "vc2hip_quantise_ld", "vc2hip_ld_pack",
-    "vc2hip_ld_qindices", "vc2hip_encode_picture_ld", "vc2hip_raw_picture_bytes",
+    "vc2hip_ld_qindices", "vc2hip_encode_picture_ld", "vc2hip_set_streams", "vc2hip_raw_picture_bytes",
     "vc2hip_max_payload_bytes", "vc2hip_encode_picture_hq", "vc2hip_decode_picture_hq",
     "vc2hip_decode_picture_ld", "vc2hip_encode_batch_dev", "vc2hip_decode_batch_dev",
     "vc2hip_profile_enable", "vc2hip_profile_count", "vc2hip_profile_get", "vc2hip_profile_reset",
@@ -76,6 +76,7 @@ def load_library():
     lib.vc2hip_error_string.argtypes = [C.c_int]
     lib.vc2hip_error_string.restype = C.c_char_p
     lib.vc2hip_sync.argtypes = [vp]
+    lib.vc2hip_set_streams.argtypes = [vp, C.c_int]
     lib.vc2hip_quant_matrix.argtypes = [C.c_int, C.c_int, i32p]
     lib.vc2hip_slice_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p]
     lib.vc2hip_dwt_forward.argtypes = [vp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
@@ -317,6 +318,9 @@ class Vc2Hip:
     def decode_batch_dev(self, d_payload, stride, d_lens, n, fmt, cp, d_raw_out):
         self._chk(self.lib.vc2hip_decode_batch_dev(self.h, d_payload, stride, d_lens, n, C.byref(fmt),
                                                    C.byref(cp), d_raw_out))
+
+    def set_streams(self, k):
+        self._chk(self.lib.vc2hip_set_streams(self.h, k))
 
     def sync(self):
         self._chk(self.lib.vc2hip_sync(self.h))
