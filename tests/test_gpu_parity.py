@@ -550,3 +550,30 @@ def test_multi_stream_batches_are_identical(oracle):
     with pytest.raises(Exception, match="Slice scalar is too small"):
         hip.sync()
     hip.set_streams(1)
+
+
+@pytest.mark.parametrize("scalar", [11, 30, 45])
+def test_large_slice_scalars(hip, oracle, scalar):
+    """Slices that may exceed 8191 bytes use 32 KiB index chunks, beyond 32767 bytes a serial walk: any slice size
+    scalar the stream syntax allows is decoded.  The GPU slice coder keeps four slice images in LDS and stops at
+    scalar 40 with an error; beyond that the stream comes from the oracle only."""
+    import ctypes as C
+    w, h, depth, prefix = 256, 128, 3, 2
+    raw = noise_frame(w, h, "422", 10, seed=59)
+    p = make_params(w, h, "422", 10, "LeGall", depth, 2, 2, q=6, scalar=scalar, prefix=prefix)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "LeGall", depth, 2, 2, q=6, scalar=scalar, prefix=prefix)
+    ph = np.zeros(64, np.uint8); m = C.c_size_t()
+    oracle.lib.vc2o_write_hq_picture_header(0, p.kernel, depth, cp.x_slices, cp.y_slices, prefix, scalar, 2,
+                                            ph.ctypes.data_as(C.c_void_p), 64, C.byref(m))
+    second = stream.index(b"BBCD", 13)
+    assert stream[second + 13:second + 13 + m.value] == bytes(ph[:m.value])
+    payload = stream[second + 13 + m.value:-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+    if scalar <= 40:
+        got, _ = hip.encode_picture_hq(raw, fmt, cp)
+        assert got == payload
+    else:
+        with pytest.raises(Exception, match="too large for the slice coder"):
+            hip.encode_picture_hq(raw, fmt, cp)

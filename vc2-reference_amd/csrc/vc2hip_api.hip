@@ -19,6 +19,7 @@ int vc2_halo_x(int kernel);
 int vc2_halo_y(int kernel);
 void vc2_upload_vlc_lut(hipStream_t s);
 bool vc2_slice_index_supported(int prefix, int scalar);
+size_t vc2_pack_lds_bytes(int prefix, int scalar);
 void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
 bool vc2_fast_level_applicable(LevelParams &p);
 int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, hipStream_t s);
@@ -677,6 +678,8 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const int32_t *store, c
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
   p.err = c->d_err; p.quantise = quantise;
   p.payload = d_payload; p.payload_stride = stride;
+  if (vc2_pack_lds_bytes(prefix, scalar) > 144 * 1024)
+    return set_err(c, VC2HIP_EINVAL, "slice prefix / size scalar too large for the slice coder (four slice images of prefix + 4 + 765 * scalar bytes must fit in LDS)");
   if (d_cbr_bytes) {
     p.cbr_bytes = d_cbr_bytes; p.cbr_offsets = d_cbr_offs;
     vc2_launch_pack(c->L, p, n, c->stream);
@@ -918,8 +921,6 @@ extern "C" int vc2hip_hq_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u,
 static int build_index(vc2hip_ctx *c, const uint8_t *d_pay, long long stride, const unsigned long long *d_lens, int n, int ns,
                        int prefix, int scalar, uint32_t **d_offs_out) {
   uint32_t *d_offs; void *ws;
-  if (!vc2_slice_index_supported(prefix, scalar))
-    return set_err(c, VC2HIP_EINVAL, "slice prefix / size scalar too large for the device slice index (prefix + 765 * scalar must be < 8188)");
   NEED(c, B_OFFS, (size_t)n * ns * 4, d_offs);
   const size_t wsb = vc2_slice_index_workspace(n, (size_t)stride, prefix, scalar);
   NEED(c, B_INDEX, wsb, ws);

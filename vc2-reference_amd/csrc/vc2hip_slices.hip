@@ -523,11 +523,15 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   }
 }
 
+size_t vc2_pack_lds_bytes(int prefix, int scalar);
+size_t vc2_pack_lds_bytes(int prefix, int scalar) {
+  const size_t img_words = ((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2;
+  return 4 * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * 32 * 16;
+}
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
   { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
-  const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
-  const size_t lds = (size_t)4 * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * 32 * 16;
+  const size_t lds = vc2_pack_lds_bytes(p.prefix, p.scalar);
   vc2_allow_lds((const void *)k_hq_pack, 144 * 1024);
   vc2_prof_begin(L, "hq_pack", s);
   hipLaunchKernelGGL(k_hq_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), lds, s, p);
@@ -931,7 +935,9 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipSt
 //   2. chain  : per picture, follow entry -> exit through the chunk tables  [one lane/picture]
 //   3. emit   : per chunk, walk again from the now-known entry and write the offsets
 // ------------------------------------------------------------------------------------------
-static constexpr int IDX_CH = 16384;
+// chunk size: 16 KiB, or 32 KiB when a slice can be longer than 8191 bytes (entry offsets must stay below the
+// chunk size and chunk-relative positions below 2^16)
+static int idx_chunk(int E) { return E <= 8191 ? 16384 : 32768; }
 
 __device__ __forceinline__ int slice_len_lds(const uint8_t *b, int pos, int prefix, int scalar) {
   int q = pos + prefix + 1;
@@ -958,7 +964,7 @@ __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long
 }
 
 static constexpr int IDX_THREADS = 1024;
-static constexpr int IDX_MAX_E = 8191;   // entry offsets (a slice's maximum size) must stay below the chunk size
+static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
 
 // Chunk function by table walk.  One pass fills next[i] = the position reached if a slice started at byte i
 // of the chunk, from the three length bytes behind every byte position (throughput-bound LDS work: PER
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
 static constexpr int IDX_GROUP = 16;
 
 __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, const uint2 *tables,
-                                                     uint2 *groups, int n_chunks, int n_groups, int E) {
+                                                     uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH) {
   const int g = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = lens[pic];
   if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) return;
@@ -1035,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
 
 __global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *lens, const uint2 *tables,
                                                     const uint2 *groups, uint2 *entries, int n_chunks,
-                                                    int n_groups, int E) {
+                                                    int n_groups, int E, int IDX_CH) {
   __shared__ uint2 g_entry[64 * 16];
   const int pic = blockIdx.x;
   const unsigned long long plen = lens[pic];
@@ -1067,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *le
 __global__ __launch_bounds__(256) void k_index_emit(const uint8_t *payload, long long stride,
                                                    const unsigned long long *lens, const uint2 *entries,
                                                    uint32_t *offsets, int n_chunks, int E, int n_slices,
-                                                   int prefix, int scalar, unsigned *err) {
+                                                   int prefix, int scalar, unsigned *err, int IDX_CH) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
@@ -1089,13 +1095,34 @@ __global__ __launch_bounds__(256) void k_index_emit(const uint8_t *payload, long
 }
 
 static int idx_entries(int prefix, int scalar) { return prefix + 4 + 3 * 255 * scalar; }
-bool vc2_slice_index_supported(int prefix, int scalar);
 
-bool vc2_slice_index_supported(int prefix, int scalar) { return idx_entries(prefix, scalar) <= IDX_MAX_E; }
+// Last resort for slices that can exceed 32767 bytes (slice size scalar > 42): one lane per picture follows the
+// length bytes through memory.  Correct for any stream, three dependent loads per slice.
+__global__ __launch_bounds__(64) void k_index_serial(const uint8_t *payload, long long stride, const unsigned long long *lens,
+                                                     uint32_t *offsets, int n_slices, int prefix, int scalar, unsigned *err,
+                                                     int n_pictures) {
+  const int pic = blockIdx.x * 64 + threadIdx.x;
+  if (pic >= n_pictures) return;
+  const uint8_t *pay = payload + (size_t)pic * stride;
+  const unsigned long long plen = lens[pic];
+  unsigned long long pos = 0;
+  for (int k = 0; k < n_slices; ++k) {
+    offsets[(size_t)pic * n_slices + k] = (uint32_t)pos;
+    if (pos >= plen) { atomicOr(err, VC2_DEVERR_STREAM); continue; }
+    unsigned long long q = pos + prefix + 1;
+    for (int c = 0; c < 3; ++c) q += 1 + (q < plen ? (unsigned long long)pay[q] * scalar : 0ull);
+    pos = q;
+  }
+}
+
+bool vc2_slice_index_supported(int prefix, int scalar);
+bool vc2_slice_index_supported(int prefix, int scalar) { (void)prefix; (void)scalar; return true; }
 
 size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix, int scalar) {
-  const size_t n_chunks = (max_payload + IDX_CH - 1) / IDX_CH + 1;
   const size_t E = idx_entries(prefix, scalar);
+  if (E > (size_t)IDX_MAX_E) return 256;
+  const size_t ch = (size_t)idx_chunk((int)E);
+  const size_t n_chunks = (max_payload + ch - 1) / ch + 1;
   const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
   return (size_t)n_pictures * (n_chunks * (E + 1) + n_groups * E) * sizeof(uint2) + 256;
 }
@@ -1105,31 +1132,46 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
                             int prefix, int scalar, int n_pictures, unsigned *err, hipStream_t s,
                             void *workspace, size_t workspace_bytes) {
   const int E = idx_entries(prefix, scalar);
+  (void)workspace_bytes;
+  if (E > IDX_MAX_E) {
+    vc2_prof_begin(L, "slice_index_serial", s);
+    hipLaunchKernelGGL(k_index_serial, dim3((n_pictures + 63) / 64), dim3(64), 0, s, payload, payload_stride, lens,
+                       offsets, n_slices, prefix, scalar, err, n_pictures);
+    vc2_prof_end(L, s);
+    return;
+  }
+  const int ch = idx_chunk(E);
   // chunk count is bounded by the payload slot size (lens live on the device)
-  const int n_chunks = (int)(((size_t)payload_stride + IDX_CH - 1) / IDX_CH) + 1;
+  const int n_chunks = (int)(((size_t)payload_stride + ch - 1) / ch) + 1;
   uint2 *tables = (uint2 *)workspace;
   uint2 *entries = tables + (size_t)n_pictures * n_chunks * E;
-  (void)workspace_bytes;
-  vc2_allow_lds((const void *)k_index_emit, 160 * 1024);
+  const size_t stage_bytes = (size_t)((ch + E + 16 + 15) & ~15);
+  vc2_allow_lds((const void *)k_index_emit, stage_bytes);
   const char *dbg_env = getenv("VC2HIP_DEBUG_INDEX");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   vc2_prof_begin(L, "slice_index_tables", s);
   {
-    const size_t lds = (size_t)((IDX_CH + E + 16 + 15) & ~15) + (size_t)IDX_CH * 2;
-    vc2_allow_lds((const void *)k_index_tables_nx<IDX_CH>, lds);
-    hipLaunchKernelGGL((k_index_tables_nx<IDX_CH>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                       lens, tables, n_chunks, E, prefix, scalar, dbg);
+    const size_t lds = stage_bytes + (size_t)ch * 2;
+    if (ch == 16384) {
+      vc2_allow_lds((const void *)k_index_tables_nx<16384>, lds);
+      hipLaunchKernelGGL((k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
+                         lens, tables, n_chunks, E, prefix, scalar, dbg);
+    } else {
+      vc2_allow_lds((const void *)k_index_tables_nx<32768>, lds);
+      hipLaunchKernelGGL((k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
+                         lens, tables, n_chunks, E, prefix, scalar, dbg);
+    }
   }
   vc2_prof_end(L, s);
-  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 512 MiB
+  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 256 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
-  hipLaunchKernelGGL(k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, tables, groups, n_chunks, n_groups, E);
-  hipLaunchKernelGGL(k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, tables, groups, entries, n_chunks, n_groups, E);
+  hipLaunchKernelGGL(k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, tables, groups, n_chunks, n_groups, E, ch);
+  hipLaunchKernelGGL(k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, tables, groups, entries, n_chunks, n_groups, E, ch);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
-  hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(256), (size_t)((IDX_CH + E + 16 + 15) & ~15), s, payload,
-                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err);
+  hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(256), stage_bytes, s, payload,
+                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch);
   vc2_prof_end(L, s);
 }
 
