@@ -577,3 +577,19 @@ def test_large_slice_scalars(hip, oracle, scalar):
     else:
         with pytest.raises(Exception, match="too large for the slice coder"):
             hip.encode_picture_hq(raw, fmt, cp)
+
+
+@pytest.mark.parametrize("u,a,cf", [(1, 1, "444"), (1, 2, "422"), (2, 2, "422"), (2, 2, "420"), (2, 4, "444"), (4, 4, "422")])
+@pytest.mark.parametrize("mode", ["HQ_ConstQ", "HQ_CBR"])
+def test_pack_lane_widths(hip, oracle, u, a, cf, mode):
+    """The slice coder gives a slice 16, 32 or 64 lanes depending on its size (4 / 2 / 1 slices per wavefront):
+    slices of 64 ... 2048 luma coefficients, VBR and CBR, against the oracle's stream."""
+    w, h, depth = 256, 128, 3
+    raw = synth(w, h, cf, 10, 60)
+    kw = dict(q=7, scalar=8, prefix=1) if mode == "HQ_ConstQ" else dict(mode="HQ_CBR", s=w * h // 2, scalar=8, prefix=1)
+    p = make_params(w, h, cf, 10, "DD97", depth, u, a, **kw)
+    stream = oracle.encode_stream(p, raw, 1)
+    fmt, cp = _fmt_cp(hip, w, h, cf, 10, "DD97", depth, u, a, **kw)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert stream.endswith(payload + stream[-13:])
+    assert hip.decode_picture(payload, fmt, cp) == oracle.decode_stream(p, stream, 1)[0]

@@ -99,6 +99,20 @@ __device__ __forceinline__ int wave_max(int v) {
   for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
   return v;
 }
+// the same inside segments of W consecutive lanes (sl = lane index inside the segment)
+template <int W> __device__ __forceinline__ int seg_incl_scan(int v, int sl) {
+#pragma unroll
+  for (int d = 1; d < W; d <<= 1) {
+    const int t = __shfl_up(v, d, W);
+    if (sl >= d) v += t;
+  }
+  return v;
+}
+template <int W> __device__ __forceinline__ int seg_max(int v) {
+#pragma unroll
+  for (int d = W / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, W));
+  return v;
+}
 __device__ __forceinline__ long long wave_sum64(long long v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
@@ -334,11 +348,16 @@ __device__ __forceinline__ int half_max(int v) { // max within each 32-lane half
   return v;
 }
 
+// W lanes work on one slice: 64 (a wavefront per slice, any geometry) or, for small slices, 32 / 16 with two / four
+// slices per wavefront, so that a slice of e.g. 128 + 2 x 64 coefficients (1080p, -u 2 -a 4) still fills its lanes.
+template <int W>
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
+  constexpr int S = 64 / W;
   extern __shared__ unsigned lds_u[];
   __shared__ unsigned long long s_base; // byte offset of this tile inside the picture payload
   __shared__ int s_tile, s_tot[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = lane / W, sl = lane % W; // slice of the wavefront, lane inside the slice
   const int pic = blockIdx.y;
   int tile = blockIdx.x;
   if (p.lookback) { // tiles are numbered in the order workgroups start, so a predecessor is always running
@@ -346,25 +365,25 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     __syncthreads();
     tile = s_tile;
   }
-  const int slice = tile * 4 + wave;
+  const int slice = (tile * 4 + wave) * S + seg;
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
-  unsigned *img = lds_u + wave * img_words;
-  unsigned *lut = lds_u + 4 * img_words;
+  unsigned *img = lds_u + (wave * S + seg) * img_words;
+  unsigned *lut = lds_u + 4 * S * img_words;
   unsigned char *band_y = (unsigned char *)(lut + VLC_LUT_N), *band_c = band_y + 512;
-  uint4 *qtab = (uint4 *)(band_c + 256) + wave * 32;
+  uint4 *qtab = (uint4 *)(band_c + 256) + (wave * S + seg) * 32;
   const bool active = slice < p.n_slices;
-  const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2];
-  for (int i = lane; i < img_words; i += 64) img[i] = 0;
+  const bool fast = p.comp_n[0] <= 8 * W && p.comp_n[1] <= 4 * W && p.comp_n[1] == p.comp_n[2];
+  for (int i = sl; i < img_words; i += W) img[i] = 0;
   build_vlc_lut(lut);
   if (fast && p.quantise) {
     const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
     const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
     for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
     for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
-    if (active && lane < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
-      const int aq = max(p.qidx[(size_t)pic * p.n_slices + slice] - p.qmatrix[lane], 0);
-      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[lane] = make_uint4(0u, 0u, 0x40000000u, 0u); }
-      else qtab[lane] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], 0u);
+    if (active && sl < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
+      const int aq = max(p.qidx[(size_t)pic * p.n_slices + slice] - p.qmatrix[sl], 0);
+      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[sl] = make_uint4(0u, 0u, 0x40000000u, 0u); }
+      else qtab[sl] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], 0u);
     }
   }
   __syncthreads();
@@ -378,14 +397,14 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     const int cbr_total = p.cbr_bytes ? p.cbr_bytes[slice] : 0;
     auto comp_len = [&](int count) -> int {
       int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
-      if (len > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
+      if (len > 255) { if (sl == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
       return len * p.scalar;
     };
     auto cbr_v = [&](int need) -> int { // Slices.cpp:352-368: V absorbs the remainder of the slice
       if (!p.cbr_bytes) return need;
       const int vb = cbr_total - 4 - bytes[0] - bytes[1];
-      if (vb < need) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); bad_cbr = true; return need; }
-      if (vb / p.scalar > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); bad_cbr = true; return need; }
+      if (vb < need) { if (sl == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); bad_cbr = true; return need; }
+      if (vb / p.scalar > 255) { if (sl == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); bad_cbr = true; return need; }
       return vb;
     };
     int base = p.prefix + 1; // byte offset of the next component's length byte
@@ -394,33 +413,33 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       { // luma: one round
         const int n = p.comp_n[0], n0 = p.comp_n0[0];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        if (p.quantise) load8_tab(c, rec + p.comp_off[0], lane * 8, n, band_y, qtab, p.err, lut);
-        else load8<false>(c, rec + p.comp_off[0], lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
-        const int incl = wave_incl_scan(c.sum, lane);
-        const int count = wave_max(c.last_end ? incl - c.sum + c.last_end : 0);
+        if (p.quantise) load8_tab(c, rec + p.comp_off[0], sl * 8, n, band_y, qtab, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[0], sl * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        const int incl = seg_incl_scan<W>(c.sum, sl);
+        const int count = seg_max<W>(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
         write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, p.debug_skip & 1);
-        if (lane == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
+        if (sl == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
         base += 1 + bytes[0];
       }
-      { // both chroma components in one round: lanes 0-31 U, lanes 32-63 V
+      { // both chroma components in one round: the lower half of the lanes U, the upper half V
         const int n = p.comp_n[1], n0 = p.comp_n0[1];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        const int half = lane >> 5, cc = 1 + half;
-        if (p.quantise) load8_tab(c, rec + p.comp_off[cc], (lane & 31) * 8, n, band_c, qtab, p.err, lut);
-        else load8<false>(c, rec + p.comp_off[cc], (lane & 31) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
-        const int incl = wave_incl_scan(c.sum, lane);
-        const int total_u = __shfl(incl, 31);
+        const int half = sl >= W / 2 ? 1 : 0, cc = 1 + half;
+        if (p.quantise) load8_tab(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, band_c, qtab, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        const int incl = seg_incl_scan<W>(c.sum, sl);
+        const int total_u = __shfl(incl, seg * W + W / 2 - 1);
         const int rel = incl - c.sum - (half ? total_u : 0);
-        const int cnt = half_max(c.last_end ? rel + c.last_end : 0);
-        bytes[1] = comp_len(__shfl(cnt, 0));
-        bytes[2] = cbr_v(comp_len(__shfl(cnt, 32)));
+        const int cnt = seg_max<W / 2>(c.last_end ? rel + c.last_end : 0);
+        bytes[1] = comp_len(__shfl(cnt, seg * W));
+        bytes[2] = cbr_v(comp_len(__shfl(cnt, seg * W + W / 2)));
         const int base_c = half ? base + 1 + bytes[1] : base;
         write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, p.debug_skip & 1);
-        if (lane == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
-        if (lane == 32) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
+        if (sl == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
+        if (sl == W / 2) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
       }
-    } else { // any geometry: two passes per component (measure, then write), 512 coefficients per round
+    } else if constexpr (W == 64) { // any geometry: two passes per component (measure, then write), 512 coefficients per round
       for (int cc = 0; cc < 3; ++cc) {
         const int n = p.comp_n[cc], n0 = p.comp_n0[cc];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         base += 1 + bytes[cc];
       }
     }
-    if (lane == 0) put_byte(img, p.prefix, (unsigned)q & 0xFF);
+    if (sl == 0) put_byte(img, p.prefix, (unsigned)q & 0xFF);
   }
   const int total = active ? p.prefix + 4 + bytes[0] + bytes[1] + bytes[2] : 0;
   if (p.lookback && lane == 0) s_tot[wave] = total;
@@ -515,26 +534,46 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   if (p.cbr_bytes) {
     if (bad_cbr) return;
     uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
-    for (int i = lane; i < total; i += 64) dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3)));
+    for (int i = sl; i < total; i += W) dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3)));
   } else {
     unsigned *dst = (unsigned *)(p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes);
-    if (lane == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
-    for (int i = lane; i < (total + 3) / 4; i += 64) dst[i] = __builtin_bswap32(img[i]);
+    if (sl == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
+    for (int i = sl; i < (total + 3) / 4; i += W) dst[i] = __builtin_bswap32(img[i]);
   }
 }
 
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
-size_t vc2_pack_lds_bytes(int prefix, int scalar) {
+static size_t pack_lds(int prefix, int scalar, int slices_per_wave) {
   const size_t img_words = ((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2;
-  return 4 * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * 32 * 16;
+  return 4 * slices_per_wave * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * (size_t)slices_per_wave * 32 * 16;
 }
+size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
   { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
-  const size_t lds = vc2_pack_lds_bytes(p.prefix, p.scalar);
-  vc2_allow_lds((const void *)k_hq_pack, 144 * 1024);
+  // lanes per slice: as few as still hold the slice (8 luma / 4 chroma coefficients and one subband constant per lane)
+  int W = 64;
+  const bool same_c = p.comp_n[1] == p.comp_n[2];
+  static const int force_w = [] { const char *e = getenv("VC2HIP_PACK_LANES"); return e ? atoi(e) : 0; }();
+  if (!p.lookback && same_c && force_w != 64) {
+    const int bands = 3 * p.depth + 1;
+    if (p.comp_n[0] <= 128 && p.comp_n[1] <= 64 && bands <= 16 && pack_lds(p.prefix, p.scalar, 4) <= 144 * 1024) W = 16;
+    else if (p.comp_n[0] <= 256 && p.comp_n[1] <= 128 && bands <= 32 && pack_lds(p.prefix, p.scalar, 2) <= 144 * 1024) W = 32;
+  }
+  const int S = 64 / W;
+  const size_t lds = pack_lds(p.prefix, p.scalar, S);
+  const int tiles = (p.n_slices + 4 * S - 1) / (4 * S);
   vc2_prof_begin(L, "hq_pack", s);
-  hipLaunchKernelGGL(k_hq_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), lds, s, p);
+  if (W == 16) {
+    vc2_allow_lds((const void *)k_hq_pack<16>, 144 * 1024);
+    hipLaunchKernelGGL(k_hq_pack<16>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+  } else if (W == 32) {
+    vc2_allow_lds((const void *)k_hq_pack<32>, 144 * 1024);
+    hipLaunchKernelGGL(k_hq_pack<32>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+  } else {
+    vc2_allow_lds((const void *)k_hq_pack<64>, 144 * 1024);
+    hipLaunchKernelGGL(k_hq_pack<64>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+  }
   vc2_prof_end(L, s);
 }
 
