@@ -182,6 +182,114 @@ __device__ __forceinline__ void v_pass(int *lds, int cq_lo, int n_cq, int ky_bas
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// Step-wise passes for long filters (Fidelity: 8 taps, 14 samples of halo).  The register-window passes above
+// would need a window of 20 pairs per parity (>180 VGPRs, 2 wavefronts per SIMD) and compute every lifting step
+// on the whole shrinking window; here every lifting step is its own sweep over LDS: a thread updates one quad of
+// the target parity in place from the (unchanged) opposite parity, each position exactly once, one barrier
+// per step.  Plane-edge tap clamping = clamped read index.
+// ------------------------------------------------------------------------------------------
+template <int K> constexpr bool stepwise() { return K == VC2HIP_FIDELITY; }
+constexpr int floor_div4(int v) { return v >= 0 ? v / 4 : -((-v + 3) / 4); }
+
+// lifting step S along x on rows [row_lo, row_lo + n_rows) of the (2 * WYP)-row stack, pair quads [q_lo, q_hi)
+template <int K, int S, bool INV>
+__device__ __forceinline__ void step_h(int *lds, int row_lo, int n_rows, int q_lo, int q_hi, int kx_base, int npx) {
+  using C = Cfg<K>;
+  constexpr bool odd = step_targets_odd<K, S>();
+  constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
+  constexpr int QL = floor_div4(dmin), QH = floor_div4(3 + dmax), NWIN = (QH - QL + 1) * 4;
+  const int nq = q_hi - q_lo, items = n_rows * nq;
+  for (int id = threadIdx.x; id < items; id += NT) {
+    const int r = id / nq, t = q_lo + (id - r * nq), rr = row_lo + r;
+    int *base = lds + (rr / C::WYP * 2) * C::PLANE + (rr % C::WYP) * C::WXP;
+    int *own = base + (odd ? C::PLANE : 0) + 4 * t;
+    const int *opp = base + (odd ? 0 : C::PLANE);
+    int Wn[NWIN];
+    const int c0 = 4 * (t + QL);           // window column of Wn[0]
+    const int k0 = kx_base + c0;           // its plane pair index
+    if (k0 >= 0 && k0 + NWIN - 1 <= npx - 1) {
+#pragma unroll
+      for (int q = 0; q < NWIN / 4; ++q) {
+        const I4 a = lds_ld4(opp + c0 + 4 * q);
+        Wn[4 * q] = a.x; Wn[4 * q + 1] = a.y; Wn[4 * q + 2] = a.z; Wn[4 * q + 3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NWIN; ++e) Wn[e] = opp[min(max(k0 + e, 0), npx - 1) - kx_base];
+    }
+    const I4 o = lds_ld4(own);
+    int v[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      auto at = [&](int d) -> int { return Wn[i + d - 4 * QL]; };
+      const int dlt = lift_delta<K, S>(at);
+      if (INV) v[i] -= dlt; else v[i] += dlt;
+    }
+    lds_st4(own, {v[0], v[1], v[2], v[3]});
+  }
+  __syncthreads();
+}
+
+// lifting step S along y on row pairs [r_lo, r_hi), column quads [cq_lo, cq_lo + n_cq) of both column parities
+template <int K, int S, bool INV>
+__device__ __forceinline__ void step_v(int *lds, int r_lo, int r_hi, int cq_lo, int n_cq, int ky_base, int npy) {
+  using C = Cfg<K>;
+  constexpr bool odd = step_targets_odd<K, S>();
+  constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
+  constexpr int NR = 4 + dmax - dmin;
+  const int groups = (r_hi - r_lo + 3) / 4, items = groups * n_cq * 2;
+  for (int id = threadIdx.x; id < items; id += NT) {
+    const int cq = cq_lo + id % n_cq, rest = id / n_cq;
+    const int cp = rest & 1, i0 = r_lo + 4 * (rest >> 1);
+    int *own = lds + ((odd ? 1 : 0) * 2 + cp) * C::PLANE + 4 * cq;
+    const int *opp = lds + ((odd ? 0 : 1) * 2 + cp) * C::PLANE + 4 * cq;
+    I4 Wn[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      const int row = min(max(ky_base + i0 + dmin + e, 0), npy - 1) - ky_base; // clamped tap row (window coordinates)
+      Wn[e] = lds_ld4(opp + row * C::WXP);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i0 + i < r_hi) {
+        auto at = [&](int d) -> I4 { return Wn[i + d - dmin]; };
+        const I4 dlt = lift_delta<K, S>(at);
+        I4 o = lds_ld4(own + (i0 + i) * C::WXP);
+        if (INV) o -= dlt; else o += dlt;
+        lds_st4(own + (i0 + i) * C::WXP, o);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// forward: S0 then S1 (the second step's reach decides how far beyond the core the first must be computed);
+// inverse: S1 then S0
+template <int K, bool INV>
+__device__ __forceinline__ void steps_h(int *lds, int row_lo, int n_rows, int kx_base, int npx) {
+  using C = Cfg<K>;
+  constexpr int NQ = C::WXP / 4, HQ = C::HX / 8; // quads per row, halo quads per side
+  static_assert(WT<K>::nsteps == 2 && HQ >= 2, "step-wise passes: two steps, one quad of reach each");
+  if constexpr (!INV) {
+    step_h<K, 0, false>(lds, row_lo, n_rows, HQ - 1, NQ - HQ + 1, kx_base, npx);
+    step_h<K, 1, false>(lds, row_lo, n_rows, HQ, NQ - HQ, kx_base, npx);
+  } else {
+    step_h<K, 1, true>(lds, row_lo, n_rows, HQ - 1, NQ - HQ + 1, kx_base, npx);
+    step_h<K, 0, true>(lds, row_lo, n_rows, HQ, NQ - HQ, kx_base, npx);
+  }
+}
+template <int K, bool INV>
+__device__ __forceinline__ void steps_v(int *lds, int cq_lo, int n_cq, int ky_base, int npy) {
+  using C = Cfg<K>;
+  constexpr int R0 = C::HY / 2, R1 = C::HY / 2 + TY / 2; // core row pairs
+  constexpr int FIRST = INV ? 1 : 0, SECOND = INV ? 0 : 1;
+  constexpr int lo = R0 + step_dmin<K, SECOND>(), hi = R1 + step_dmax<K, SECOND>();
+  static_assert(lo + step_dmin<K, FIRST>() >= 0 && hi - 1 + step_dmax<K, FIRST>() <= C::WYP - 1, "halo too small");
+  step_v<K, FIRST, INV>(lds, lo, hi, cq_lo, n_cq, ky_base, npy);
+  step_v<K, SECOND, INV>(lds, R0, R1, cq_lo, n_cq, ky_base, npy);
+}
+
 __device__ __forceinline__ int dequant_f(int v, int qf, int off) {
   if (v == 0) return 0;
   const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
@@ -314,8 +422,13 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
     // plane are skipped (the vertical pass replicates across the plane edge itself).
     constexpr int NITH = (2 * C::WYP * 16 + NT - 1) / NT;
     if (!(p.debug_skip & 2)) {
-    h_pass<K, false, NITH>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
-    v_pass<K, false, 1>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+    if constexpr (stepwise<K>()) {
+      steps_h<K, false>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
+      steps_v<K, false>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+    } else {
+      h_pass<K, false, NITH>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
+      v_pass<K, false, 1>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+    }
     }
   }
 
@@ -479,12 +592,18 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
     constexpr int NQ = WXP / 4;
     constexpr int NITV = (NQ * 2 * (TY / 8) + NT - 1) / NT;
     if (!(p.debug_skip & 2)) {
+    if constexpr (stepwise<K>()) {
+      steps_v<K, true>(lds, 0, NQ, ky_base, npy);
+      steps_h<K, true>(lds, HY / 2, TY / 2, kx_base, npx);
+      steps_h<K, true>(lds, WYP + HY / 2, TY / 2, kx_base, npx);
+    } else {
     v_pass<K, true, NITV>(lds, 0, NQ, ky_base, npy);
     // core rows of both parities: stack rows rp*WYP + HY/2 + [0, TY/2); h_pass takes one contiguous
     // range, so run it once per row parity
     constexpr int NITH = ((TY / 2) * 16 + NT - 1) / NT;
     h_pass<K, true, NITH>(lds, HY / 2, TY / 2, kx_base, npx);
     h_pass<K, true, NITH>(lds, WYP + HY / 2, TY / 2, kx_base, npx);
+    }
     }
   }
   if (p.debug_skip & 4) return;
