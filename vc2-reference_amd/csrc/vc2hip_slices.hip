@@ -342,11 +342,6 @@ __device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const 
 }
 __device__ __forceinline__ void put_byte(unsigned *img, int off, unsigned b) { atomicOr(&img[off >> 2], b << (24 - 8 * (off & 3))); }
 
-__device__ __forceinline__ int half_max(int v) { // max within each 32-lane half
-#pragma unroll
-  for (int d = 16; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
-  return v;
-}
 
 // W lanes work on one slice: 64 (a wavefront per slice, any geometry) or, for small slices, 32 / 16 with two / four
 // slices per wavefront, so that a slice of e.g. 128 + 2 x 64 coefficients (1080p, -u 2 -a 4) still fills its lanes.
@@ -721,84 +716,6 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t
 // ------------------------------------------------------------------------------------------
 // HQ unpack: one lane per slice component
 // ------------------------------------------------------------------------------------------
-struct BitReader { // bounded MSB-first reader; past the bound (or the payload) bits read as 1
-  const uint8_t *p;
-  unsigned nbytes, pos;
-  unsigned long long acc;
-  int have;
-  __device__ __forceinline__ void init(const uint8_t *ptr, unsigned n) { p = ptr; nbytes = n; pos = 0; acc = 0; have = 0; }
-  __device__ __forceinline__ void refill() {
-    while (have <= 56) {
-      const unsigned b = pos < nbytes ? p[pos] : 0xFFu;
-      ++pos;
-      acc |= (unsigned long long)b << (56 - have);
-      have += 8;
-    }
-  }
-  __device__ __forceinline__ void skip(int n) { acc = n >= 64 ? 0 : acc << n; have -= n; }
-};
-
-__device__ __forceinline__ unsigned long long compact_odd64(unsigned long long x) {
-  // gather bits at positions 0,2,4,... into the low half
-  x &= 0x5555555555555555ull;
-  x = (x | (x >> 1)) & 0x3333333333333333ull;
-  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-  return x;
-}
-
-// decode n signed exp-Golomb values (VLC.cpp:283-317) from a bounded region into out[0..n)
-__device__ void decode_component(const uint8_t *data, unsigned nbytes, int n, int32_t *out) {
-  BitReader br;
-  br.init(data, nbytes);
-  int j = 0;
-  while (j < n) {
-    br.refill();
-    // run of '1' bits = run of zero coefficients
-    const int ones = __clzll((long long)~br.acc);
-    if (ones > 0) {
-      const int z = min(min(ones, br.have), n - j);
-      for (int k = 0; k < z; ++k) out[j + k] = 0;
-      j += z;
-      br.skip(z);
-      continue;
-    }
-    // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
-    const unsigned long long follow = br.acc & 0xAAAAAAAAAAAAAAAAull;
-    const int K = follow ? __clzll((long long)follow) / 2 : 32;
-    if (2 * K + 2 <= br.have && K <= 27) {
-      const unsigned long long body = br.acc >> (64 - 2 * K); // top 2K bits: (0 b) pairs
-      const unsigned data_bits = (unsigned)compact_odd64(body);
-      const unsigned mag = ((1u << K) | data_bits) - 1u;
-      const int neg = (int)((br.acc >> (62 - 2 * K)) & 1ull);
-      out[j++] = neg ? (int)(0u - mag) : (int)mag;
-      br.skip(2 * K + 2);
-    } else {
-      // very long code (outside the reference's 32-bit domain): bit-serial, wraps like the oracle
-      unsigned value = 1;
-      for (;;) {
-        br.refill();
-        const int f = (int)(br.acc >> 63);
-        br.skip(1);
-        if (f) break;
-        br.refill();
-        value = (value << 1) | (unsigned)(br.acc >> 63);
-        br.skip(1);
-      }
-      value -= 1u;
-      int r = 0;
-      if (value) {
-        br.refill();
-        r = (br.acc >> 63) ? (int)(0u - value) : (int)value;
-        br.skip(1);
-      }
-      out[j++] = r;
-    }
-  }
-}
-
 // Bounded bit reader over 64-bit big-endian words with one word of lookahead: `acc` holds `have`
 // unread bits (top aligned), `nxt` the following 64 bits, so peek() always shows 64 valid bits and
 // a whole token (zero run + one code, <= 48 bits) is consumed with a single refill check.
