@@ -119,6 +119,14 @@ __device__ __forceinline__ long long wave_sum64(long long v) {
   return v;
 }
 
+// LDS written by some lanes of a wavefront and read by others of the SAME wavefront: the hardware executes a
+// wavefront's LDS operations in order, this only keeps the compiler from moving accesses across the hand-over
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // OR a code of nb bits at MSB-first bit position pos of a big-endian-word bit buffer
 __device__ __forceinline__ void put_code(unsigned *buf, int pos, unsigned code, int nb) {
   const int wi = pos >> 5, bo = pos & 31;
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   int *co = lds_i + wave * p.slice_coefs;
   const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
-  // LDS traffic of one wavefront is ordered; no cross-wave sharing of `co`
+  wave_lds_sync(); // no cross-wave sharing of `co`
 
   const int avail = p.slice_bytes[slice] - 4;
   auto need_bytes = [&](int tq, bool &bad) -> int {
@@ -853,9 +861,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     // flush: 4 lanes x 16 bytes per component run.  The staging rows are private to the wavefront, so only
     // its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup barrier,
     // the four wavefronts of the workgroup drift apart freely.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
     const int *sw = stage[wave];
     constexpr int LPR = UNP_N / 4; // lanes per component run
 #pragma unroll
@@ -869,9 +875,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
   }
 }
 
@@ -1251,6 +1255,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   int *co = lds_i + wave * 2 * p.slice_coefs, *qv = co + p.slice_coefs;
   int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
+  wave_lds_sync();
 
   // quantise the whole slice at index tq into qv; true if an adjusted index leaves the table
   auto quantise_at = [&](int tq) -> bool {
@@ -1289,6 +1294,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
         qv[off + j] = quant_dev(co[off + j], aq);
       }
     }
+    wave_lds_sync(); // qv is complete before any lane measures it
     return __any(bad);
   };
   // luma_slice_bits + chroma_slice_bits, Slices.cpp:51-95 (U and V coefficients alternate)
@@ -1318,6 +1324,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   }
   if (!bad) bad = quantise_at(q);
   if (bad) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); return; }
+  wave_lds_sync();
   for (int i = lane; i < p.slice_coefs; i += 64) rec[i] = qv[i];
 }
 
@@ -1330,6 +1337,7 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   const int size = p.slice_bytes[slice];
   unsigned *img = lds_u + wave * p.img_words;
   for (int i = lane; i < p.img_words; i += 64) img[i] = 0;
+  wave_lds_sync();
   const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   auto ly = [&](int j) -> int { return rec[p.comp_off[0] + j]; };
   auto lc = [&](int j) -> int { return rec[p.comp_off[1 + (j & 1)] + (j >> 1)]; };
@@ -1346,6 +1354,7 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   // (VLC.cpp:151-172); flush pads the bound with 0 bits, which the zeroed image already holds
   component_bits<false, true>(ly, p.comp_n[0], 1, 0, nullptr, lane, img, ybits, p.err, 7 + split);
   component_bits<false, true>(lc, 2 * p.comp_n[1], 1, 0, nullptr, lane, img, uvbits, p.err, 7 + split + ybits);
+  wave_lds_sync();
   uint8_t *out = p.payload + (size_t)pic * p.payload_stride + p.offsets[slice];
   for (int k = lane; k < size; k += 64) out[k] = (uint8_t)(img[k >> 2] >> (24 - 8 * (k & 3)));
 }
