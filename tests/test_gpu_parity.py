@@ -593,3 +593,15 @@ def test_pack_lane_widths(hip, oracle, u, a, cf, mode):
     payload, _ = hip.encode_picture_hq(raw, fmt, cp)
     assert stream.endswith(payload + stream[-13:])
     assert hip.decode_picture(payload, fmt, cp) == oracle.decode_stream(p, stream, 1)[0]
+
+
+def test_random_geometries_against_oracle():
+    """tools/fuzz_geometry.py: 80 random combinations of picture size (with padding), chroma format, bit depth, kernel,
+    depth, slice size and mode; every encode payload and decoded picture equals the oracle's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_geometry.py"), "11", "80"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "80 cases, 0 bad" in out.stdout, out.stdout[-2000:]

@@ -978,7 +978,7 @@ extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
-  if ((size_t)g.slice_coefs * 16 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
+  if ((size_t)g.slice_coefs * 4 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
   const int ns = g.ys * g.xs;
   int32_t *d_store, *d_q, *d_sb;
   NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
@@ -1061,7 +1061,7 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
   p.img_words = (max_slice + 3) / 4 + 2;
   p.payload = d_pay; p.payload_stride = stride; p.err = c->d_err;
-  if ((size_t)g.slice_coefs * 32 > 160 * 1024 || (size_t)p.img_words * 16 > 160 * 1024)
+  if ((size_t)g.slice_coefs * 8 > 160 * 1024 || (size_t)p.img_words * 4 > 160 * 1024)
     return set_err(c, VC2HIP_EINVAL, "slice too large for the LD encode kernels");
   return VC2HIP_OK;
 }
@@ -1226,7 +1226,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     return VC2HIP_OK;
   }
   if (cp->mode == VC2HIP_HQ_CBR) {
-    if ((size_t)g.slice_coefs * 16 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
+    if ((size_t)g.slice_coefs * 4 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
     const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
     if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
       std::vector<int32_t> sb(ns);

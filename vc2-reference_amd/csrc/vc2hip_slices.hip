@@ -14,6 +14,8 @@
 // coding order, so reads and writes here are plain streams.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "vc2hip_internal.h"
 
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
@@ -651,7 +653,7 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
 __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   extern __shared__ int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  const int slice = blockIdx.x * (blockDim.x >> 6) + wave, pic = blockIdx.y; // 1..4 wavefronts per workgroup
   if (slice >= p.n_slices) return; // no workgroup barriers below
   int *co = lds_i + wave * p.slice_coefs;
   const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
@@ -713,11 +715,19 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
 }
 
+// wavefronts per workgroup so that their LDS (per_wave bytes each) fits: 4 down to 1; 0 if even one does not
+int vc2_waves_for_lds(size_t per_wave);
+int vc2_waves_for_lds(size_t per_wave) {
+  if (per_wave == 0) return 4;
+  const size_t w = (size_t)(160 * 1024) / per_wave;
+  return (int)std::min<size_t>(4, w);
+}
 void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
+  const size_t per_wave = (size_t)p.slice_coefs * 4;
+  const int wpw = vc2_waves_for_lds(per_wave);
   vc2_allow_lds((const void *)k_cbr_search, 160 * 1024);
   vc2_prof_begin(L, "cbr_search", s);
-  hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256),
-                     (size_t)4 * p.slice_coefs * 4, s, p);
+  hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p);
   vc2_prof_end(L, s);
 }
 
@@ -1249,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   extern __shared__ int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y;
-  const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x * 4 + wave;
+  const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
   if (sv > min(p.ys - 1, d)) return; // no workgroup barriers below
   const int sh = d - sv, slice = sv * p.xs + sh;
   int *co = lds_i + wave * 2 * p.slice_coefs, *qv = co + p.slice_coefs;
@@ -1332,7 +1342,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
 __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   extern __shared__ unsigned lds_u[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  const int slice = blockIdx.x * (blockDim.x >> 6) + wave, pic = blockIdx.y;
   if (slice >= p.n_slices) return;
   const int size = p.slice_bytes[slice];
   unsigned *img = lds_u + wave * p.img_words;
@@ -1360,18 +1370,22 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
 }
 
 void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
+  const size_t per_wave = (size_t)2 * p.slice_coefs * 4;
+  const int wpw = vc2_waves_for_lds(per_wave);
   vc2_allow_lds((const void *)k_ld_quantise_diag, 160 * 1024);
   vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
   for (int d = 0; d < p.ys + p.xs - 1; ++d) {
     const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
-    hipLaunchKernelGGL(k_ld_quantise_diag, dim3((cnt + 3) / 4, n_pictures), dim3(256), (size_t)4 * 2 * p.slice_coefs * 4, s, p, d);
+    hipLaunchKernelGGL(k_ld_quantise_diag, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
   }
   vc2_prof_end(L, s);
 }
 void vc2_launch_ld_pack(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
+  const size_t per_wave = (size_t)p.img_words * 4;
+  const int wpw = vc2_waves_for_lds(per_wave);
   vc2_allow_lds((const void *)k_ld_pack, 160 * 1024);
   vc2_prof_begin(L, "ld_pack", s);
-  hipLaunchKernelGGL(k_ld_pack, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), (size_t)4 * p.img_words * 4, s, p);
+  hipLaunchKernelGGL(k_ld_pack, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p);
   vc2_prof_end(L, s);
 }
 
