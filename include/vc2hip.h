@@ -182,6 +182,8 @@ int vc2hip_decode_picture_ld(vc2hip_ctx *ctx, const uint8_t *payload, size_t len
  *   d_raw       n * vc2hip_raw_picture_bytes() bytes of raw planar pictures (device memory)
  *   d_payload   n slots of payload_stride bytes each (device memory)
  *   d_lens      n uint64 payload lengths (device memory; written by encode, read by decode)
+ * d_raw, d_payload and payload_stride must be multiples of 16 bytes (VC2HIP_EINVAL otherwise); when a
+ * picture's raw size is not a multiple of 16 the pictures of a batch are still packed back to back.
  * Nothing is allocated or synchronised inside these calls once the ctx has seen the geometry
  * (first call sizes the workspace). */
 /* Cut every device-resident batch into k contiguous sub-batches, each on its own HIP stream and workspace,

@@ -1170,6 +1170,8 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
                                        const vc2hip_coding_params *cp, void *d_payload, size_t payload_stride,
                                        uint64_t *d_lens) {
   if (!c || !d_raw || n < 1 || !f || !cp || !d_payload || !d_lens) return set_err(c, VC2HIP_EINVAL);
+  if (((size_t)d_raw | (size_t)d_payload | payload_stride) & 15 || ((size_t)d_lens & 7))
+    return set_err(c, VC2HIP_EINVAL, "device buffers and the payload stride must be 16-byte aligned");
   if (c->lanes.size() > 1 && n > 1 && !c->in_split) {
     const size_t rb = vc2hip_raw_picture_bytes(f);
     const uint8_t *raw8 = (const uint8_t *)d_raw, *pay8 = (const uint8_t *)d_payload, *len8 = (const uint8_t *)d_lens;
@@ -1257,6 +1259,8 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
 static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens, int n,
                                const vc2hip_picture_format *f, const vc2hip_coding_params *cp, void *d_raw_out, bool ld) {
   if (!c || !d_payload || n < 1 || !f || !cp || !d_raw_out) return set_err(c, VC2HIP_EINVAL);
+  if (((size_t)d_raw_out | (size_t)d_payload | payload_stride) & 15 || ((size_t)d_lens & 7))
+    return set_err(c, VC2HIP_EINVAL, "device buffers and the payload stride must be 16-byte aligned");
   if (cp->kernel < 0 || cp->kernel > 6) return set_err(c, VC2HIP_EINVAL, "invalid wavelet kernel");
   ENTER(c);
   Geom g;
@@ -1337,7 +1341,7 @@ extern "C" int vc2hip_encode_picture_hq(vc2hip_ctx *c, const void *raw, const vc
                                         int32_t *qidx_out) {
   if (!c || !raw || !f || !cp || !payload || !len) return set_err(c, VC2HIP_EINVAL);
   ENTER(c);
-  const size_t rb = vc2hip_raw_picture_bytes(f), pcap = vc2hip_max_payload_bytes(f, cp);
+  const size_t rb = vc2hip_raw_picture_bytes(f), pcap = (vc2hip_max_payload_bytes(f, cp) + 15) & ~(size_t)15;
   uint8_t *d_raw, *d_pay; unsigned long long *d_len;
   NEED(c, B_RAW, rb + 64, d_raw);
   NEED(c, B_PAYLOAD, pcap + 64, d_pay);
