@@ -978,7 +978,7 @@ extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
-  if ((size_t)g.slice_coefs * 4 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
+  if ((size_t)g.slice_coefs * 4 + 2048 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
   const int ns = g.ys * g.xs;
   int32_t *d_store, *d_q, *d_sb;
   NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
@@ -995,6 +995,7 @@ extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_
   fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
   p.scalar = scalar; p.err = c->d_err;
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm[b];
+  p.n_bands = 3 * g.depth + 1;
   vc2_launch_cbr(c->L, p, 1, c->stream);
   HIPCHK(c, hipMemcpyAsync(qidx, d_q, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
   return vc2hip_sync(c);
@@ -1228,7 +1229,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     return VC2HIP_OK;
   }
   if (cp->mode == VC2HIP_HQ_CBR) {
-    if ((size_t)g.slice_coefs * 4 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
+    if ((size_t)g.slice_coefs * 4 + 2048 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
     const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
     if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
       std::vector<int32_t> sb(ns);
@@ -1246,6 +1247,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
     p.scalar = cp->scalar; p.err = c->d_err;
     for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm[b];
+    p.n_bands = 3 * g.depth + 1;
     vc2_launch_cbr(c->L, p, n, c->stream);
   } else {
     if (payload_stride < vc2hip_max_payload_bytes(f, cp)) return set_err(c, VC2HIP_ECAP);

@@ -154,6 +154,7 @@ struct CbrParams {
   int n_slices, slice_coefs;
   int comp_n[3], comp_off[3], comp_n0[3];
   int scalar;
+  int n_bands;
   int qmatrix[VC2_MAX_BANDS];
   unsigned *err;
 };

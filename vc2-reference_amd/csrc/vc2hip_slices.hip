@@ -185,6 +185,45 @@ __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, con
   return count;
 }
 
+// component_bits<true, false> for coefficients staged in LDS: a lane's eight consecutive coefficients are read
+// as two 16-byte words (eight scalar reads at a 32-byte lane stride would hit every bank eight times over)
+__device__ __forceinline__ int component_bits_lds(const int *src, int n, int n0, int q, const int *qm, int lane, unsigned *err) {
+  int base = 0, count = 0;
+  const int n0_shift = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
+  const bool aligned = (((size_t)src) & 15) == 0;
+  for (int r0 = 0; r0 < n; r0 += 512) {
+    const int j0 = r0 + lane * 8;
+    int v[8];
+    if (aligned && j0 + 8 <= n) {
+      const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = j0 + k < n ? src[j0 + k] : 0;
+    }
+    int sum = 0, last_end = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int j = j0 + k;
+      int nb = 0;
+      if (j < n) {
+        const int aq = max(q - qm[band_of_index_fast(j, n0, n0_shift)], 0);
+        int c = 0;
+        if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
+        else c = quant_dev(v[k], aq);
+        nb = svlc_bits(c);
+        if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); c = 0; nb = 1; }
+        sum += nb;
+        if (c != 0) last_end = sum;
+      }
+    }
+    const int incl = wave_incl_scan(sum, lane);
+    count = max(count, wave_max(last_end ? base + incl - sum + last_end : 0));
+    base += __shfl(incl, 63);
+  }
+  return count;
+}
+
 // ------------------------------------------------------------------------------------------
 // HQ pack: one wavefront per slice.  The slice's byte image (prefix, qindex, then per component
 // a length byte + bounded exp-Golomb data, Slices.cpp:469-533 / :305-382) is assembled in LDS as
@@ -651,9 +690,23 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
 // HQ_CBR quantiser search: one wavefront per slice, slice coefficients staged in LDS
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
-  extern __shared__ int lds_i[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x * (blockDim.x >> 6) + wave, pic = blockIdx.y; // 1..4 wavefronts per workgroup
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6; // 1..4 wavefronts per workgroup
+  const int slice = blockIdx.x * wpw + wave, pic = blockIdx.y;
+  // Common geometry (component <= 512 / 256 coefficients): the subband of every coefficient index comes from a byte
+  // table, the quantiser constants of every subband at the trial index from a per-wavefront table, both in LDS --
+  // indexing the kernel-argument matrix and the constant-memory factor tables per lane costs several dependent
+  // memory operations per coefficient.
+  const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32;
+  unsigned char *band_y = (unsigned char *)(lds_i + wpw * p.slice_coefs), *band_c = band_y + 512;
+  uint4 *qtab = (uint4 *)(band_c + 256) + wave * 32;
+  if (fast) {
+    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
+    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
+    for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
+    for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+  }
+  __syncthreads();
   if (slice >= p.n_slices) return; // no workgroup barriers below
   int *co = lds_i + wave * p.slice_coefs;
   const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
@@ -661,23 +714,94 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   wave_lds_sync(); // no cross-wave sharing of `co`
 
   const int avail = p.slice_bytes[slice] - 4;
+  // (magic, shift, factor, offset) of every subband at index tq; false if an adjusted index leaves the table
+  auto set_q = [&](int tq) -> bool {
+    bool ok = true;
+    wave_lds_sync(); // the previous trial's readers are done
+    if (lane < p.n_bands) {
+      const int aq = max(tq - p.qmatrix[lane], 0);
+      ok = aq <= 119;
+      const int a = min(aq, 119);
+      qtab[lane] = make_uint4(c_qs.magic[a], (unsigned)c_qs.shift[a], (unsigned)c_qs.qf[a], (unsigned)c_qs.off[a]);
+    }
+    wave_lds_sync();
+    return !__any(!ok);
+  };
+  // bits of eight coefficients of one component, quantised through the tables: total and end of the last non-zero code
+  auto bits8 = [&](const int *src, int j0, int n, const unsigned char *band_lut, int &sum, int &last_end) {
+    sum = 0; last_end = 0;
+    if (j0 + 8 <= n) {
+      const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
+      const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const uint2 bands = *(const uint2 *)(band_lut + j0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint4 t = qtab[((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu];
+        const int c = quant_core(v[k], (int)t.z, t.x, (int)t.y);
+        int nb = svlc_bits(c);
+        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; }
+        sum += nb;
+        if (c != 0) last_end = sum;
+      }
+    } else {
+      for (int k = 0; k < 8 && j0 + k < n; ++k) {
+        const uint4 t = qtab[band_lut[j0 + k]];
+        const int c = quant_core(src[j0 + k], (int)t.z, t.x, (int)t.y);
+        int nb = svlc_bits(c);
+        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; }
+        sum += nb;
+        if (c != 0) last_end = sum;
+      }
+    }
+  };
+  auto comp_bytes = [&](int count, bool &bad) -> int {
+    const int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
+    if (len > 255) { bad = true; if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); }
+    return len * p.scalar;
+  };
   auto need_bytes = [&](int tq, bool &bad) -> int {
     int need = 0;
-    for (int c = 0; c < 3; ++c) {
-      const int *src = co + p.comp_off[c];
-      auto ld = [&](int j) -> int { return src[j]; };
-      const int count = component_bits<true, false>(ld, p.comp_n[c], p.comp_n0[c], tq, p.qmatrix, lane,
-                                                    nullptr, 0, p.err);
-      const int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
-      if (len > 255) { bad = true; if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); }
-      need += len * p.scalar;
+    if (fast) {
+      if (!set_q(tq)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); }
+      int sum, last_end;
+      bits8(co + p.comp_off[0], lane * 8, p.comp_n[0], band_y, sum, last_end); // luma: one round
+      int incl = wave_incl_scan(sum, lane);
+      need += comp_bytes(wave_max(last_end ? incl - sum + last_end : 0), bad);
+      const int half = lane >> 5;                                               // lanes 0-31 U, lanes 32-63 V
+      bits8(co + p.comp_off[1 + half], (lane & 31) * 8, p.comp_n[1], band_c, sum, last_end);
+      incl = wave_incl_scan(sum, lane);
+      const int total_u = __shfl(incl, 31); // every lane takes part in the shuffle
+      const int rel = incl - sum - (half ? total_u : 0);
+      const int cnt = seg_max<32>(last_end ? rel + last_end : 0);
+      need += comp_bytes(__shfl(cnt, 0), bad) + comp_bytes(__shfl(cnt, 32), bad);
+      return need;
     }
+    for (int c = 0; c < 3; ++c)
+      need += comp_bytes(component_bits_lds(co + p.comp_off[c], p.comp_n[c], p.comp_n0[c], tq, p.qmatrix, lane, p.err), bad);
     return need;
   };
   // luma-only sum of squared reconstruction error (int product, 64-bit sum)
   auto yss = [&](int tq, bool &bad) -> long long {
     long long acc = 0;
     const int *src = co + p.comp_off[0];
+    if (fast) {
+      if (!set_q(tq)) bad = true;
+      for (int j = lane; j < p.comp_n[0]; j += 64) {
+        const uint4 t = qtab[band_y[j]];
+        const int v = src[j];
+        const int qv = quant_core(v, (int)t.z, t.x, (int)t.y);
+        // scale(), Quantisation.cpp:86-95, with the table's factor and offset
+        const unsigned mag = qv < 0 ? 0u - (unsigned)qv : (unsigned)qv;
+        int r = (int)(mag * t.z);
+        if (r > 0) r = (int)((unsigned)r + t.w);
+        r = (int)((unsigned)r + 2u);
+        r /= 4;
+        if (qv < 0) r = (int)(0u - (unsigned)r);
+        const int d = (int)((unsigned)v - (unsigned)r);
+        acc += (int)((unsigned)d * (unsigned)d);
+      }
+      return wave_sum64(acc);
+    }
     for (int j = lane; j < p.comp_n[0]; j += 64) {
       const int aq = max(tq - p.qmatrix[band_of_index(j, p.comp_n0[0])], 0);
       if (aq > 119) { bad = true; continue; }
@@ -692,8 +816,8 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   int trial = 63, q = 127, delta = 64;
   while (delta > 0) {
     delta >>= 1;
-    if (trial - 0 > 119 + 64) { bad = true; break; }
     const int need = need_bytes(trial, bad);
+    bad = __any(bad);
     if (bad) break;
     if (need <= avail) { if (trial < q) q = trial; trial -= delta; }
     else trial += delta;
@@ -723,11 +847,11 @@ int vc2_waves_for_lds(size_t per_wave) {
   return (int)std::min<size_t>(4, w);
 }
 void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
-  const size_t per_wave = (size_t)p.slice_coefs * 4;
-  const int wpw = vc2_waves_for_lds(per_wave);
+  const size_t per_wave = (size_t)p.slice_coefs * 4 + 32 * 16, tables = 768; // + the wavefront's quantiser table; + band tables
+  const int wpw = std::max(1, std::min(4, (int)((160 * 1024 - tables) / per_wave)));
   vc2_allow_lds((const void *)k_cbr_search, 160 * 1024);
   vc2_prof_begin(L, "cbr_search", s);
-  hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p);
+  hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
   vc2_prof_end(L, s);
 }
 
