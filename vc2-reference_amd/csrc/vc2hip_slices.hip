@@ -264,8 +264,8 @@ __device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, u
 
 // load (and quantise) the 8 coefficients [j0, j0+8) of a component record
 template <bool QUANT>
-__device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int n, int n0, int n0_shift, int q,
-                                      const int *qm, unsigned *err, const unsigned *lut) {
+__device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int n, int n0, int n0_shift, const uint4 *qtab,
+                                      unsigned *err, const unsigned *lut) {
   c.sum = 0;
   c.last_end = 0;
   int raw[8];
@@ -277,27 +277,18 @@ __device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int 
 #pragma unroll
     for (int k = 0; k < 8; ++k) raw[k] = j0 + k < n ? src[j0 + k] : 0;
   }
-  if (QUANT) {
+  if (QUANT) { // quantiser constants of the slice's index per subband: qtab (LDS), see k_hq_pack
     const int b0 = band_of_index_fast(min(j0, n - 1), n0, n0_shift), b7 = band_of_index_fast(min(j0 + 7, n - 1), n0, n0_shift);
     if (b0 == b7) { // the usual case: all eight coefficients in one subband
-      const int aq = max(q - qm[b0], 0);
-      if (aq > 119) {
-        atomicOr(err, VC2_DEVERR_QINDEX);
+      const uint4 t = qtab[b0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) raw[k] = 0;
-      } else {
-        const int qf = c_qs.qf[aq], sh = c_qs.shift[aq];
-        const unsigned mg = c_qs.magic[aq];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) raw[k] = quant_core(raw[k], qf, mg, sh);
-      }
+      for (int k = 0; k < 8; ++k) raw[k] = quant_core(raw[k], (int)t.z, t.x, (int)t.y);
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (j0 + k >= n) continue;
-        const int aq = max(q - qm[band_of_index_fast(j0 + k, n0, n0_shift)], 0);
-        if (aq > 119) { atomicOr(err, VC2_DEVERR_QINDEX); raw[k] = 0; }
-        else raw[k] = quant_dev(raw[k], aq);
+        const uint4 t = qtab[band_of_index_fast(j0 + k, n0, n0_shift)];
+        raw[k] = quant_core(raw[k], (int)t.z, t.x, (int)t.y);
       }
     }
   }
@@ -424,6 +415,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
     for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
     for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+  }
+  if (p.quantise) {
     if (active && sl < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
       const int aq = max(p.qidx[(size_t)pic * p.n_slices + slice] - p.qmatrix[sl], 0);
       if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[sl] = make_uint4(0u, 0u, 0x40000000u, 0u); }
@@ -458,7 +451,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int n = p.comp_n[0], n0 = p.comp_n0[0];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
         if (p.quantise) load8_tab(c, rec + p.comp_off[0], sl * 8, n, band_y, qtab, p.err, lut);
-        else load8<false>(c, rec + p.comp_off[0], sl * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[0], sl * 8, n, n0, n0s, qtab, p.err, lut);
         const int incl = seg_incl_scan<W>(c.sum, sl);
         const int count = seg_max<W>(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
@@ -471,7 +464,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
         const int half = sl >= W / 2 ? 1 : 0, cc = 1 + half;
         if (p.quantise) load8_tab(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, band_c, qtab, p.err, lut);
-        else load8<false>(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, n0, n0s, qtab, p.err, lut);
         const int incl = seg_incl_scan<W>(c.sum, sl);
         const int total_u = __shfl(incl, seg * W + W / 2 - 1);
         const int rel = incl - c.sum - (half ? total_u : 0);
@@ -491,8 +484,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         Coef8 c;
         int run = 0, count = 0;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
-          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           count = max(count, wave_max(c.last_end ? run + incl - c.sum + c.last_end : 0));
           run += __shfl(incl, 63);
@@ -501,8 +494,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         if (cc == 2) bytes[2] = cbr_v(bytes[2]);
         run = 0;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
-          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, q, p.qmatrix, p.err, lut);
+          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           write8(img, 8 * (base + 1) + run + incl - c.sum, 8 * (base + 1 + bytes[cc]), c);
           run += __shfl(incl, 63);
