@@ -1058,11 +1058,14 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
     p.bh[k] = (g.c[k].ph >> g.depth) / g.ys; p.bw[k] = (g.c[k].pw >> g.depth) / g.xs;
   }
   p.ys = g.ys; p.xs = g.xs; p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  p.depth = g.depth;
+  p.rs_ints = 0;
+  for (int k = 0; k < 3; ++k) if (g.c[k].ph) p.rs_ints += (p.bh[k] + 1) * (p.bw[k] + 1);
   fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
   p.img_words = (max_slice + 3) / 4 + 2;
   p.payload = d_pay; p.payload_stride = stride; p.err = c->d_err;
-  if ((size_t)g.slice_coefs * 8 > 160 * 1024 || (size_t)p.img_words * 4 > 160 * 1024)
+  if ((size_t)g.slice_coefs * 8 + 512 + (size_t)p.rs_ints * 4 > 160 * 1024 || (size_t)p.img_words * 4 > 160 * 1024)
     return set_err(c, VC2HIP_EINVAL, "slice too large for the LD encode kernels");
   return VC2HIP_OK;
 }

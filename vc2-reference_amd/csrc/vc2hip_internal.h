@@ -232,6 +232,8 @@ struct LdEncParams {
   int bh[3], bw[3];           // LL block of one slice
   int ys, xs, n_slices, slice_coefs;
   int comp_n[3], comp_off[3], comp_n0[3];
+  int depth;
+  int rs_ints;                // LDS ints per wavefront for the LL blocks with their halo: sum of (bh + 1) * (bw + 1)
   int qmatrix[VC2_MAX_BANDS];
   int search;
   int img_words;              // LDS words of one slice image (pack)

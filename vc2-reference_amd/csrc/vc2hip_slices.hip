@@ -1373,7 +1373,7 @@ void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride,
 // coefficients -- LL band as prediction residuals -- in the coefficient store, in coding order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, int d) {
-  extern __shared__ int lds_i[];
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y;
   const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
@@ -1385,30 +1385,60 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   wave_lds_sync();
 
   // quantise the whole slice at index tq into qv; true if an adjusted index leaves the table
+  const int wpw = blockDim.x >> 6;
+  uint4 *qtab = (uint4 *)(lds_i + wpw * 2 * p.slice_coefs) + wave * 32; // per subband: magic, shift, factor
+  const int n_bands = 3 * p.depth + 1;
+  // reconstructed LL samples of the slice's blocks with one row above and one column to the left (the neighbours'
+  // final values, loaded once): the trials then run without touching memory
+  int *rs = lds_i + wpw * (2 * p.slice_coefs + 32 * 4) + wave * p.rs_ints;
+  {
+    int *r0 = rs;
+    for (int c = 0; c < 3; ++c) {
+      if (!p.comp_n[c]) continue;
+      const int32_t *res = p.restored[c] + (size_t)pic * p.restored_stride[c];
+      const int llw = p.ll_w[c], bh = p.bh[c], bw = p.bw[c], pitch = bw + 1;
+      for (int i = lane; i < bh + bw + 1; i += 64) {
+        const int yy = i <= bw ? 0 : i - bw, xx = i <= bw ? i : 0; // row 0: bw + 1 samples, then column 0
+        const int y = sv * bh - 1 + yy, x = sh * bw - 1 + xx;
+        r0[yy * pitch + xx] = (y >= 0 && x >= 0) ? res[(size_t)y * llw + x] : 0;
+      }
+      r0 += (bh + 1) * pitch;
+    }
+  }
   auto quantise_at = [&](int tq) -> bool {
     bool bad = false;
-    if (lane == 0) { // LL blocks: serial raster scan, prediction from the reconstructed plane
+    wave_lds_sync();
+    if (lane < n_bands) {
+      const int aq = max(tq - p.qmatrix[lane], 0);
+      if (aq > 119) bad = true;
+      const int a = min(aq, 119);
+      qtab[lane] = make_uint4(c_qs.magic[a], (unsigned)c_qs.shift[a], (unsigned)c_qs.qf[a], 0u);
+    }
+    wave_lds_sync();
+    if (lane == 0) { // LL blocks: serial raster scan, prediction from the reconstructed samples (rs: block + halo, LDS)
       const int aq = max(tq - p.qmatrix[0], 0);
       if (aq > 119) bad = true;
+      int *r0 = rs;
       for (int c = 0; c < 3 && !bad; ++c) {
         if (!p.comp_n[c]) continue;
-        int32_t *res = p.restored[c] + (size_t)pic * p.restored_stride[c];
-        const int llw = p.ll_w[c], bh = p.bh[c], bw = p.bw[c];
+        const int bh = p.bh[c], bw = p.bw[c], pitch = bw + 1;
         for (int yy = 0; yy < bh; ++yy)
           for (int xx = 0; xx < bw; ++xx) {
             const int y = sv * bh + yy, x = sh * bw + xx;
+            const int *up = r0 + yy * pitch + xx; // up-left; up + 1: above; up + pitch: left
             int pred; // predictDC, Quantisation.cpp:191-208
             if (y > 0 && x > 0) {
-              const int r = res[(size_t)(y - 1) * llw + x - 1] + res[(size_t)(y - 1) * llw + x] + res[(size_t)y * llw + x - 1];
+              const int r = up[0] + up[1] + up[pitch];
               pred = r >= 0 ? (r + 1) / 3 : (r - 1) / 3;
-            } else if (y > 0) pred = res[(size_t)(y - 1) * llw + x];
-            else if (x > 0) pred = res[(size_t)y * llw + x - 1];
+            } else if (y > 0) pred = up[1];
+            else if (x > 0) pred = up[pitch];
             else pred = 0;
             const int v = co[p.comp_off[c] + yy * bw + xx];
             const int qq = quant_dev((int)((unsigned)v - (unsigned)pred), aq);
-            res[(size_t)y * llw + x] = (int)((unsigned)scale_dev(qq, aq) + (unsigned)pred);
+            r0[(yy + 1) * pitch + xx + 1] = (int)((unsigned)scale_dev(qq, aq) + (unsigned)pred);
             qv[p.comp_off[c] + yy * bw + xx] = qq;
           }
+        r0 += (bh + 1) * pitch;
       }
     }
     for (int c = 0; c < 3; ++c) {
@@ -1416,9 +1446,8 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
       if (!n) continue;
       const int n0_shift = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
       for (int j = n0 + lane; j < n; j += 64) {
-        const int aq = max(tq - p.qmatrix[band_of_index_fast(j, n0, n0_shift)], 0);
-        if (aq > 119) { bad = true; continue; }
-        qv[off + j] = quant_dev(co[off + j], aq);
+        const uint4 t = qtab[band_of_index_fast(j, n0, n0_shift)];
+        qv[off + j] = quant_core(co[off + j], (int)t.z, t.x, (int)t.y);
       }
     }
     wave_lds_sync(); // qv is complete before any lane measures it
@@ -1453,6 +1482,19 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   if (bad) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); return; }
   wave_lds_sync();
   for (int i = lane; i < p.slice_coefs; i += 64) rec[i] = qv[i];
+  { // the slice's reconstructed LL samples become the neighbours' halo
+    const int *r0 = rs;
+    for (int c = 0; c < 3; ++c) {
+      if (!p.comp_n[c]) continue;
+      int32_t *res = p.restored[c] + (size_t)pic * p.restored_stride[c];
+      const int llw = p.ll_w[c], bh = p.bh[c], bw = p.bw[c], pitch = bw + 1;
+      for (int i = lane; i < bh * bw; i += 64) {
+        const int yy = i / bw, xx = i - yy * bw;
+        res[(size_t)(sv * bh + yy) * llw + sh * bw + xx] = r0[(yy + 1) * pitch + xx + 1];
+      }
+      r0 += (bh + 1) * pitch;
+    }
+  }
 }
 
 // LD slice writer: one wavefront per slice, image assembled in LDS as big-endian words
@@ -1487,7 +1529,7 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
 }
 
 void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
-  const size_t per_wave = (size_t)2 * p.slice_coefs * 4;
+  const size_t per_wave = (size_t)2 * p.slice_coefs * 4 + 32 * 16 + (size_t)p.rs_ints * 4; // coefficients, quantised copy, subband table, LL blocks + halo
   const int wpw = vc2_waves_for_lds(per_wave);
   vc2_allow_lds((const void *)k_ld_quantise_diag, 160 * 1024);
   vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
