@@ -341,12 +341,45 @@ __device__ __forceinline__ void load8_tab(Coef8 &c, const int32_t *src, int j0, 
     const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
     raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w;
     const uint2 bands = *(const uint2 *)(band_lut + j0);
+    // quant(), Quantisation.cpp:69-76, eight at a time: the reciprocal multiply for all, then ONE test whether any of
+    // them left its domain (factor <= 1 or |v| << 2 overflowed: sign bit of `a | (factor - 2)`, the table's 4th word)
+    unsigned mag4[8], qf2[8], dom = 0;
+    int qq[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const unsigned b = ((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu;
       const uint4 t = qtab[b];
-      raw[k] = quant_core(raw[k], (int)t.z, t.x, (int)t.y);
+      const int v = raw[k];
+      const unsigned a = (v < 0 ? 0u - (unsigned)v : (unsigned)v) << 2;
+      const unsigned m = __umulhi(t.x, a);
+      qq[k] = (int)((m + ((a - m) >> 1)) >> t.y);
+      mag4[k] = a; qf2[k] = t.w;
+      dom |= a | t.w;
     }
+    if (__any((int)dom < 0)) { // rare: the literal int division for the coefficients concerned
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((int)(mag4[k] | qf2[k]) < 0) qq[k] = (int)mag4[k] / (int)(qf2[k] + 2u);
+    }
+    // codes straight from magnitude and sign (the table holds the code of +m; a negative value sets its last bit)
+    unsigned all = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned m = (unsigned)qq[k], e = lut[m & (VLC_LUT_N - 1)];
+      c.code[k] = (e >> 6) | ((unsigned)raw[k] >> 31);
+      c.nb[k] = (int)(e & 63u);
+      all |= m;
+    }
+    if (!__any(all >= (unsigned)VLC_LUT_N)) { // every magnitude inside the table (and no negative quotient)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c.sum += c.nb[k];
+        if (qq[k] != 0) c.last_end = c.sum;
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = raw[k] < 0 ? (int)(0u - (unsigned)qq[k]) : qq[k];
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -419,8 +452,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   if (p.quantise) {
     if (active && sl < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
       const int aq = max(p.qidx[(size_t)pic * p.n_slices + slice] - p.qmatrix[sl], 0);
-      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[sl] = make_uint4(0u, 0u, 0x40000000u, 0u); }
-      else qtab[sl] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], 0u);
+      // (magic, shift, factor, factor - 2): the 4th word's sign bit marks a factor outside the multiply's domain
+      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[sl] = make_uint4(0u, 0u, 0x40000000u, 0x3FFFFFFEu); }
+      else qtab[sl] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], (unsigned)c_qs.qf[aq] - 2u);
     }
   }
   __syncthreads();
