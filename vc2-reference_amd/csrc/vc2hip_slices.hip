@@ -88,33 +88,43 @@ __device__ __forceinline__ unsigned svlc_code(int v) {
   return (u << 1) | (v < 0 ? 1u : 0u);
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
+// Scans and reductions over the lanes of a wavefront (or of its segments of W consecutive lanes) with DPP adds:
+// row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into
+// rows 2 and 3 -- one VALU instruction per step instead of a ds_bpermute round trip.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp0(int v) { // lanes without a source read 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive sum over segments of W = 16, 32 or 64 lanes
+template <int W> __device__ __forceinline__ int seg_incl_scan(int v, int /*sl*/) {
+  static_assert(W == 16 || W == 32 || W == 64, "segments are whole DPP rows");
+  v += dpp0<0x111, 0xf>(v);
+  v += dpp0<0x112, 0xf>(v);
+  v += dpp0<0x114, 0xf>(v);
+  v += dpp0<0x118, 0xf>(v);
+  if constexpr (W >= 32) v += dpp0<0x142, 0xa>(v);
+  if constexpr (W >= 64) v += dpp0<0x143, 0xc>(v);
   return v;
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
-  return v;
-}
-// the same inside segments of W consecutive lanes (sl = lane index inside the segment)
-template <int W> __device__ __forceinline__ int seg_incl_scan(int v, int sl) {
-#pragma unroll
-  for (int d = 1; d < W; d <<= 1) {
-    const int t = __shfl_up(v, d, W);
-    if (sl >= d) v += t;
-  }
-  return v;
-}
+// maximum of NON-NEGATIVE values over each segment of W lanes, in every lane of the segment
 template <int W> __device__ __forceinline__ int seg_max(int v) {
+  if constexpr (W < 16) { // half of a 16-lane segment: butterfly
 #pragma unroll
-  for (int d = W / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, W));
-  return v;
+    for (int d = W / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, W));
+    return v;
+  } else {
+    v = max(v, dpp0<0x111, 0xf>(v));
+    v = max(v, dpp0<0x112, 0xf>(v));
+    v = max(v, dpp0<0x114, 0xf>(v));
+    v = max(v, dpp0<0x118, 0xf>(v));
+    if constexpr (W >= 32) v = max(v, dpp0<0x142, 0xa>(v));
+    if constexpr (W >= 64) v = max(v, dpp0<0x143, 0xc>(v));
+    // the last lane of the segment holds the maximum
+    if constexpr (W == 64) return __builtin_amdgcn_readlane(v, 63);
+    else return __shfl(v, (int)(__lane_id() | (W - 1)));
+  }
 }
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) { return seg_incl_scan<64>(v, lane); }
+__device__ __forceinline__ int wave_max(int v) { return seg_max<64>(v); }
 __device__ __forceinline__ long long wave_sum64(long long v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
