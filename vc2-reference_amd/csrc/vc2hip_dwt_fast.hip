@@ -483,7 +483,10 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
 // ------------------------------------------------------------------------------------------
 // inverse level
 // ------------------------------------------------------------------------------------------
-template <int K, bool FINAL>
+// SMALL: the band blocks of a slice are narrower than four coefficients (deep levels), so the gather is element by
+// element; those loads (value and slice index each) are then issued in the first phase as well, not one dependent
+// pair after the other in the conversion phase.  A separate instantiation because it costs registers.
+template <int K, bool FINAL, bool SMALL>
 __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   using C = Cfg<K>;
   extern __shared__ __attribute__((aligned(16))) int lds[];
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   {
     constexpr int NQI = (WYP * (WXP / 4) + NT - 1) / NT;
     int4 val[4][NQI];
+    int4 q4[SMALL ? 4 : 1][SMALL ? NQI : 1]; // SMALL: the slice index of each of the four elements
     int qv[4][NQI], kind[4][NQI]; // kind: 0 skip, 1 vector loaded, 2 element-wise path
     const int32_t *llp = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
 #pragma unroll
@@ -532,6 +536,24 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
         const bool inside = vec && bx0 >= 0 && bx0 + 4 <= npx;
         kind[band][it] = inside ? 1 : 2;
+        if constexpr (SMALL) {
+          if (!inside) { // four clamped element loads (+ their slices' indices), all in flight together
+            int e[4], qq[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int bx = min(max(bx0 + k, 0), npx - 1);
+              if (from_plane) e[k] = llp[(size_t)by * npx + bx];
+              else {
+                const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx >> lbsw, c = bx & (bsw - 1);
+                e[k] = store[(size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c];
+                if (p.dequant) qq[k] = qidx[sv * p.xs + sh];
+              }
+            }
+            val[band][it] = make_int4(e[0], e[1], e[2], e[3]);
+            q4[band][it] = make_int4(qq[0], qq[1], qq[2], qq[3]);
+            continue;
+          }
+        }
         if (!inside) continue;
         if (from_plane) val[band][it] = *(const int4 *)(llp + (size_t)by * npx + bx0);
         else {
@@ -561,6 +583,17 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
             const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)];
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
+          }
+        } else if (SMALL) { // loaded in the first phase
+          if (!from_plane && p.dequant && !(p.debug_skip & 8)) {
+            const int qs[4] = {q4[SMALL ? band : 0][SMALL ? it : 0].x, q4[SMALL ? band : 0][SMALL ? it : 0].y,
+                               q4[SMALL ? band : 0][SMALL ? it : 0].z, q4[SMALL ? band : 0][SMALL ? it : 0].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int aq = max(qs[k] - qm, 0);
+              if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+              e[k] = dequant_f(e[k], qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
+            }
           }
         } else if (from_plane) {
           const int32_t *row = llp + (size_t)by * npx;
@@ -659,9 +692,17 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
   dim3 grid(gx, gy, 3 * n_pictures), block(NT);
   const size_t lds = INV ? Cfg<K>::LDS_INV : Cfg<K>::LDS;
   if constexpr (INV) {
-    vc2_allow_lds((const void *)k_inv_fast<K, EDGE>, 160 * 1024);
+    // element-wise gather when some component's band blocks are narrower than four coefficients
+    bool small = false;
+    for (int c = 0; c < 3; ++c) if (p.tiles_x[c] && p.fw[c] / 2 < 4) small = true;
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
-    hipLaunchKernelGGL((k_inv_fast<K, EDGE>), grid, block, lds, s, p);
+    if (small) {
+      vc2_allow_lds((const void *)k_inv_fast<K, EDGE, true>, 160 * 1024);
+      hipLaunchKernelGGL((k_inv_fast<K, EDGE, true>), grid, block, lds, s, p);
+    } else {
+      vc2_allow_lds((const void *)k_inv_fast<K, EDGE, false>, 160 * 1024);
+      hipLaunchKernelGGL((k_inv_fast<K, EDGE, false>), grid, block, lds, s, p);
+    }
   } else {
     vc2_allow_lds((const void *)k_fwd_fast<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
