@@ -771,14 +771,30 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
       const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
       const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       const uint2 bands = *(const uint2 *)(band_lut + j0);
+      // the reciprocal multiply for all eight, one test whether any left its domain (see load8_tab)
+      unsigned a8[8], qf8[8], dom = 0;
+      int qq[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint4 t = qtab[((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu];
-        const int c = quant_core(v[k], (int)t.z, t.x, (int)t.y);
-        int nb = svlc_bits(c);
+        const unsigned a = (v[k] < 0 ? 0u - (unsigned)v[k] : (unsigned)v[k]) << 2;
+        const unsigned m = __umulhi(t.x, a);
+        qq[k] = (int)((m + ((a - m) >> 1)) >> t.y);
+        a8[k] = a; qf8[k] = t.z;
+        dom |= a | (t.z - 2u);
+      }
+      if (__any((int)dom < 0)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if ((int)(a8[k] | (qf8[k] - 2u)) < 0) qq[k] = (int)a8[k] / (int)qf8[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { // only the length matters: the sign of the quantised value does not change it
+        const unsigned m1 = (unsigned)(qq[k] < 0 ? -qq[k] : qq[k]) + 1u;
+        int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2;
         if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; }
         sum += nb;
-        if (c != 0) last_end = sum;
+        if (qq[k] != 0) last_end = sum;
       }
     } else {
       for (int k = 0; k < 8 && j0 + k < n; ++k) {
