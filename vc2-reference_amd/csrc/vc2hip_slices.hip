@@ -1015,18 +1015,13 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
       // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0)
       const int z = min(__clzll((long long)~win), room - cnt);
       cnt += z;
-      if (cnt >= room || z >= 32) { br.skip(z); continue; }
+      // a non-zero coefficient follows unless the round is full (z <= room <= 32: the code lies inside the window);
+      // one code path for both cases
+      const bool nz = cnt < room;
       // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
       const unsigned hi = (unsigned)((win << z) >> 32);
       const unsigned follow = hi & 0xAAAAAAAAu;
-      if (follow != 0) {
-        const int K = __clz(follow) >> 1;                       // 1..15 (bit 31 of hi is 0 here)
-        const unsigned body = hi >> (32 - 2 * K);               // top 2K bits: (0 b) pairs
-        const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
-        const int neg = (int)((hi >> (30 - 2 * K)) & 1u);
-        st[cnt++] = neg ? (int)(0u - mag) : (int)mag;
-        br.skip(z + 2 * K + 2);
-      } else { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
+      if (nz && follow == 0) { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
         br.skip(z);
         unsigned value = 1;
         for (;;) {
@@ -1043,7 +1038,15 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
           br.skip(1);
         }
         st[cnt++] = r;
+        continue;
       }
+      const int K = __clz((int)(follow | 1u)) >> 1;                // 1..15 for a real code (bit 31 of hi is 0 there)
+      const unsigned body = hi >> ((32 - 2 * K) & 31);             // top 2K bits: (0 b) pairs
+      const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
+      const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
+      if (nz) st[cnt] = neg ? (int)(0u - mag) : (int)mag;
+      cnt += nz ? 1 : 0;
+      br.skip(nz ? z + 2 * K + 2 : z);
     }
     // flush: 4 lanes x 16 bytes per component run.  The staging rows are private to the wavefront, so only
     // its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup barrier,
