@@ -916,39 +916,40 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t
 // a whole token (zero run + one code, <= 48 bits) is consumed with a single refill check.
 // Bytes past the component bound read as 0xFF (VLC.cpp:182-185).
 struct WordReader {
-  const uint2 *w8;     // 8-byte aligned base
-  int lead, len;       // bytes to skip in word 0; bounded length in bytes
-  int k;               // next word index to fetch
+  const uint2 *pw;     // next word to fetch (8-byte aligned)
+  int left;            // data bytes from the start of that word to the end of the bounded data (<= 0: past the end)
   unsigned long long acc, nxt;
   int have;
-  __device__ __forceinline__ unsigned long long fetch(int idx) const {
-    const int rel = 8 * idx - lead; // byte offset of this word relative to the data start
-    if (rel >= len) return ~0ull;
-    const uint2 w = w8[idx];
-    unsigned long long v = ((unsigned long long)__builtin_bswap32(w.x) << 32) | __builtin_bswap32(w.y);
-    if (rel + 8 > len) v |= ~0ull >> (8 * (len - rel));
+  __device__ __forceinline__ unsigned long long fetch() {
+    unsigned long long v = ~0ull; // bytes past the bound read as 0xFF (VLC.cpp:182-185)
+    if (left > 0) {
+      const uint2 w = *pw;
+      v = ((unsigned long long)__builtin_bswap32(w.x) << 32) | __builtin_bswap32(w.y);
+      if (left < 8) v |= ~0ull >> (8 * left);
+    }
+    ++pw;
+    left -= 8;
     return v;
   }
   __device__ __forceinline__ void init(const uint8_t *data, int nbytes) {
     const size_t a = (size_t)data;
-    w8 = (const uint2 *)(a & ~(size_t)7);
-    lead = (int)(a & 7);
-    len = nbytes;
-    acc = fetch(0) << (8 * lead);
+    const int lead = (int)(a & 7);
+    pw = (const uint2 *)(a & ~(size_t)7);
+    left = nbytes + lead; // word 0 starts `lead` bytes before the data
+    acc = fetch() << (8 * lead);
     have = 64 - 8 * lead;
-    nxt = fetch(1);
-    k = 2;
+    nxt = fetch();
   }
-  __device__ __forceinline__ void init_ones() { w8 = nullptr; lead = 0; len = 0; k = 0; acc = nxt = ~0ull; have = 64; }
-  // the next 64 unread bits
-  __device__ __forceinline__ unsigned long long peek() const { return have >= 64 ? acc : (acc | (nxt >> have)); }
+  __device__ __forceinline__ void init_ones() { pw = nullptr; left = 0; acc = nxt = ~0ull; have = 64; }
+  // the next 64 unread bits; have is 1..64, so both shifts are in range
+  __device__ __forceinline__ unsigned long long peek() const { return acc | ((nxt >> 1) >> (have - 1)); }
   __device__ __forceinline__ void skip(int n) { // n <= 64
     if (n < have) { acc <<= n; have -= n; }
     else {
       const int r = n - have; // 0..63 bits into nxt
-      acc = r >= 64 ? 0 : nxt << r;
+      acc = nxt << r;
       have = 64 - r;
-      nxt = fetch(k++);
+      nxt = fetch();
     }
   }
 };
