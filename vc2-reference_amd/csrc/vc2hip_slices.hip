@@ -1047,7 +1047,27 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
       const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
       if (nz) st[cnt] = neg ? (int)(0u - mag) : (int)mag;
       cnt += nz ? 1 : 0;
-      br.skip(nz ? z + 2 * K + 2 : z);
+      int n = nz ? z + 2 * K + 2 : z;
+      // a second token from the same window when it lies wholly inside it (saves a window build, a refill test and a
+      // loop turn per pair): zero run, then a code with its terminator and sign inside the 32 bits examined
+      if (n <= 31) {
+        const unsigned long long w2 = win << n;
+        const int z2 = min(__clzll((long long)~w2), room - cnt);
+        const unsigned hi2 = (unsigned)((w2 << z2) >> 32);
+        const unsigned follow2 = hi2 & 0xAAAAAAAAu;
+        const int K2 = __clz((int)(follow2 | 1u)) >> 1;
+        // n + z2 + 32 <= 64 keeps every examined bit a real stream bit
+        const bool take = nz && n + z2 <= 32 && cnt + z2 < room && follow2 != 0;
+        if (take) {
+          const unsigned body2 = hi2 >> ((32 - 2 * K2) & 31);
+          const unsigned mag2 = ((1u << K2) | compact_even32(body2)) - 1u;
+          const int neg2 = (int)((hi2 >> ((30 - 2 * K2) & 31)) & 1u);
+          cnt += z2;
+          st[cnt++] = neg2 ? (int)(0u - mag2) : (int)mag2;
+          n += z2 + 2 * K2 + 2;
+        }
+      }
+      br.skip(n);
     }
     // flush: 4 lanes x 16 bytes per component run.  The staging rows are private to the wavefront, so only
     // its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup barrier,
