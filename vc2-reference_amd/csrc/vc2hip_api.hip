@@ -40,24 +40,30 @@ struct Launcher {
   const char *last_name = nullptr;
   std::string launch_error;
   std::vector<ProfEntry> entries;
-  struct Pending { int entry; hipEvent_t a, b; };
+  // One event after every launch; a launch that directly follows another on the same stream takes the previous
+  // launch's end event as its start (half the event records, and the stream never idles between two records).
+  struct Pending { int entry, a, b; }; // indices into `used`
   std::vector<Pending> pending;
-  std::vector<hipEvent_t> pool;
-  int cur = -1;
-  hipEvent_t ev() {
-    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+  std::vector<hipEvent_t> used, pool;
+  int last_end = -1;
+  hipStream_t last_stream = nullptr;
+  int record(hipStream_t s) {
     hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
+    if (!pool.empty()) { e = pool.back(); pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    (void)hipEventRecord(e, s);
+    used.push_back(e);
+    return (int)used.size() - 1;
   }
   void collect() {
     for (auto &p : pending) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { entries[p.entry].ms += ms; entries[p.entry].launches++; }
-      pool.push_back(p.a);
-      pool.push_back(p.b);
+      if (hipEventElapsedTime(&ms, used[p.a], used[p.b]) == hipSuccess) { entries[p.entry].ms += ms; entries[p.entry].launches++; }
     }
     pending.clear();
+    pool.insert(pool.end(), used.begin(), used.end());
+    used.clear();
+    last_end = -1;
   }
 };
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
@@ -66,9 +72,8 @@ void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
   int idx = -1;
   for (size_t i = 0; i < L.entries.size(); ++i) if (L.entries[i].name == name) { idx = (int)i; break; }
   if (idx < 0) { L.entries.push_back(ProfEntry{name, 0, 0}); idx = (int)L.entries.size() - 1; }
-  Launcher::Pending p{idx, L.ev(), L.ev()};
-  (void)hipEventRecord(p.a, s);
-  L.pending.push_back(p);
+  const int a = (L.last_end >= 0 && L.last_stream == s) ? L.last_end : L.record(s);
+  L.pending.push_back(Launcher::Pending{idx, a, -1});
 }
 void vc2_prof_end(Launcher &L, hipStream_t s) {
   // every launcher calls this right after hipLaunchKernelGGL: catch launch failures (bad grid / LDS size)
@@ -76,8 +81,12 @@ void vc2_prof_end(Launcher &L, hipStream_t s) {
   if (le != hipSuccess && L.launch_error.empty())
     L.launch_error = std::string("kernel launch failed (") + (L.last_name ? L.last_name : "?") + "): " + hipGetErrorString(le);
   if (!L.on) return;
-  (void)hipEventRecord(L.pending.back().b, s);
+  L.pending.back().b = L.record(s);
+  L.last_end = L.pending.back().b;
+  L.last_stream = s;
 }
+// operations enqueued outside the launchers (copies, memsets) must not be billed to the next kernel
+void vc2_prof_break(Launcher &L) { L.last_end = -1; }
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -317,6 +326,7 @@ static int join_lanes(vc2hip_ctx *c) {
 // every entry point that enqueues on the context's stream starts here
 static int enter(vc2hip_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
+  if (!c->in_split) vc2_prof_break(c->L); // whatever the caller enqueued since is not part of the next kernel
   return join_lanes(c);
 }
 #define ENTER(ctx) do { int rc_ = enter(ctx); if (rc_) return rc_; } while (0)
@@ -691,6 +701,7 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const int32_t *store, c
     unsigned long long *lb;
     NEED(c, B_SIZES, (size_t)n * lb_stride * 8, lb);
     HIPCHK(c, hipMemsetAsync(lb, 0, (size_t)n * lb_stride * 8, c->stream));
+    vc2_prof_break(c->L);
     p.lookback = lb; p.lookback_stride = lb_stride; p.lens = d_lens;
     vc2_launch_pack(c->L, p, n, c->stream);
     return VC2HIP_OK;
@@ -925,6 +936,7 @@ static int build_index(vc2hip_ctx *c, const uint8_t *d_pay, long long stride, co
   const size_t wsb = vc2_slice_index_workspace(n, (size_t)stride, prefix, scalar);
   NEED(c, B_INDEX, wsb, ws);
   HIPCHK(c, hipMemsetAsync(d_offs, 0xFF, (size_t)n * ns * 4, c->stream)); // unreachable slices read past the payload
+  vc2_prof_break(c->L);
   vc2_launch_slice_index(c->L, d_pay, stride, d_lens, d_offs, ns, prefix, scalar, n, c->d_err, c->stream, ws, wsb);
   *d_offs_out = d_offs;
   return VC2HIP_OK;
