@@ -691,10 +691,12 @@ void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets
   vc2_prof_end(L, s);
 }
 
+// W lanes copy one slice: 64, or 32 / 16 when slices are short (at most 4 * W dwords per trip would leave lanes idle)
+template <int W>
 __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_bytes,
                                                  const uint32_t *sizes, const uint32_t *offsets,
                                                  uint8_t *payload, long long payload_stride, int n) {
-  const int lane = threadIdx.x & 63, slice = blockIdx.x * 4 + (threadIdx.x >> 6), pic = blockIdx.y;
+  const int sl = threadIdx.x % W, slice = (blockIdx.x * 256 + threadIdx.x) / W, pic = blockIdx.y;
   if (slice >= n) return;
   const size_t si = (size_t)pic * n + slice;
   const uint8_t *src = slots + si * slot_bytes; // 16-byte aligned
@@ -704,11 +706,11 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_
   // dwords), byte stores for its ragged head and tail
   const int head = min((int)((4 - ((size_t)dst & 3)) & 3), size);
   const int nw = (size - head) >> 2, tail0 = head + 4 * nw;
-  if (lane < head) dst[lane] = src[lane];
-  if (lane < size - tail0) dst[tail0 + lane] = src[tail0 + lane];
+  if (sl < head) dst[sl] = src[sl];
+  if (sl < size - tail0) dst[tail0 + sl] = src[tail0 + sl];
   const unsigned *s4 = (const unsigned *)src;
   unsigned *d4 = (unsigned *)(dst + head);
-  for (int w = lane; w < nw; w += 64) {
+  for (int w = sl; w < nw; w += W) {
     const int i0 = head + 4 * w;
     d4[w] = __builtin_amdgcn_alignbyte(s4[(i0 >> 2) + 1], s4[i0 >> 2], (unsigned)(i0 & 3));
   }
@@ -718,8 +720,14 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
                         const uint32_t *offsets, uint8_t *payload, long long payload_stride,
                         int n_slices, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "slice_compact", s);
-  hipLaunchKernelGGL(k_compact, dim3((n_slices + 3) / 4, n_pictures), dim3(256), 0, s, slots, slot_bytes,
-                     sizes, offsets, payload, payload_stride, n_slices);
+  // lanes per slice from the slot size (an upper bound of the slice size; typical slices are far shorter)
+  static const int force = [] { const char *e = getenv("VC2HIP_COMPACT_LANES"); return e ? atoi(e) : 0; }();
+  const int W = force ? force : (slot_bytes <= 800 ? 16 : (slot_bytes <= 1600 ? 32 : 64));
+  const int per_wg = 256 / W;
+  const dim3 grid((n_slices + per_wg - 1) / per_wg, n_pictures);
+  if (W == 16) hipLaunchKernelGGL(k_compact<16>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  else if (W == 32) hipLaunchKernelGGL(k_compact<32>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  else hipLaunchKernelGGL(k_compact<64>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
   vc2_prof_end(L, s);
 }
 
