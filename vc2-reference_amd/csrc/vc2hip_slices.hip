@@ -982,6 +982,24 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   constexpr int UNP_PITCH = UNP_N + 4; // ints per staging row, 16-byte aligned rows
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
   __shared__ unsigned long long outp[4][64];
+  // codes of up to 10 bits (|value| <= 30) by their leading 10 bits: length << 8 | value (8-bit two's complement); 0 = longer
+  __shared__ unsigned short vlut[1024];
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    unsigned e = 0;
+    for (int K = 1; K <= 4 && !e; ++K) {
+      bool ok = ((i >> (9 - 2 * K)) & 1) == 1; // terminator after K pairs ...
+      for (int j = 0; j < K; ++j) ok = ok && ((i >> (9 - 2 * j)) & 1) == 0; // ... whose flag bits are all 0
+      if (ok) {
+        unsigned m = 1;
+        for (int j = 0; j < K; ++j) m = (m << 1) | ((i >> (8 - 2 * j)) & 1);
+        m -= 1;
+        const int v = ((i >> (8 - 2 * K)) & 1) ? -(int)m : (int)m;
+        e = ((unsigned)(2 * K + 2) << 8) | ((unsigned)v & 0xFFu);
+      }
+    }
+    vlut[i] = (unsigned short)e;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y, comp = blockIdx.z;
   const int slice = blockIdx.x * 256 + threadIdx.x;
@@ -1049,13 +1067,20 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         st[cnt++] = r;
         continue;
       }
-      const int K = __clz((int)(follow | 1u)) >> 1;                // 1..15 for a real code (bit 31 of hi is 0 there)
-      const unsigned body = hi >> ((32 - 2 * K) & 31);             // top 2K bits: (0 b) pairs
-      const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
-      const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
-      if (nz) st[cnt] = neg ? (int)(0u - mag) : (int)mag;
+      int val, len;
+      const unsigned e1 = vlut[hi >> 22];
+      if (e1) { val = __builtin_amdgcn_sbfe((int)e1, 0, 8); len = (int)(e1 >> 8); }
+      else {
+        const int K = __clz((int)(follow | 1u)) >> 1;              // 1..15 for a real code (bit 31 of hi is 0 there)
+        const unsigned body = hi >> ((32 - 2 * K) & 31);           // top 2K bits: (0 b) pairs
+        const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
+        const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
+        val = neg ? (int)(0u - mag) : (int)mag;
+        len = 2 * K + 2;
+      }
+      if (nz) st[cnt] = val;
       cnt += nz ? 1 : 0;
-      int n = nz ? z + 2 * K + 2 : z;
+      int n = nz ? z + len : z;
       // a second token from the same window when it lies wholly inside it (saves a window build, a refill test and a
       // loop turn per pair): zero run, then a code with its terminator and sign inside the 32 bits examined
       if (n <= 31) {
@@ -1063,16 +1088,23 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         const int z2 = min(__clzll((long long)~w2), room - cnt);
         const unsigned hi2 = (unsigned)((w2 << z2) >> 32);
         const unsigned follow2 = hi2 & 0xAAAAAAAAu;
-        const int K2 = __clz((int)(follow2 | 1u)) >> 1;
         // n + z2 + 32 <= 64 keeps every examined bit a real stream bit
         const bool take = nz && n + z2 <= 32 && cnt + z2 < room && follow2 != 0;
         if (take) {
-          const unsigned body2 = hi2 >> ((32 - 2 * K2) & 31);
-          const unsigned mag2 = ((1u << K2) | compact_even32(body2)) - 1u;
-          const int neg2 = (int)((hi2 >> ((30 - 2 * K2) & 31)) & 1u);
+          int val2, len2;
+          const unsigned e2 = vlut[hi2 >> 22];
+          if (e2) { val2 = __builtin_amdgcn_sbfe((int)e2, 0, 8); len2 = (int)(e2 >> 8); }
+          else {
+            const int K2 = __clz((int)follow2) >> 1;
+            const unsigned body2 = hi2 >> ((32 - 2 * K2) & 31);
+            const unsigned mag2 = ((1u << K2) | compact_even32(body2)) - 1u;
+            const int neg2 = (int)((hi2 >> ((30 - 2 * K2) & 31)) & 1u);
+            val2 = neg2 ? (int)(0u - mag2) : (int)mag2;
+            len2 = 2 * K2 + 2;
+          }
           cnt += z2;
-          st[cnt++] = neg2 ? (int)(0u - mag2) : (int)mag2;
-          n += z2 + 2 * K2 + 2;
+          st[cnt++] = val2;
+          n += z2 + len2;
         }
       }
       br.skip(n);
