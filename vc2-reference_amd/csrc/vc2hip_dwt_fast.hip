@@ -26,6 +26,7 @@ void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s) {
 namespace {
 
 constexpr int TY = 32, TX = 128, NT = 256;
+constexpr int TXQ = TX / 8; // 16-byte chunks (8 samples, 4 pairs) across a tile row
 
 struct I4 {
   int x, y, z, w;
@@ -106,8 +107,8 @@ __device__ __forceinline__ void h_pass(int *lds, int row_lo, int n_rows, int kx_
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int id = it * NT + threadIdx.x;
-    if (id < n_rows * 16) {
-      const int rr = row_lo + (id >> 4), t = id & 15; // rr indexes rows of the (2*WYP)-row stack
+    if (id < n_rows * TXQ) {
+      const int rr = row_lo + id / TXQ, t = id % TXQ; // rr indexes rows of the (2*WYP)-row stack
       const int j0 = C::HX / 2 + 4 * t;
       const int *erow = lds + (rr / C::WYP * 2 + 0) * C::PLANE + (rr % C::WYP) * C::WXP + j0 - P;
       const int *orow = erow + C::PLANE;
@@ -129,8 +130,8 @@ __device__ __forceinline__ void h_pass(int *lds, int row_lo, int n_rows, int kx_
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int id = it * NT + threadIdx.x;
-    if (id < n_rows * 16) {
-      const int rr = row_lo + (id >> 4), t = id & 15;
+    if (id < n_rows * TXQ) {
+      const int rr = row_lo + id / TXQ, t = id % TXQ;
       int *erow = lds + (rr / C::WYP * 2 + 0) * C::PLANE + (rr % C::WYP) * C::WXP + C::HX / 2 + 4 * t;
       lds_st4(erow, re[it]);
       lds_st4(erow + C::PLANE, ro[it]);
@@ -420,14 +421,14 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
   {
     // window rows gy in [0,in_h): stack index rr = rp*WYP + i, row r = 2*i + rp.  Rows outside the
     // plane are skipped (the vertical pass replicates across the plane edge itself).
-    constexpr int NITH = (2 * C::WYP * 16 + NT - 1) / NT;
+    constexpr int NITH = (2 * C::WYP * TXQ + NT - 1) / NT;
     if (!(p.debug_skip & 2)) {
     if constexpr (stepwise<K>()) {
       steps_h<K, false>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
-      steps_v<K, false>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+      steps_v<K, false>(lds, HX / 8, TXQ, (y0 - HY) / 2, in_h / 2);
     } else {
       h_pass<K, false, NITH>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
-      v_pass<K, false, 1>(lds, HX / 8, 16, (y0 - HY) / 2, in_h / 2);
+      v_pass<K, false, 1>(lds, HX / 8, TXQ, (y0 - HY) / 2, in_h / 2);
     }
     }
   }
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
       const int ow = in_w >> 1;
       const bool v4 = (ow & 3) == 0;
       for (int id = threadIdx.x; id < (TY / 2) * (TX / 8); id += NT) {
-        const int i = id >> 4, jq = id & 15;
+        const int i = id / TXQ, jq = id % TXQ;
         const I4 v = lds_ld4(src + i * WXP + 4 * jq);
         int32_t *d = ll + (size_t)(y0 / 2 + i) * ow + x0 / 2 + 4 * jq;
         if (v4) *(int4 *)d = make_int4(v.x, v.y, v.z, v.w);
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
     v_pass<K, true, NITV>(lds, 0, NQ, ky_base, npy);
     // core rows of both parities: stack rows rp*WYP + HY/2 + [0, TY/2); h_pass takes one contiguous
     // range, so run it once per row parity
-    constexpr int NITH = ((TY / 2) * 16 + NT - 1) / NT;
+    constexpr int NITH = ((TY / 2) * TXQ + NT - 1) / NT;
     h_pass<K, true, NITH>(lds, HY / 2, TY / 2, kx_base, npx);
     h_pass<K, true, NITH>(lds, WYP + HY / 2, TY / 2, kx_base, npx);
     }
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   const int lim_h = FINAL ? p.pic_h[comp] : out_h, lim_w = FINAL ? p.pic_w[comp] : out_w;
   const bool vec_out = FINAL ? (p.word_bytes == 2 && (lim_w & 7) == 0) : ((out_w & 3) == 0);
   for (int id = threadIdx.x; id < TY * (TX / 8); id += NT) {
-    const int r = id >> 4, ch = id & 15;
+    const int r = id / TXQ, ch = id % TXQ;
     const int gy = y0 + r, gx0 = x0 + 8 * ch;
     if (gy >= lim_h || gx0 >= lim_w) continue;
     const int *e = lds + ((r & 1) * 2 + 0) * C::PLANE + ((r + HY) >> 1) * WXP + HX / 2 + 4 * ch;
