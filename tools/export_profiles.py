@@ -7,8 +7,8 @@ HBM traffic per launch from the two PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950 c
 """
 import csv, json, sqlite3, sys
 
-SHORT = {'k_hq_unpack': 'hq_unpack', 'k_hq_pack': 'hq_pack', 'k_inv_fast<0, true>': 'idwt_level_final',
-         'k_inv_fast<0, false>': 'idwt_level', 'k_fwd_fast<0, true>': 'dwt_level_first', 'k_fwd_fast<0, false>': 'dwt_level',
+SHORT = {'k_hq_unpack': 'hq_unpack', 'k_hq_pack': 'hq_pack', 'k_inv_fast<0, true': 'idwt_level_final',
+         'k_inv_fast<0, false': 'idwt_level', 'k_fwd_fast<0, true': 'dwt_level_first', 'k_fwd_fast<0, false': 'dwt_level',
          'k_compact': 'slice_compact', 'k_scan_sizes': 'slice_offsets_scan', 'k_index_tables_nx': 'slice_index_tables',
          'k_index_group': 'slice_index_chain(group)', 'k_index_chain': 'slice_index_chain(chain)', 'k_index_emit': 'slice_index_emit'}
 
@@ -33,12 +33,17 @@ def main(tag, stats, fetch, write):
     out = {}
     for name, d in (('FETCH_SIZE', fetch), ('WRITE_SIZE', write)):
         c = sqlite3.connect(f'gpurun_out/{d}/run_results.db')
-        for kn, cnt, avg in c.execute("select kernel_name,count(*),avg(value) from counters_collection where counter_name=? "
+        acc = {}
+        for kn, cnt, tot in c.execute("select kernel_name,count(*),sum(value) from counters_collection where counter_name=? "
                                       "group by kernel_name", (name,)):
             s = short(kn)
-            if s:
-                out.setdefault(s, {})[name + '_KiB'] = avg
-                out[s]['launches_sampled'] = cnt
+            if s:  # several instantiations (and launch sizes) can share a short name: average over all their launches
+                a = acc.setdefault(s, [0, 0.0])
+                a[0] += cnt
+                a[1] += tot
+        for s, (cnt, tot) in acc.items():
+            out.setdefault(s, {})[name + '_KiB'] = tot / cnt
+            out[s]['launches_sampled'] = cnt
     res = {"_comment": "rocprofv3 PMC, two separate passes (--kernel-trace --pmc FETCH_SIZE ; --kernel-trace --pmc WRITE_SIZE) of "
                        "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (batch 16 UHD cfg-2 pictures per launch), averages "
                        "per launch. FETCH_SIZE/WRITE_SIZE are in KiB. hbm_bytes_per_launch applies the gfx950 correction of "
