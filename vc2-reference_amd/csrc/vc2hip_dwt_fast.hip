@@ -484,9 +484,8 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
 // ------------------------------------------------------------------------------------------
 // inverse level
 // ------------------------------------------------------------------------------------------
-// SMALL: the band blocks of a slice are narrower than four coefficients (deep levels), so the gather is element by
-// element; those loads (value and slice index each) are then issued in the first phase as well, not one dependent
-// pair after the other in the conversion phase.  A separate instantiation because it costs registers.
+// SMALL: the band blocks of a slice are narrower than four coefficients (deep levels); the store bands are then
+// gathered slice by slice (see below) instead of window position by window position.
 template <int K, bool FINAL, bool SMALL>
 __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   using C = Cfg<K>;
@@ -517,7 +516,6 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   {
     constexpr int NQI = (WYP * (WXP / 4) + NT - 1) / NT;
     int4 val[4][NQI];
-    int4 q4[SMALL ? 4 : 1][SMALL ? NQI : 1]; // SMALL: the slice index of each of the four elements
     int qv[4][NQI], kind[4][NQI]; // kind: 0 skip, 1 vector loaded, 2 element-wise path
     const int32_t *llp = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
 #pragma unroll
@@ -531,30 +529,13 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         kind[band][it] = 0;
         qv[band][it] = 0;
         val[band][it] = make_int4(0, 0, 0, 0);
+        if (SMALL && !from_plane) continue; // the store bands come slice by slice, below
         if (id >= WYP * (WXP / 4) || (p.debug_skip & 1)) continue;
         const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
         const int by = ky_base + i, bx0 = kx_base + 4 * jq;
         if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
         const bool inside = vec && bx0 >= 0 && bx0 + 4 <= npx;
         kind[band][it] = inside ? 1 : 2;
-        if constexpr (SMALL) {
-          if (!inside) { // four clamped element loads (+ their slices' indices), all in flight together
-            int e[4], qq[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int bx = min(max(bx0 + k, 0), npx - 1);
-              if (from_plane) e[k] = llp[(size_t)by * npx + bx];
-              else {
-                const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx >> lbsw, c = bx & (bsw - 1);
-                e[k] = store[(size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c];
-                if (p.dequant) qq[k] = qidx[sv * p.xs + sh];
-              }
-            }
-            val[band][it] = make_int4(e[0], e[1], e[2], e[3]);
-            q4[band][it] = make_int4(qq[0], qq[1], qq[2], qq[3]);
-            continue;
-          }
-        }
         if (!inside) continue;
         if (from_plane) val[band][it] = *(const int4 *)(llp + (size_t)by * npx + bx0);
         else {
@@ -585,17 +566,6 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
           }
-        } else if (SMALL) { // loaded in the first phase
-          if (!from_plane && p.dequant && !(p.debug_skip & 8)) {
-            const int qs[4] = {q4[SMALL ? band : 0][SMALL ? it : 0].x, q4[SMALL ? band : 0][SMALL ? it : 0].y,
-                               q4[SMALL ? band : 0][SMALL ? it : 0].z, q4[SMALL ? band : 0][SMALL ? it : 0].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int aq = max(qs[k] - qm, 0);
-              if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
-              e[k] = dequant_f(e[k], qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
-            }
-          }
         } else if (from_plane) {
           const int32_t *row = llp + (size_t)by * npx;
 #pragma unroll
@@ -616,6 +586,50 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
           }
         }
         lds_st4(dst + i * WXP + 4 * jq, {e[0], e[1], e[2], e[3]});
+      }
+    }
+  }
+  if constexpr (SMALL) {
+    // Deep levels: the level's bands of one slice and component are ONE short contiguous run of its record
+    // ([LL |] HL | LH | HH, a few to a few dozen coefficients), so they are fetched slice by slice -- one 16-byte load
+    // per four coefficients and one index load per slice -- and scattered to their plane positions in LDS, instead of
+    // one scattered element load per window position and band.
+    const int band_n = p.band_n[comp], lbn = ilog2(band_n);
+    const int band_first = p.ll_from_store ? 0 : 1;
+    const int chunk0 = p.coef_off[comp] + (p.ll_from_store ? 0 : p.band_off[comp]);
+    const int chunk_n = (4 - band_first) * band_n;
+    const int sr0 = max(ky_base, 0) >> lbsh, sr1 = min(ky_base + WYP - 1, npy - 1) >> lbsh;
+    const int sc0 = max(kx_base, 0) >> lbsw, sc1 = min(kx_base + WXP - 1, npx - 1) >> lbsw;
+    const int nsc = sc1 - sc0 + 1, nsl = (sr1 - sr0 + 1) * nsc, nq = (chunk_n + 3) >> 2;
+    const bool al = ((chunk0 | p.slice_coefs) & 3) == 0;
+    const int qm0 = p.qmatrix[0], qm1 = p.qmatrix[p.band], qm2 = p.qmatrix[p.band + 1], qm3 = p.qmatrix[p.band + 2];
+    for (int id = threadIdx.x; id < nsl * nq && !(p.debug_skip & 1); id += NT) {
+      const int sidx = id / nq, qd = id - sidx * nq;
+      const int sr = sidx / nsc, sv = sr0 + sr, sh = sc0 + (sidx - sr * nsc);
+      const int32_t *rec = store + (size_t)(sv * p.xs + sh) * p.slice_coefs + chunk0;
+      int e[4];
+      if (al && 4 * qd + 4 <= chunk_n) {
+        const int4 v = *(const int4 *)(rec + 4 * qd);
+        e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = 4 * qd + k < chunk_n ? rec[4 * qd + k] : 0;
+      }
+      const int q = p.dequant ? qidx[sv * p.xs + sh] : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = 4 * qd + k;
+        if (idx >= chunk_n) continue;
+        const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
+        const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
+        if (i < 0 || i >= WYP || j < 0 || j >= WXP) continue;
+        int v = e[k];
+        if (p.dequant && !(p.debug_skip & 8)) {
+          const int aq = max(q - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
+          if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+          v = dequant_f(v, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
+        }
+        lds[band * C::PLANE + i * WXP + j] = v;
       }
     }
   }
