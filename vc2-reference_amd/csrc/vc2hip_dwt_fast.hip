@@ -442,9 +442,38 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
   int32_t *store = p.store + (size_t)pic * p.store_stride;
   const int *core = lds + (HY / 2) * WXP + HX / 2;
   if (p.debug_skip & 4) return;
+  // Deep levels (band blocks narrower than four coefficients): the level's bands of one slice are one short contiguous
+  // run of its record ([LL |] HL | LH | HH), written slice by slice with 16-byte stores assembled from the planes.
+  const bool by_slice = lbsw < 2;
+  if (by_slice) {
+    const int band_n = bsh * bsw, lbn = lblk;
+    const int band_first = p.ll_to_store ? 0 : 1;
+    const int chunk0 = p.coef_off[comp] + (p.ll_to_store ? 0 : p.band_off[comp]);
+    const int chunk_n = (4 - band_first) * band_n, nq = (chunk_n + 3) >> 2;
+    const int tsx = TX / fw, nsl = (TY / fh) * tsx;
+    const bool al = ((chunk0 | p.slice_coefs) & 3) == 0;
+    for (int id = threadIdx.x; id < nsl * nq; id += NT) {
+      const int sidx = id / nq, qd = id - sidx * nq;
+      const int si = sidx / tsx, sj = sidx - si * tsx;
+      int e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = min(4 * qd + k, chunk_n - 1);
+        const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
+        e[k] = core[band * C::PLANE + ((si << (lblk - lbsw)) + (rem >> lbsw)) * WXP + (sj << lbsw) + (rem & (bsw - 1))];
+      }
+      int32_t *d = store + (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + chunk0 + 4 * qd;
+      if (al && 4 * qd + 4 <= chunk_n) *(int4 *)d = make_int4(e[0], e[1], e[2], e[3]);
+      else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (4 * qd + k < chunk_n) d[k] = e[k];
+      }
+    }
+  }
 #pragma unroll 1
   for (int band = 0; band < 4; ++band) {
     const int *src = core + band * C::PLANE;
+    if (by_slice && !(band == 0 && !p.ll_to_store)) continue; // written above
     if (band == 0 && !p.ll_to_store) {
       int32_t *ll = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
       const int ow = in_w >> 1;
