@@ -209,3 +209,30 @@ def test_ld_diagnostic_outputs(tools, oracle, tmp_path):
     assert all(np.array_equal(a, b) for a, b in zip(got, q))
     run("EncodeStream", *base, "-o", "Packaged", tmp_path / "in.raw", tmp_path / "p.bin")
     assert (tmp_path / "p.bin").read_bytes() == bytes(oracle.ld_pack(q[0], q[1], q[2], depth, qi, sb))
+
+
+def test_decodestream_resynchronises_and_skips_other_units(tools, oracle, tmp_path):
+    """Bytes before the first parse-info prefix are skipped (dataunitio::synchronise, DataUnit.cpp:1086-1109); auxiliary
+    and padding data units between the pictures are stepped over (DecodeStream.cpp:281-290)."""
+    w, h = 128, 64
+    raw = synth(w, h, "422", 10, 57, frames=2)
+    p = make_params(w, h, "422", 10, "LeGall", 2, 2, 2, q=9, scalar=2)
+    stream = oracle.encode_stream(p, raw, 2)
+    want = oracle.decode_stream(p, stream, 2)[0]
+    # cut the stream into its data units and splice an auxiliary (0x20) and a padding (0x30) unit between the pictures
+    pos, units = 0, []
+    while pos < len(stream):
+        nxt = int.from_bytes(stream[pos + 5:pos + 9], "big") or 13
+        units.append(bytearray(stream[pos:pos + nxt]))
+        pos += nxt
+    aux = bytearray(b"BBCD\x20" + (13 + 5).to_bytes(4, "big") + bytes(4) + b"hello")
+    pad = bytearray(b"BBCD\x30" + (13 + 32).to_bytes(4, "big") + bytes(4) + bytes(32))
+    units = units[:2] + [aux, pad] + units[2:]
+    prev = 0
+    for u in units:  # re-chain the previous-parse-offset fields
+        u[9:13] = prev.to_bytes(4, "big")
+        prev = int.from_bytes(u[5:9], "big")
+    spliced = b"\x00garbage BBC" + b"".join(bytes(u) for u in units)
+    (tmp_path / "s.vc2").write_bytes(spliced)
+    run("DecodeStream", tmp_path / "s.vc2", tmp_path / "d.raw")
+    assert (tmp_path / "d.raw").read_bytes() == want
