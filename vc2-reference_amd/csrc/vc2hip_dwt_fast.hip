@@ -52,7 +52,7 @@ template <int K> struct Cfg {
   static constexpr int NWV = 4 + 2 * PADV;
   static constexpr int PLANE = WYP * WXP;    // ints per parity plane
   static constexpr size_t LDS = (size_t)4 * PLANE * 4;
-  static constexpr size_t LDS_INV = LDS + 2 * 120 * 4; // + the dequantiser table (factor, offset per index)
+  static constexpr size_t LDS_INV = LDS + 3 * 120 * 4; // + the dequantiser table (factor, offset, domain limit per index)
 };
 
 // one lifting step on a register window; E / O are the even / odd parity values of NW pairs
@@ -536,7 +536,12 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   // quant_factor / quant_offset by adjusted index, copied next to the planes: the look-up that follows the
   // slice's index load is then an LDS read instead of a second dependent trip to memory
   int *qtab = lds + 4 * C::PLANE;
-  if (threadIdx.x < 120) { qtab[threadIdx.x] = c_qd.qf[threadIdx.x]; qtab[120 + threadIdx.x] = c_qd.off[threadIdx.x]; }
+  if (threadIdx.x < 120) {
+    const int qf = c_qd.qf[threadIdx.x], off = c_qd.off[threadIdx.x];
+    qtab[threadIdx.x] = qf; qtab[120 + threadIdx.x] = off;
+    // largest magnitude for which |v| * factor + offset + 2 stays below 2^31 (the literal arithmetic otherwise)
+    qtab[240 + threadIdx.x] = qf > 0 ? (int)((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf) : -1;
+  }
   __syncthreads();
 
   // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in.
@@ -591,9 +596,22 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
           if (!from_plane && p.dequant && !(p.debug_skip & 8)) {
             const int aq = max(qv[band][it] - qm, 0);
             if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
-            const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)];
+            const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)], lim = qtab[240 + min(aq, 119)];
+            // scale(), Quantisation.cpp:86-95: inside the domain (no int overflow) it is (|v| * factor + offset + 2) >> 2
+            // for v != 0; one magnitude test for the four values, the literal sequence outside
+            unsigned mg[4], any = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
+            for (int k = 0; k < 4; ++k) { mg[k] = e[k] < 0 ? 0u - (unsigned)e[k] : (unsigned)e[k]; any |= mg[k]; }
+            if ((int)any >= 0 && (int)any <= lim) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const unsigned r = mg[k] ? (mg[k] * (unsigned)qf + (unsigned)(qo + 2)) >> 2 : 0u;
+                e[k] = e[k] < 0 ? (int)(0u - r) : (int)r;
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) e[k] = dequant_f(e[k], qf, qo);
+            }
           }
         } else if (from_plane) {
           const int32_t *row = llp + (size_t)by * npx;
