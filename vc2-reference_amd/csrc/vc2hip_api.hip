@@ -113,7 +113,7 @@ struct vc2hip_ctx {
   int debug_skip = 0;
   // VBR payload assembly.  Default: fixed-stride slots + scan + compaction (three launches).
   // VC2HIP_SINGLE_PASS_VBR=1: decoupled look-back inside the pack kernel -- measured 2x SLOWER on
-  // MI355X (1.28 vs 0.62 + 0.20 ms per 16 UHD pictures: the look-back sits on every workgroup's
+  // MI355X when it was measured (1.28 vs 0.62 + 0.20 ms per 16 UHD pictures: the look-back sits on every workgroup's
   // critical path and the kernel is latency-bound), kept as a tested alternative.
   bool two_pass_vbr = true;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)

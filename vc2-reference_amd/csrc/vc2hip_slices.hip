@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "hq_unpack", s);
-  static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 0; }(); // A/B on MI355X: 64-byte runs 0.75 ms, 128-byte 0.80 ms per 16 pictures
+  static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 0; }(); // A/B on MI355X: 64-byte runs 0.59 ms, 128-byte runs 0.64 ms per 16 UHD pictures (twice the staging LDS)
   if (wide) hipLaunchKernelGGL(k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_hq_unpack<16>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
