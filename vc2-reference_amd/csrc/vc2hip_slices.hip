@@ -1476,13 +1476,61 @@ __global__ __launch_bounds__(1024) void k_ld_ll(const int32_t *store, long long 
   }
 }
 
+// The same with the whole LL plane in LDS (it fits for HD pictures: 135 x 240 x 4 bytes): the residuals are dequantised
+// into LDS in one parallel sweep, the anti-diagonal wavefront then only touches LDS (a barrier per diagonal costs
+// tenths of a microsecond instead of a round trip to memory), and the plane is written out once.
+__global__ __launch_bounds__(1024) void k_ld_ll_lds(const int32_t *store, long long store_stride,
+                                                    int slice_coefs, int coef_off, int llh, int llw,
+                                                    int ys, int xs, const int32_t *qidx, int qm0,
+                                                    int32_t *ll_plane, long long ll_stride, unsigned *err) {
+  extern __shared__ int rs[];
+  const int pic = blockIdx.x;
+  const int32_t *st = store + (size_t)pic * store_stride;
+  const int32_t *qi = qidx + (size_t)pic * ys * xs;
+  const int bh = llh / ys, bw = llw / xs; // LL block of one slice
+  for (int i = threadIdx.x; i < llh * llw; i += blockDim.x) {
+    const int y = i / llw, x = i - y * llw;
+    const int sv = y / bh, sh = x / bw;
+    const int qv = st[(size_t)(sv * xs + sh) * slice_coefs + coef_off + (y - sv * bh) * bw + (x - sh * bw)];
+    // slice whose index quantises this LL sample: Quantisation.cpp:298-299
+    const int yb = ((y + 1) * ys - 1) / llh, xb = ((x + 1) * xs - 1) / llw;
+    const int aq = max(qi[yb * xs + xb] - qm0, 0);
+    if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
+    rs[i] = scale_dev(qv, min(aq, 119));
+  }
+  __syncthreads();
+  for (int d = 1; d < llh + llw - 1; ++d) { // (0,0) has no prediction
+    const int ylo = max(0, d - (llw - 1)), yhi = min(llh - 1, d);
+    for (int y = ylo + (int)threadIdx.x; y <= yhi; y += blockDim.x) {
+      const int x = d - y;
+      int pred; // predictDC, Quantisation.cpp:191-208
+      if (y > 0 && x > 0) {
+        const int r = rs[(y - 1) * llw + x - 1] + rs[(y - 1) * llw + x] + rs[y * llw + x - 1];
+        pred = r >= 0 ? (r + 1) / 3 : (r - 1) / 3;
+      } else if (y > 0) pred = rs[(y - 1) * llw + x];
+      else pred = rs[y * llw + x - 1];
+      rs[y * llw + x] = (int)((unsigned)rs[y * llw + x] + (unsigned)pred);
+    }
+    __syncthreads();
+  }
+  int32_t *ll = ll_plane + (size_t)pic * ll_stride;
+  for (int i = threadIdx.x; i < llh * llw; i += blockDim.x) ll[i] = rs[i];
+}
+
 void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride, int slice_coefs,
                       int coef_off, int n0, int llh, int llw, int ys, int xs, const int32_t *qidx,
                       int qm0, int32_t *ll_plane, long long ll_stride, int n_pictures, unsigned *err,
                       hipStream_t s) {
   vc2_prof_begin(L, "ld_ll_predict", s);
-  hipLaunchKernelGGL(k_ld_ll, dim3(n_pictures), dim3(1024), 0, s, store, store_stride, slice_coefs, coef_off, n0,
-                     llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
+  const size_t plane_bytes = (size_t)llh * llw * 4;
+  if (plane_bytes <= 150 * 1024) {
+    vc2_allow_lds((const void *)k_ld_ll_lds, 150 * 1024);
+    hipLaunchKernelGGL(k_ld_ll_lds, dim3(n_pictures), dim3(1024), plane_bytes, s, store, store_stride, slice_coefs, coef_off,
+                       llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
+  } else {
+    hipLaunchKernelGGL(k_ld_ll, dim3(n_pictures), dim3(1024), 0, s, store, store_stride, slice_coefs, coef_off, n0,
+                       llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
+  }
   vc2_prof_end(L, s);
 }
 
