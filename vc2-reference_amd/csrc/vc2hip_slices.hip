@@ -925,29 +925,31 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t
 // Bytes past the component bound read as 0xFF (VLC.cpp:182-185).
 struct WordReader {
   const uint2 *pw;     // next word to fetch (8-byte aligned)
-  int left;            // data bytes from the start of that word to the end of the bounded data (<= 0: past the end)
+  int left;            // data BITS from the start of that word to the end of the bounded data (<= 0: past the end)
   unsigned long long acc, nxt;
   int have;
   __device__ __forceinline__ unsigned long long fetch() {
-    unsigned long long v = ~0ull; // bytes past the bound read as 0xFF (VLC.cpp:182-185)
+    unsigned long long v = ~0ull; // bits past the bound read as 1 (VLC.cpp:182-185)
     if (left > 0) {
       const uint2 w = *pw;
       v = ((unsigned long long)__builtin_bswap32(w.x) << 32) | __builtin_bswap32(w.y);
-      if (left < 8) v |= ~0ull >> (8 * left);
+      if (left < 64) v |= ~0ull >> left;
     }
     ++pw;
-    left -= 8;
+    left -= 64;
     return v;
   }
-  __device__ __forceinline__ void init(const uint8_t *data, int nbytes) {
+  // nbits (> 0) of data starting bitoff (0..7) bits into *data
+  __device__ __forceinline__ void init_bits(const uint8_t *data, int bitoff, int nbits) {
     const size_t a = (size_t)data;
-    const int lead = (int)(a & 7);
+    const int lead = 8 * (int)(a & 7) + bitoff; // 0..63: word 0 starts `lead` bits before the data
     pw = (const uint2 *)(a & ~(size_t)7);
-    left = nbytes + lead; // word 0 starts `lead` bytes before the data
-    acc = fetch() << (8 * lead);
-    have = 64 - 8 * lead;
+    left = nbits + lead;
+    acc = fetch() << lead;
+    have = 64 - lead;
     nxt = fetch();
   }
+  __device__ __forceinline__ void init(const uint8_t *data, int nbytes) { init_bits(data, 0, 8 * nbytes); }
   __device__ __forceinline__ void init_ones() { pw = nullptr; left = 0; acc = nxt = ~0ull; have = 64; }
   // the next 64 unread bits; have is 1..64, so both shifts are in range
   __device__ __forceinline__ unsigned long long peek() const { return acc | ((nxt >> 1) >> (have - 1)); }
@@ -975,16 +977,9 @@ __device__ __forceinline__ unsigned compact_even32(unsigned x) {
   return x;
 }
 
-// UNP_N coefficients are staged per lane and round: 16 = 64-byte runs, 32 = whole 128-byte lines (no
-// read-for-ownership of the other half line, but twice the LDS).
-template <int UNP_N>
-__global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
-  constexpr int UNP_PITCH = UNP_N + 4; // ints per staging row, 16-byte aligned rows
-  __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
-  __shared__ unsigned long long outp[4][64];
-  // codes of up to 10 bits (|value| <= 30) by their leading 10 bits: length << 8 | value (8-bit two's complement); 0 = longer
-  __shared__ unsigned short vlut[1024];
-  for (int i = threadIdx.x; i < 1024; i += 256) {
+// codes of up to 10 bits (|value| <= 30) by their leading 10 bits: length << 8 | value (8-bit two's complement); 0 = longer
+__device__ __forceinline__ void vlut_init(unsigned short *vlut) {
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
     unsigned e = 0;
     for (int K = 1; K <= 4 && !e; ++K) {
       bool ok = ((i >> (9 - 2 * K)) & 1) == 1; // terminator after K pairs ...
@@ -999,6 +994,99 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     }
     vlut[i] = (unsigned short)e;
   }
+}
+
+// One round of the exp-Golomb decoder: `room` (<= UNP_N) coefficients from br into the lane's staging row st.
+template <int UNP_N>
+__device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, const unsigned short *vlut) {
+  // zero coefficients are the common case: clear the row, then only non-zero values are stored
+#pragma unroll
+  for (int k = 0; k < UNP_N; k += 4) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
+  int cnt = 0;
+  while (cnt < room) {
+    const unsigned long long win = br.peek();
+    // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0)
+    const int z = min(__clzll((long long)~win), room - cnt);
+    cnt += z;
+    // a non-zero coefficient follows unless the round is full (z <= room <= 32: the code lies inside the window);
+    // one code path for both cases
+    const bool nz = cnt < room;
+    // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
+    const unsigned hi = (unsigned)((win << z) >> 32);
+    const unsigned follow = hi & 0xAAAAAAAAu;
+    if (nz && follow == 0) { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
+      br.skip(z);
+      unsigned value = 1;
+      for (;;) {
+        const int f = (int)(br.peek() >> 63);
+        br.skip(1);
+        if (f) break;
+        value = (value << 1) | (unsigned)(br.peek() >> 63);
+        br.skip(1);
+      }
+      value -= 1u;
+      int r = 0;
+      if (value) {
+        r = (br.peek() >> 63) ? (int)(0u - value) : (int)value;
+        br.skip(1);
+      }
+      st[cnt++] = r;
+      continue;
+    }
+    int val, len;
+    const unsigned e1 = vlut[hi >> 22];
+    if (e1) { val = __builtin_amdgcn_sbfe((int)e1, 0, 8); len = (int)(e1 >> 8); }
+    else {
+      const int K = __clz((int)(follow | 1u)) >> 1;              // 1..15 for a real code (bit 31 of hi is 0 there)
+      const unsigned body = hi >> ((32 - 2 * K) & 31);           // top 2K bits: (0 b) pairs
+      const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
+      const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
+      val = neg ? (int)(0u - mag) : (int)mag;
+      len = 2 * K + 2;
+    }
+    if (nz) st[cnt] = val;
+    cnt += nz ? 1 : 0;
+    int n = nz ? z + len : z;
+    // a second token from the same window when it lies wholly inside it (saves a window build, a refill test and a
+    // loop turn per pair): zero run, then a code with its terminator and sign inside the 32 bits examined
+    if (n <= 31) {
+      const unsigned long long w2 = win << n;
+      const int z2 = min(__clzll((long long)~w2), room - cnt);
+      const unsigned hi2 = (unsigned)((w2 << z2) >> 32);
+      const unsigned follow2 = hi2 & 0xAAAAAAAAu;
+      // n + z2 + 32 <= 64 keeps every examined bit a real stream bit
+      const bool take = nz && n + z2 <= 32 && cnt + z2 < room && follow2 != 0;
+      if (take) {
+        int val2, len2;
+        const unsigned e2 = vlut[hi2 >> 22];
+        if (e2) { val2 = __builtin_amdgcn_sbfe((int)e2, 0, 8); len2 = (int)(e2 >> 8); }
+        else {
+          const int K2 = __clz((int)follow2) >> 1;
+          const unsigned body2 = hi2 >> ((32 - 2 * K2) & 31);
+          const unsigned mag2 = ((1u << K2) | compact_even32(body2)) - 1u;
+          const int neg2 = (int)((hi2 >> ((30 - 2 * K2) & 31)) & 1u);
+          val2 = neg2 ? (int)(0u - mag2) : (int)mag2;
+          len2 = 2 * K2 + 2;
+        }
+        cnt += z2;
+        st[cnt++] = val2;
+        n += z2 + len2;
+      }
+    }
+    br.skip(n);
+  }
+}
+
+// UNP_N coefficients are staged per lane and round: 16 = 64-byte runs, 32 = whole 128-byte lines (no
+// read-for-ownership of the other half line, but twice the LDS).
+template <int UNP_N>
+__global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
+  constexpr int UNP_PITCH = UNP_N + 4; // ints per staging row, 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
+  __shared__ unsigned long long outp[4][64];
+  // codes of up to 10 bits (|value| <= 30) by their leading 10 bits: length << 8 | value (8-bit two's complement); 0 = longer
+  __shared__ unsigned short vlut[1024];
+  vlut_init(vlut);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y, comp = blockIdx.z;
@@ -1033,82 +1121,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   }
   for (int base = 0; base < n; base += UNP_N) {
     const int room = min(UNP_N, n - base);
-    // zero coefficients are the common case: clear the row, then only non-zero values are stored
-#pragma unroll
-    for (int k = 0; k < UNP_N; k += 4) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
-    int cnt = 0;
-    while (cnt < room) {
-      const unsigned long long win = br.peek();
-      // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0)
-      const int z = min(__clzll((long long)~win), room - cnt);
-      cnt += z;
-      // a non-zero coefficient follows unless the round is full (z <= room <= 32: the code lies inside the window);
-      // one code path for both cases
-      const bool nz = cnt < room;
-      // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
-      const unsigned hi = (unsigned)((win << z) >> 32);
-      const unsigned follow = hi & 0xAAAAAAAAu;
-      if (nz && follow == 0) { // code longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
-        br.skip(z);
-        unsigned value = 1;
-        for (;;) {
-          const int f = (int)(br.peek() >> 63);
-          br.skip(1);
-          if (f) break;
-          value = (value << 1) | (unsigned)(br.peek() >> 63);
-          br.skip(1);
-        }
-        value -= 1u;
-        int r = 0;
-        if (value) {
-          r = (br.peek() >> 63) ? (int)(0u - value) : (int)value;
-          br.skip(1);
-        }
-        st[cnt++] = r;
-        continue;
-      }
-      int val, len;
-      const unsigned e1 = vlut[hi >> 22];
-      if (e1) { val = __builtin_amdgcn_sbfe((int)e1, 0, 8); len = (int)(e1 >> 8); }
-      else {
-        const int K = __clz((int)(follow | 1u)) >> 1;              // 1..15 for a real code (bit 31 of hi is 0 there)
-        const unsigned body = hi >> ((32 - 2 * K) & 31);           // top 2K bits: (0 b) pairs
-        const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
-        const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
-        val = neg ? (int)(0u - mag) : (int)mag;
-        len = 2 * K + 2;
-      }
-      if (nz) st[cnt] = val;
-      cnt += nz ? 1 : 0;
-      int n = nz ? z + len : z;
-      // a second token from the same window when it lies wholly inside it (saves a window build, a refill test and a
-      // loop turn per pair): zero run, then a code with its terminator and sign inside the 32 bits examined
-      if (n <= 31) {
-        const unsigned long long w2 = win << n;
-        const int z2 = min(__clzll((long long)~w2), room - cnt);
-        const unsigned hi2 = (unsigned)((w2 << z2) >> 32);
-        const unsigned follow2 = hi2 & 0xAAAAAAAAu;
-        // n + z2 + 32 <= 64 keeps every examined bit a real stream bit
-        const bool take = nz && n + z2 <= 32 && cnt + z2 < room && follow2 != 0;
-        if (take) {
-          int val2, len2;
-          const unsigned e2 = vlut[hi2 >> 22];
-          if (e2) { val2 = __builtin_amdgcn_sbfe((int)e2, 0, 8); len2 = (int)(e2 >> 8); }
-          else {
-            const int K2 = __clz((int)follow2) >> 1;
-            const unsigned body2 = hi2 >> ((32 - 2 * K2) & 31);
-            const unsigned mag2 = ((1u << K2) | compact_even32(body2)) - 1u;
-            const int neg2 = (int)((hi2 >> ((30 - 2 * K2) & 31)) & 1u);
-            val2 = neg2 ? (int)(0u - mag2) : (int)mag2;
-            len2 = 2 * K2 + 2;
-          }
-          cnt += z2;
-          st[cnt++] = val2;
-          n += z2 + len2;
-        }
-      }
-      br.skip(n);
-    }
+    decode_round<UNP_N>(br, room, st, vlut);
     // flush: 4 lanes x 16 bytes per component run.  The staging rows are private to the wavefront, so only
     // its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup barrier,
     // the four wavefronts of the workgroup drift apart freely.
@@ -1387,56 +1400,90 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
 }
 
 // ------------------------------------------------------------------------------------------
-// LD slices (decode only): one lane per slice, bit-serial (legacy profile, cfg 5)
+// LD slices, decode (legacy profile, cfg 5): one lane per slice, the luma stream then the interleaved
+// chroma stream (Slices.cpp:485-560) through the same windowed decoder and staged flush as the HQ slices.
 // ------------------------------------------------------------------------------------------
-struct SerialBits { // VLC.cpp:182-202 on a memory buffer
-  const uint8_t *p;
-  int nbytes, bitpos, bounded, left;
-  __device__ __forceinline__ int get() {
-    if (bounded && left < 1) return 1;
-    const int by = bitpos >> 3;
-    const int b = by < nbytes ? (p[by] >> (7 - (bitpos & 7))) & 1 : 1;
-    ++bitpos;
-    --left;
-    return b;
-  }
-  __device__ __forceinline__ unsigned bits(int n) { unsigned v = 0; while (n-- > 0) v = (v << 1) | (unsigned)get(); return v; }
-  __device__ __forceinline__ int svlc() {
-    unsigned value = 1;
-    while (!get()) value = (value << 1) | (unsigned)get();
-    value -= 1u;
-    if (!value) return 0;
-    return get() ? (int)(0u - value) : (int)value;
-  }
-  __device__ __forceinline__ void bound(int n) { bounded = 1; left = n; }
-  __device__ __forceinline__ void flush() { if (bounded) { if (left > 0) bitpos += left; left = 0; } }
-};
-
 __device__ __forceinline__ int intlog2_dev(int value) { int l = 0; --value; while (value > 0) { value >>= 1; ++l; } return l; }
 
-__global__ __launch_bounds__(64) void k_ld_unpack(const LdUnpackParams p) {
-  const int slice = blockIdx.x * 64 + threadIdx.x, pic = blockIdx.y;
-  if (slice >= p.n_slices) return;
-  const int size = p.slice_bytes[slice];
-  SerialBits br{p.payload + (size_t)pic * p.payload_stride + p.offsets[slice], size, 0, 0, 0};
-  p.qidx[(size_t)pic * p.n_slices + slice] = (int)br.bits(7);
-  const int split = intlog2_dev(8 * size - 7);
-  const int ybits = (int)br.bits(split);
-  const int uvbits = 8 * size - 7 - split - ybits;
-  int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-  br.bound(ybits);
-  for (int j = 0; j < p.comp_n[0]; ++j) rec[p.comp_off[0] + j] = br.svlc();
-  br.flush();
-  br.bound(uvbits);
-  for (int j = 0; j < p.comp_n[1]; ++j) {
-    rec[p.comp_off[1] + j] = br.svlc();
-    rec[p.comp_off[2] + j] = br.svlc();
+__global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
+  constexpr int UNP_N = 16, UNP_PITCH = UNP_N + 4;
+  __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
+  __shared__ unsigned long long outp[4][64];
+  __shared__ unsigned short vlut[1024];
+  vlut_init(vlut);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x * 256 + threadIdx.x, pic = blockIdx.y;
+  const bool active = slice < p.n_slices;
+  int *st = stage[wave] + lane * UNP_PITCH;
+  const int *sw = stage[wave];
+  const uint8_t *data = nullptr;
+  int ystart = 0, ybits = 0, total = 0; // bit positions inside the slice
+  if (active) {
+    const int size = p.slice_bytes[slice];
+    data = p.payload + (size_t)pic * p.payload_stride + p.offsets[slice];
+    unsigned head = 0; // 7 bits of quantiser index, then intlog2(8*size-7) bits of luma length: at most 30 bits
+    for (int k = 0; k < 4; ++k) head = (head << 8) | (k < size ? data[k] : 0xFFu);
+    p.qidx[(size_t)pic * p.n_slices + slice] = (int)(head >> 25);
+    const int split = intlog2_dev(8 * size - 7);
+    ybits = split ? (int)((head << 7) >> (32 - split)) : 0;
+    ystart = 7 + split;
+    total = 8 * size;
+    outp[wave][lane] = (unsigned long long)(p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs);
+  } else outp[wave][lane] = 0;
+  WordReader br;
+  // luma: ybits bits from ystart; bits past the slice read as 1 like bits past the bound (VLC.cpp:182-185)
+  {
+    const int nb = min(ybits, total - ystart);
+    if (active && nb > 0) br.init_bits(data + (ystart >> 3), ystart & 7, nb); else br.init_ones();
+  }
+  const int ny = p.comp_n[0];
+  for (int base = 0; base < ny; base += UNP_N) {
+    const int room = min(UNP_N, ny - base);
+    decode_round<UNP_N>(br, room, st, vlut);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 16 + lane / 4, c = (lane % 4) * 4;
+      int32_t *rec = (int32_t *)outp[wave][r];
+      if (rec && c < room) {
+        const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
+        int *d = rec + p.comp_off[0] + base + c;
+        __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
+        __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+      }
+    }
+    wave_lds_sync();
+  }
+  // chroma: the rest of the slice, U and V coefficients alternating
+  {
+    const int cstart = ystart + ybits;
+    const int nb = total - cstart;
+    if (active && nb > 0 && ybits >= 0) br.init_bits(data + (cstart >> 3), cstart & 7, nb); else br.init_ones();
+  }
+  const int nc = 2 * p.comp_n[1];
+  for (int base = 0; base < nc; base += UNP_N) {
+    const int room = min(UNP_N, nc - base);
+    decode_round<UNP_N>(br, room, st, vlut);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 16 + lane / 4, c = (lane % 4) * 4;
+      int32_t *rec = (int32_t *)outp[wave][r];
+      if (rec && c < room) { // room is even: (u, v) pairs
+        const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
+        int *du = rec + p.comp_off[1] + (base + c) / 2, *dv = rec + p.comp_off[2] + (base + c) / 2;
+        __builtin_nontemporal_store(v.x, du); __builtin_nontemporal_store(v.y, dv);
+        if (c + 2 < room) { __builtin_nontemporal_store(v.z, du + 1); __builtin_nontemporal_store(v.w, dv + 1); }
+      }
+    }
+    wave_lds_sync();
   }
 }
 
 void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "ld_unpack", s);
-  hipLaunchKernelGGL(k_ld_unpack, dim3((p.n_slices + 63) / 64, n_pictures), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(k_ld_unpack, dim3((p.n_slices + 255) / 256, n_pictures), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
 
