@@ -274,7 +274,8 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
   c->stream = stream;
   c->own_stream = own;
-  if (hipMalloc((void **)&c->d_err, sizeof(unsigned)) != hipSuccess ||
+  if (hipMalloc((void **)&c->d_err, 256 + 4096) != hipSuccess || // error word, then the LD search tables
+     
       hipHostMalloc((void **)&c->h_err, sizeof(unsigned)) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   (void)hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream);
   QuantTables t;
@@ -1077,6 +1078,7 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
   p.img_words = (max_slice + 3) / 4 + 2;
   p.payload = d_pay; p.payload_stride = stride; p.err = c->d_err;
+  p.tab = (int *)((char *)c->d_err + 256);
   if ((size_t)g.slice_coefs * 8 + 512 + (size_t)p.rs_ints * 4 > 160 * 1024 || (size_t)p.img_words * 4 > 160 * 1024)
     return set_err(c, VC2HIP_EINVAL, "slice too large for the LD encode kernels");
   return VC2HIP_OK;

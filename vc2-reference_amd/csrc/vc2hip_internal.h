@@ -236,6 +236,7 @@ struct LdEncParams {
   int rs_ints;                // LDS ints per wavefront for the LL blocks with their halo: sum of (bh + 1) * (bw + 1)
   int qmatrix[VC2_MAX_BANDS];
   int search;
+  int *tab;                   // device scratch for the search tables (LD_TAB_INTS ints)
   int img_words;              // LDS words of one slice image (pack)
   uint8_t *payload;
   long long payload_stride;

@@ -731,6 +731,51 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
   vc2_prof_end(L, s);
 }
 
+// bits of eight coefficients of one component, quantised through the tables: total and end of the last non-zero code
+__device__ __forceinline__ void bits8_tab(const int *src, int j0, int n, const unsigned char *band_lut, const uint4 *qtab,
+                                        unsigned *err, int &sum, int &last_end) {
+  sum = 0; last_end = 0;
+  if (j0 + 8 <= n) {
+    const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
+    const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint2 bands = *(const uint2 *)(band_lut + j0);
+    // the reciprocal multiply for all eight, one test whether any left its domain (see load8_tab)
+    unsigned a8[8], qf8[8], dom = 0;
+    int qq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint4 t = qtab[((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu];
+      const unsigned a = (v[k] < 0 ? 0u - (unsigned)v[k] : (unsigned)v[k]) << 2;
+      const unsigned m = __umulhi(t.x, a);
+      qq[k] = (int)((m + ((a - m) >> 1)) >> t.y);
+      a8[k] = a; qf8[k] = t.z;
+      dom |= a | (t.z - 2u);
+    }
+    if (__any((int)dom < 0)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((int)(a8[k] | (qf8[k] - 2u)) < 0) qq[k] = (int)a8[k] / (int)qf8[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { // only the length matters: the sign of the quantised value does not change it
+      const unsigned m1 = (unsigned)(qq[k] < 0 ? -qq[k] : qq[k]) + 1u;
+      int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2;
+      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
+      sum += nb;
+      if (qq[k] != 0) last_end = sum;
+    }
+  } else {
+    for (int k = 0; k < 8 && j0 + k < n; ++k) {
+      const uint4 t = qtab[band_lut[j0 + k]];
+      const int c = quant_core(src[j0 + k], (int)t.z, t.x, (int)t.y);
+      int nb = svlc_bits(c);
+      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
+      sum += nb;
+      if (c != 0) last_end = sum;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // HQ_CBR quantiser search: one wavefront per slice, slice coefficients staged in LDS
 // ------------------------------------------------------------------------------------------
@@ -772,49 +817,6 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
     wave_lds_sync();
     return !__any(!ok);
   };
-  // bits of eight coefficients of one component, quantised through the tables: total and end of the last non-zero code
-  auto bits8 = [&](const int *src, int j0, int n, const unsigned char *band_lut, int &sum, int &last_end) {
-    sum = 0; last_end = 0;
-    if (j0 + 8 <= n) {
-      const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
-      const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      const uint2 bands = *(const uint2 *)(band_lut + j0);
-      // the reciprocal multiply for all eight, one test whether any left its domain (see load8_tab)
-      unsigned a8[8], qf8[8], dom = 0;
-      int qq[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint4 t = qtab[((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu];
-        const unsigned a = (v[k] < 0 ? 0u - (unsigned)v[k] : (unsigned)v[k]) << 2;
-        const unsigned m = __umulhi(t.x, a);
-        qq[k] = (int)((m + ((a - m) >> 1)) >> t.y);
-        a8[k] = a; qf8[k] = t.z;
-        dom |= a | (t.z - 2u);
-      }
-      if (__any((int)dom < 0)) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if ((int)(a8[k] | (qf8[k] - 2u)) < 0) qq[k] = (int)a8[k] / (int)qf8[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { // only the length matters: the sign of the quantised value does not change it
-        const unsigned m1 = (unsigned)(qq[k] < 0 ? -qq[k] : qq[k]) + 1u;
-        int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2;
-        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; }
-        sum += nb;
-        if (qq[k] != 0) last_end = sum;
-      }
-    } else {
-      for (int k = 0; k < 8 && j0 + k < n; ++k) {
-        const uint4 t = qtab[band_lut[j0 + k]];
-        const int c = quant_core(src[j0 + k], (int)t.z, t.x, (int)t.y);
-        int nb = svlc_bits(c);
-        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; }
-        sum += nb;
-        if (c != 0) last_end = sum;
-      }
-    }
-  };
   auto comp_bytes = [&](int count, bool &bad) -> int {
     const int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
     if (len > 255) { bad = true; if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); }
@@ -825,11 +827,11 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
     if (fast) {
       if (!set_q(tq)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); }
       int sum, last_end;
-      bits8(co + p.comp_off[0], lane * 8, p.comp_n[0], band_y, sum, last_end); // luma: one round
+      bits8_tab(co + p.comp_off[0], lane * 8, p.comp_n[0], band_y, qtab, p.err, sum, last_end); // luma: one round
       int incl = wave_incl_scan(sum, lane);
       need += comp_bytes(wave_max(last_end ? incl - sum + last_end : 0), bad);
       const int half = lane >> 5;                                               // lanes 0-31 U, lanes 32-63 V
-      bits8(co + p.comp_off[1 + half], (lane & 31) * 8, p.comp_n[1], band_c, sum, last_end);
+      bits8_tab(co + p.comp_off[1 + half], (lane & 31) * 8, p.comp_n[1], band_c, qtab, p.err, sum, last_end);
       incl = wave_incl_scan(sum, lane);
       const int total_u = __shfl(incl, 31); // every lane takes part in the shuffle
       const int rel = incl - sum - (half ? total_u : 0);
@@ -1716,6 +1718,327 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   }
 }
 
+// Tables of the fast anti-diagonal step, built once per batch: subband of every luma / interleaved chroma index
+// (2 x 512 bytes), the 120 quantiser entries (magic, shift, factor, offset), the quantisation matrix (32 ints)
+constexpr int LD_TAB_INTS = 256 + 480 + 32;
+__global__ __launch_bounds__(256) void k_ld_tables(const LdEncParams p) {
+  unsigned char *band_y = (unsigned char *)p.tab, *band_uv = band_y + 512;
+  uint4 *qs = (uint4 *)(p.tab + 256);
+  int *qm = p.tab + 736;
+  const int n_y = p.comp_n[0], n_c = p.comp_n[1], n0y = p.comp_n0[0], n0c = p.comp_n0[1];
+  const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
+  for (int j = threadIdx.x; j < 512; j += blockDim.x) {
+    band_y[j] = (unsigned char)band_of_index_fast(min(j, n_y - 1), n0y, sy);
+    band_uv[j] = (unsigned char)band_of_index_fast(min(j >> 1, n_c - 1), n0c, sc);
+  }
+  for (int j = threadIdx.x; j < 120; j += blockDim.x)
+    qs[j] = make_uint4(c_qs.magic[j], (unsigned)c_qs.shift[j], (unsigned)c_qs.qf[j], (unsigned)c_qs.off[j]);
+  for (int j = threadIdx.x; j < 32; j += blockDim.x) qm[j] = j < 3 * p.depth + 1 ? p.qmatrix[j] : 0;
+}
+
+// The same anti-diagonal step for the common geometry (a component of at most 512 / 256 coefficients, its LL block
+// inside the first eight).  The chain of anti-diagonals is latency bound, so what counts is the length of the
+// dependent chain inside a step.  One workgroup of four wavefronts per slice; every wavefront keeps the slice's
+// coefficients (CPL per lane, luma / interleaved chroma stream) and their matrix entries in registers.  The seven
+// bisection steps of quantIndicesLD (EncodeStream.cpp:141-190) are taken in four rounds of 2 + 2 + 2 + 1 steps: a
+// round measures the three indices its two steps can visit (the trial, the trial -/+ half the step).  In a round
+// wavefront 0 runs the DC-predicted LL chains of the candidates side by side (one lane per candidate and component,
+// each on its own copy of the reconstructed LL block), wavefronts 1-3 measure the remaining subbands of one
+// candidate each; the walk over the results is the reference's loop.  Ten measurements instead of seven, a
+// dependent chain of four instead of seven.  All global loads of a step are issued together, nothing is written
+// until the index is final.
+constexpr int LD_SLOTS = 16; // candidates of round r: 4 r + (0: trial, 1: trial - step, 2: trial + step); 15: an index that was no trial
+
+template <int CPL>
+__global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams p, int d, int rs_pad) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int pic = blockIdx.y;
+  const int n_y = p.comp_n[0], n_c = p.comp_n[1], n_uv = 2 * n_c, n0y = p.comp_n0[0], n0c = p.comp_n0[1];
+  const unsigned char *band_y = (const unsigned char *)lds_i, *band_uv = band_y + 512;
+  const uint4 *qs = (const uint4 *)(lds_i + 256);
+  const int *qmt = lds_i + 736;
+  int *llv = lds_i + LD_TAB_INTS;          // LL coefficients: [0,8) luma, [8,16) U/V alternating
+  int *rsS = llv + 16;                     // per candidate: LL blocks with the row above and the column to the left
+  int *llq = rsS + LD_SLOTS * rs_pad;      // per candidate: quantised LL residuals, laid out like llv
+  int *llpack = llq + LD_SLOTS * 16;       // per candidate and component: code lengths of the residuals, a byte each
+  int *acres = llpack + LD_SLOTS * 8;      // per candidate: luma count, chroma count (behind the LL blocks), bad index
+  const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x, sh = d - sv, slice = sv * p.xs + sh;
+  int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  const bool dual = n_y <= 32 * CPL && n_uv <= 32 * CPL; // luma on lanes 0-31, chroma on lanes 32-63: one pass per candidate
+  const bool ch = dual && lane >= 32;
+  // slot A: luma (dual: chroma on the upper lanes); slot B: chroma when not dual
+  const int j0 = (dual ? lane & 31 : lane) * CPL;
+  const int nA = ch ? n_uv : n_y, nB = dual ? 0 : n_uv;
+  const int llA = ch ? 2 * n0c : n0y, llB = 2 * n0c; // stream indices below these are LL
+  int vA[CPL], vB[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) vA[k] = vB[k] = 0;
+  auto load_y = [&](int (&v)[CPL]) {
+    if (j0 < n_y) { const int4 a = *(const int4 *)(rec + p.comp_off[0] + j0); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+    if constexpr (CPL == 8)
+      if (j0 + 4 < n_y) { const int4 a = *(const int4 *)(rec + p.comp_off[0] + j0 + 4); v[4] = a.x; v[5] = a.y; v[6] = a.z; v[7] = a.w; }
+  };
+  auto load_uv = [&](int (&v)[CPL]) {
+    if (j0 < n_uv) {
+      if constexpr (CPL == 8) {
+        const int4 a = *(const int4 *)(rec + p.comp_off[1] + j0 / 2), b = *(const int4 *)(rec + p.comp_off[2] + j0 / 2);
+        v[0] = a.x; v[1] = b.x; v[2] = a.y; v[3] = b.y; v[4] = a.z; v[5] = b.z; v[6] = a.w; v[7] = b.w;
+      } else {
+        const int2 a = *(const int2 *)(rec + p.comp_off[1] + j0 / 2), b = *(const int2 *)(rec + p.comp_off[2] + j0 / 2);
+        v[0] = a.x; v[1] = b.x; v[2] = a.y; v[3] = b.y;
+      }
+    }
+  };
+  if (ch) load_uv(vA); else load_y(vA);
+  if (!dual) load_uv(vB);
+  int bytes = 0, qfix = 0;
+  if (p.search) bytes = p.slice_bytes[slice]; else qfix = p.qidx[(size_t)pic * p.n_slices + slice];
+  if (wave == 0) { // reconstructed LL samples around the slice's blocks (row above: bw + 1 samples, then the column to the left), into every candidate's copy
+    const int h0 = p.bh[0] + p.bw[0] + 1, h1 = p.bh[1] + p.bw[1] + 1, h2 = p.bh[2] + p.bw[2] + 1;
+    const int o1 = (p.bh[0] + 1) * (p.bw[0] + 1), o2 = o1 + (p.bh[1] + 1) * (p.bw[1] + 1);
+    for (int e = lane; e < h0 + h1 + h2; e += 64) { // one load per lane, all components in flight together
+      const int c = e < h0 ? 0 : e < h0 + h1 ? 1 : 2, i = e - (c == 0 ? 0 : c == 1 ? h0 : h0 + h1);
+      const int32_t *res = (c == 0 ? p.restored[0] : c == 1 ? p.restored[1] : p.restored[2]) +
+                           (size_t)pic * (c == 0 ? p.restored_stride[0] : c == 1 ? p.restored_stride[1] : p.restored_stride[2]);
+      const int llw = c == 0 ? p.ll_w[0] : c == 1 ? p.ll_w[1] : p.ll_w[2];
+      const int bh = c == 0 ? p.bh[0] : c == 1 ? p.bh[1] : p.bh[2], bw = c == 0 ? p.bw[0] : c == 1 ? p.bw[1] : p.bw[2];
+      const int yy = i <= bw ? 0 : i - bw, xx = i <= bw ? i : 0;
+      const int y = sv * bh - 1 + yy, x = sh * bw - 1 + xx;
+      const int val = (y >= 0 && x >= 0) ? res[(size_t)y * llw + x] : 0;
+      const int at = (c == 0 ? 0 : c == 1 ? o1 : o2) + yy * (bw + 1) + xx;
+      for (int sl = 0; sl < LD_SLOTS; ++sl) rsS[sl * rs_pad + at] = val;
+    }
+    if (j0 < 8) { // the LL coefficients go to the chains
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) llv[(ch ? 8 : 0) + j0 + k] = vA[k];
+      if (!dual) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) llv[8 + j0 + k] = vB[k];
+      }
+    }
+  }
+  for (int i = threadIdx.x * 4; i < LD_TAB_INTS; i += blockDim.x * 4) *(int4 *)(lds_i + i) = *(const int4 *)(p.tab + i);
+  __syncthreads();
+  int qmA[CPL], qmB[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    qmA[k] = qmt[(ch ? band_uv : band_y)[min(j0 + k, 511)]];
+    qmB[k] = qmt[band_uv[min(j0 + k, 511)]];
+  }
+  const int qm0 = qmt[0];
+
+  // component c's LL chain of candidate slot sl at index tq: raster scan, prediction from the reconstructed samples
+  auto chain = [&](int sl, int c, int tq) {
+    if (tq - qm0 > 119) return; // reported by the subband pass
+    const int bh = c == 0 ? p.bh[0] : c == 1 ? p.bh[1] : p.bh[2], bw = c == 0 ? p.bw[0] : c == 1 ? p.bw[1] : p.bw[2];
+    int *r0 = rsS + sl * rs_pad + (c == 0 ? 0 : (p.bh[0] + 1) * (p.bw[0] + 1) + (c == 1 ? 0 : (p.bh[1] + 1) * (p.bw[1] + 1)));
+    const int ll0 = c == 0 ? 0 : 7 + c, step = c == 0 ? 1 : 2;
+    const uint4 t = qs[max(tq - qm0, 0)];
+    const int pitch = bw + 1;
+    int pack0 = 0, pack1 = 0, i = 0;
+    for (int yy = 0; yy < bh; ++yy)
+      for (int xx = 0; xx < bw; ++xx, ++i) {
+        const int y = sv * bh + yy, x = sh * bw + xx;
+        const int *up = r0 + yy * pitch + xx; // up-left; up + 1: above; up + pitch: left
+        int pred; // predictDC, Quantisation.cpp:191-208
+        if (y > 0 && x > 0) {
+          const int r = up[0] + up[1] + up[pitch];
+          pred = r >= 0 ? (r + 1) / 3 : (r - 1) / 3;
+        } else if (y > 0) pred = up[1];
+        else if (x > 0) pred = up[pitch];
+        else pred = 0;
+        int qq = quant_core((int)((unsigned)llv[ll0 + i * step] - (unsigned)pred), (int)t.z, t.x, (int)t.y);
+        int nb = svlc_bits(qq);
+        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; qq = 0; }
+        // scale(), Quantisation.cpp:86-95, with the table's factor and offset
+        const unsigned mag = qq < 0 ? 0u - (unsigned)qq : (unsigned)qq;
+        int r = (int)(mag * t.z);
+        if (r > 0) r = (int)((unsigned)r + t.w);
+        r = (int)((unsigned)r + 2u);
+        r /= 4;
+        if (qq < 0) r = (int)(0u - (unsigned)r);
+        r0[(yy + 1) * pitch + xx + 1] = (int)((unsigned)r + (unsigned)pred);
+        llq[sl * 16 + ll0 + i * step] = qq;
+        if (i < 4) pack0 |= nb << (8 * i); else pack1 |= nb << (8 * (i - 4));
+      }
+    llpack[sl * 8 + 2 * c] = pack0;
+    llpack[sl * 8 + 2 * c + 1] = pack1;
+  };
+  // one stream at index tq: bits of the lane's coefficients behind the LL block (sum) and the end of its last non-zero code
+  auto eval = [&](const int (&v)[CPL], const int (&qm)[CPL], int n, int n_ll, int tq, bool &over, int &sum, int &le) {
+    sum = 0; le = 0;
+    if (j0 >= n) return;
+    unsigned a8[CPL], qf8[CPL], dom = 0;
+    int qq[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int aq = max(tq - qm[k], 0);
+      over = over || aq > 119;
+      const uint4 t = qs[min(aq, 119)];
+      const unsigned a = (v[k] < 0 ? 0u - (unsigned)v[k] : (unsigned)v[k]) << 2;
+      const unsigned m = __umulhi(t.x, a);
+      qq[k] = (int)((m + ((a - m) >> 1)) >> t.y);
+      a8[k] = a; qf8[k] = t.z;
+      dom |= a | (t.z - 2u);
+    }
+    if (__any((int)dom < 0)) { // outside the reciprocal's domain: the literal division (see quant_core)
+#pragma unroll
+      for (int k = 0; k < CPL; ++k)
+        if ((int)(a8[k] | (qf8[k] - 2u)) < 0) qq[k] = (int)a8[k] / (int)qf8[k];
+    }
+    unsigned big = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { // only the length matters: the sign of the quantised value does not change it
+      const unsigned m1 = (unsigned)(qq[k] < 0 ? -qq[k] : qq[k]) + 1u;
+      int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2;
+      big |= (unsigned)(nb > 32);
+      if (nb > 32) { nb = 1; qq[k] = 0; }
+      if (j0 + k < n && j0 + k >= n_ll) {
+        sum += nb;
+        if (qq[k] != 0) le = sum;
+      }
+    }
+    if (big) atomicOr(p.err, VC2_DEVERR_CODE32);
+  };
+  // the subbands of candidate slot sl at index tq: coded bits of each stream behind its LL block, up to the last
+  // non-zero coefficient
+  auto ac = [&](int sl, int tq) {
+    bool over = tq - qm0 > 119;
+    int sumA, leA, sumB = 0, leB = 0;
+    eval(vA, qmA, nA, llA, tq, over, sumA, leA);
+    if (!dual) eval(vB, qmB, nB, llB, tq, over, sumB, leB);
+    const bool any_over = __any(over);
+    int cy, cc;
+    int incl = wave_incl_scan(sumA, lane);
+    if (dual) {
+      const int total_y = __builtin_amdgcn_readlane(incl, 31);
+      int m = leA ? incl - sumA - (ch ? total_y : 0) + leA : 0; // prefix maximum inside each half
+      m = max(m, dpp0<0x111, 0xf>(m));
+      m = max(m, dpp0<0x112, 0xf>(m));
+      m = max(m, dpp0<0x114, 0xf>(m));
+      m = max(m, dpp0<0x118, 0xf>(m));
+      m = max(m, dpp0<0x142, 0xa>(m));
+      cy = __builtin_amdgcn_readlane(m, 31);
+      cc = __builtin_amdgcn_readlane(m, 63);
+    } else {
+      cy = wave_max(leA ? incl - sumA + leA : 0);
+      incl = wave_incl_scan(sumB, lane);
+      cc = wave_max(leB ? incl - sumB + leB : 0);
+    }
+    if (lane == 0) { acres[sl * 4] = cy; acres[sl * 4 + 1] = cc; acres[sl * 4 + 2] = any_over ? 1 : 0; }
+  };
+  auto run_round = [&](int slot0, int ncand, int trial, int step) { // candidates: trial, trial - step, trial + step
+    auto tq_of = [&](int cand) { return cand == 0 ? trial : cand == 1 ? trial - step : trial + step; };
+    if (wave == 0) {
+      const int cand = lane >> 2, c = lane & 3;
+      if (cand < ncand && c < 3) chain(slot0 + cand, c, tq_of(cand));
+    } else {
+      for (int cand = wave - 1; cand < ncand; cand += nw - 1) ac(slot0 + cand, tq_of(cand));
+    }
+    __syncthreads();
+  };
+  // coded bits of the slice for candidate slot sl (luma_slice_bits + chroma_slice_bits, Slices.cpp:51-95: each stream up
+  // to its last non-zero coefficient)
+  auto need_of = [&](int sl) -> int {
+    const int cy = acres[sl * 4], cc = acres[sl * 4 + 1];
+    const unsigned y0 = (unsigned)llpack[sl * 8], y1 = (unsigned)llpack[sl * 8 + 1];
+    const unsigned u0 = (unsigned)llpack[sl * 8 + 2], v0 = (unsigned)llpack[sl * 8 + 4];
+    int ytot = 0, ylast = 0, ctot = 0, clast = 0; // LL sections: total bits, end of the last non-zero code (>= 4 bits)
+    for (int i = 0; i < n0y; ++i) {
+      const int nb = (int)(((i < 4 ? y0 : y1) >> (8 * (i & 3))) & 0xFFu);
+      ytot += nb;
+      if (nb > 1) ylast = ytot;
+    }
+    for (int i = 0; i < n0c; ++i) {
+      const int nu = (int)((u0 >> (8 * i)) & 0xFFu), nv = (int)((v0 >> (8 * i)) & 0xFFu);
+      ctot += nu;
+      if (nu > 1) clast = ctot;
+      ctot += nv;
+      if (nv > 1) clast = ctot;
+    }
+    return (cy ? ytot + cy : ylast) + (cc ? ctot + cc : clast);
+  };
+
+  int q, slot = LD_SLOTS - 1;
+  bool bad = false;
+  if (p.search) {
+    const int avail = 8 * bytes - 7 - intlog2_dev(8 * bytes - 7);
+    int trial = 63, delta = 64;
+    q = 127;
+    for (int round = 0; round < 4 && !bad; ++round) {
+      const int steps = round < 3 ? 2 : 1, ncand = round < 3 ? 3 : 1, slot0 = 4 * round;
+      run_round(slot0, ncand, trial, delta >> 1);
+      // lane c measures candidate c; the walk is the reference's loop on the two ballots
+      const bool mine = lane < ncand;
+      const unsigned long long is_bad = __ballot(mine && acres[(slot0 + (mine ? lane : 0)) * 4 + 2] != 0);
+      const unsigned long long fits = __ballot(mine && need_of(slot0 + (mine ? lane : 0)) <= avail);
+      int cand = 0;
+      for (int k = 0; k < steps; ++k) {
+        delta >>= 1;
+        if ((is_bad >> cand) & 1) { bad = true; break; }
+        if ((fits >> cand) & 1) { if (trial < q) { q = trial; slot = slot0 + cand; } trial -= delta; cand = 1; }
+        else { trial += delta; cand = 2; }
+      }
+    }
+    if (threadIdx.x == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
+  } else {
+    q = qfix;
+  }
+  if (!bad && (q == 127 || !p.search)) { // not a trial of the search: its LL chains now
+    slot = LD_SLOTS - 1;
+    run_round(slot, 1, q, 0);
+    if (acres[slot * 4 + 2]) bad = true;
+  }
+  if (bad) { if (threadIdx.x == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); return; }
+  if (wave == 1) { // the quantised slice: LL residuals from the chains, everything else through the table
+    auto quant8 = [&](const int (&v)[CPL], const int (&qm)[CPL], int n_ll, const int *ll, int (&out)[CPL]) {
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        const uint4 t = qs[min(max(q - qm[k], 0), 119)];
+        const int r = quant_core(v[k], (int)t.z, t.x, (int)t.y);
+        out[k] = j0 + k < n_ll ? ll[min(j0 + k, 7)] : r;
+      }
+    };
+    auto store_y = [&](const int (&o)[CPL]) {
+      if (j0 < n_y) *(int4 *)(rec + p.comp_off[0] + j0) = make_int4(o[0], o[1], o[2], o[3]);
+      if constexpr (CPL == 8)
+        if (j0 + 4 < n_y) *(int4 *)(rec + p.comp_off[0] + j0 + 4) = make_int4(o[4], o[5], o[6], o[7]);
+    };
+    auto store_uv = [&](const int (&o)[CPL]) {
+      if (j0 < n_uv) {
+        if constexpr (CPL == 8) {
+          *(int4 *)(rec + p.comp_off[1] + j0 / 2) = make_int4(o[0], o[2], o[4], o[6]);
+          *(int4 *)(rec + p.comp_off[2] + j0 / 2) = make_int4(o[1], o[3], o[5], o[7]);
+        } else {
+          *(int2 *)(rec + p.comp_off[1] + j0 / 2) = make_int2(o[0], o[2]);
+          *(int2 *)(rec + p.comp_off[2] + j0 / 2) = make_int2(o[1], o[3]);
+        }
+      }
+    };
+    int out[CPL];
+    if (j0 < nA) {
+      quant8(vA, qmA, llA, llq + slot * 16 + (ch ? 8 : 0), out);
+      if (ch) store_uv(out); else store_y(out);
+    }
+    if (!dual && j0 < nB) {
+      quant8(vB, qmB, llB, llq + slot * 16 + 8, out);
+      store_uv(out);
+    }
+  } else if (wave == 0) { // the slice's reconstructed LL samples become the neighbours' halo
+    const int *r0 = rsS + slot * rs_pad;
+    for (int c = 0; c < 3; ++c) {
+      int32_t *res = p.restored[c] + (size_t)pic * p.restored_stride[c];
+      const int llw = p.ll_w[c], bh = p.bh[c], bw = p.bw[c], pitch = bw + 1;
+      for (int i = lane; i < bh * bw; i += 64) {
+        const int yy = i / bw, xx = i - yy * bw;
+        res[(size_t)(sv * bh + yy) * llw + sh * bw + xx] = r0[(yy + 1) * pitch + xx + 1];
+      }
+      r0 += (bh + 1) * pitch;
+    }
+  }
+}
+
 // LD slice writer: one wavefront per slice, image assembled in LDS as big-endian words
 __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   extern __shared__ unsigned lds_u[];
@@ -1748,10 +2071,26 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
 }
 
 void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
+  vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
+  const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.comp_n[1] > 0 && 3 * p.depth + 1 <= 32 &&
+                    p.comp_n0[0] <= 8 && p.comp_n0[1] <= 4 && p.comp_n[0] % 4 == 0 && p.comp_off[0] == 0 &&
+                    p.comp_off[1] == p.comp_n[0] && p.comp_off[2] == p.comp_n[0] + p.comp_n[1];
+  if (fast) {
+    const int rs_pad = p.rs_ints | 1; // LL blocks + halo of one candidate (odd: the candidates' copies in different banks)
+    const size_t lds = (size_t)(LD_TAB_INTS + 16 + LD_SLOTS * (rs_pad + 16 + 8 + 4)) * 4;
+    const bool small = p.comp_n[0] <= 256 && 2 * p.comp_n[1] <= 256; // four coefficients per lane cover a stream
+    hipLaunchKernelGGL(k_ld_tables, dim3(1), dim3(256), 0, s, p);
+    for (int d = 0; d < p.ys + p.xs - 1; ++d) {
+      const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
+      if (small) hipLaunchKernelGGL(k_ld_quantise_diag_fast<4>, dim3(cnt, n_pictures), dim3(256), lds, s, p, d, rs_pad);
+      else hipLaunchKernelGGL(k_ld_quantise_diag_fast<8>, dim3(cnt, n_pictures), dim3(256), lds, s, p, d, rs_pad);
+    }
+    vc2_prof_end(L, s);
+    return;
+  }
   const size_t per_wave = (size_t)2 * p.slice_coefs * 4 + 32 * 16 + (size_t)p.rs_ints * 4; // coefficients, quantised copy, subband table, LL blocks + halo
   const int wpw = vc2_waves_for_lds(per_wave);
   vc2_allow_lds((const void *)k_ld_quantise_diag, 160 * 1024);
-  vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
   for (int d = 0; d < p.ys + p.xs - 1; ++d) {
     const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
     hipLaunchKernelGGL(k_ld_quantise_diag, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
