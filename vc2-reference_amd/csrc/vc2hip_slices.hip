@@ -1749,8 +1749,8 @@ __global__ __launch_bounds__(256) void k_ld_tables(const LdEncParams p) {
 // until the index is final.
 constexpr int LD_SLOTS = 16; // candidates of round r: 4 r + (0: trial, 1: trial - step, 2: trial + step); 15: an index that was no trial
 
-template <int CPL>
-__global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams p, int d, int rs_pad) {
+template <int CPL, bool DUAL>
+__device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs_pad) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int pic = blockIdx.y;
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams
   int *acres = llpack + LD_SLOTS * 8;      // per candidate: luma count, chroma count (behind the LL blocks), bad index
   const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x, sh = d - sv, slice = sv * p.xs + sh;
   int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-  const bool dual = n_y <= 32 * CPL && n_uv <= 32 * CPL; // luma on lanes 0-31, chroma on lanes 32-63: one pass per candidate
+  constexpr bool dual = DUAL; // n_y, n_uv <= 32 CPL: luma on lanes 0-31, chroma on lanes 32-63, one pass per candidate
   const bool ch = dual && lane >= 32;
   // slot A: luma (dual: chroma on the upper lanes); slot B: chroma when not dual
   const int j0 = (dual ? lane & 31 : lane) * CPL;
@@ -2039,6 +2039,8 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams
   }
 }
 
+template <int CPL, bool DUAL>
+__global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams p, int d, int rs_pad) { ld_diag_body<CPL, DUAL>(p, d, rs_pad); }
 // LD slice writer: one wavefront per slice, image assembled in LDS as big-endian words
 __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   extern __shared__ unsigned lds_u[];
@@ -2079,11 +2081,16 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     const int rs_pad = p.rs_ints | 1; // LL blocks + halo of one candidate (odd: the candidates' copies in different banks)
     const size_t lds = (size_t)(LD_TAB_INTS + 16 + LD_SLOTS * (rs_pad + 16 + 8 + 4)) * 4;
     const bool small = p.comp_n[0] <= 256 && 2 * p.comp_n[1] <= 256; // four coefficients per lane cover a stream
+    const int reach = small ? 128 : 256;
+    const bool dual = p.comp_n[0] <= reach && 2 * p.comp_n[1] <= reach; // half a wavefront covers a stream
     hipLaunchKernelGGL(k_ld_tables, dim3(1), dim3(256), 0, s, p);
     for (int d = 0; d < p.ys + p.xs - 1; ++d) {
       const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
-      if (small) hipLaunchKernelGGL(k_ld_quantise_diag_fast<4>, dim3(cnt, n_pictures), dim3(256), lds, s, p, d, rs_pad);
-      else hipLaunchKernelGGL(k_ld_quantise_diag_fast<8>, dim3(cnt, n_pictures), dim3(256), lds, s, p, d, rs_pad);
+      const dim3 grid(cnt, n_pictures);
+      if (small && dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, true>), grid, dim3(256), lds, s, p, d, rs_pad); // 75 registers: forcing 64 for full residency of a 16-picture diagonal spills and measured slower
+      else if (small) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, false>), grid, dim3(256), lds, s, p, d, rs_pad);
+      else if (dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, true>), grid, dim3(256), lds, s, p, d, rs_pad);
+      else hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, false>), grid, dim3(256), lds, s, p, d, rs_pad);
     }
     vc2_prof_end(L, s);
     return;
