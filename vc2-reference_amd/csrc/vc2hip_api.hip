@@ -1325,6 +1325,14 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     LdUnpackParams p;
     fill_ld_unpack(p, g, (const uint8_t *)d_payload, (long long)payload_stride, d_sb, d_so, d_store, d_q, c->d_err);
     vc2_launch_ld_unpack(c->L, p, n, c->stream);
+    LdLl3Params lp;
+    lp.store = d_store; lp.store_stride = (long long)ns * g.slice_coefs; lp.slice_coefs = g.slice_coefs;
+    lp.ys = g.ys; lp.xs = g.xs; lp.qidx = d_q; lp.qm0 = qm[0]; lp.err = c->d_err;
+    for (int k = 0; k < 3; ++k) {
+      lp.coef_off[k] = g.c[k].coef_off; lp.llh[k] = g.c[k].ph >> g.depth; lp.llw[k] = g.c[k].pw >> g.depth;
+      lp.ll_plane[k] = ll.p[g.depth][k]; lp.ll_stride[k] = ll.stride[g.depth][k];
+    }
+    if (!vc2_launch_ld_ll3(c->L, lp, n, c->stream))
     for (int k = 0; k < 3; ++k)
       vc2_launch_ld_ll(c->L, d_store, (long long)ns * g.slice_coefs, g.slice_coefs, g.c[k].coef_off, g.c[k].n0,
                        g.c[k].ph >> g.depth, g.c[k].pw >> g.depth, g.ys, g.xs, d_q, qm[0], ll.p[g.depth][k],

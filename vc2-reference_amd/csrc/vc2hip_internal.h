@@ -200,6 +200,17 @@ void vc2_launch_quantise_store(Launcher &L, int32_t *store, int n_slices, int sl
                                int comp_off, int n0, const int32_t *qidx, const int *qmatrix,
                                unsigned *err, hipStream_t s);
 // LD: DC-predicted reconstruction of the LL band of one component (Quantisation.cpp:287-306)
+struct LdLl3Params {
+  const int32_t *store;
+  long long store_stride;
+  int slice_coefs, coef_off[3], llh[3], llw[3], ys, xs;
+  const int32_t *qidx;
+  int qm0;
+  int32_t *ll_plane[3];
+  long long ll_stride[3];
+  unsigned *err;
+};
+bool vc2_launch_ld_ll3(Launcher &L, const LdLl3Params &p, int n_pictures, hipStream_t s); // false: a plane does not fit in LDS (use vc2_launch_ld_ll)
 void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride, int slice_coefs,
                       int coef_off, int n0, int llh, int llw, int ys, int xs, const int32_t *qidx,
                       int qm0, int32_t *ll_plane, long long ll_stride, int n_pictures, unsigned *err,

@@ -1528,12 +1528,11 @@ __global__ __launch_bounds__(1024) void k_ld_ll(const int32_t *store, long long 
 // The same with the whole LL plane in LDS (it fits for HD pictures: 135 x 240 x 4 bytes): the residuals are dequantised
 // into LDS in one parallel sweep, the anti-diagonal wavefront then only touches LDS (a barrier per diagonal costs
 // tenths of a microsecond instead of a round trip to memory), and the plane is written out once.
-__global__ __launch_bounds__(1024) void k_ld_ll_lds(const int32_t *store, long long store_stride,
-                                                    int slice_coefs, int coef_off, int llh, int llw,
-                                                    int ys, int xs, const int32_t *qidx, int qm0,
-                                                    int32_t *ll_plane, long long ll_stride, unsigned *err) {
+__device__ __forceinline__ void ld_ll_lds_body(int pic, const int32_t *store, long long store_stride,
+                                               int slice_coefs, int coef_off, int llh, int llw,
+                                               int ys, int xs, const int32_t *qidx, int qm0,
+                                               int32_t *ll_plane, long long ll_stride, unsigned *err) {
   extern __shared__ int rs[];
-  const int pic = blockIdx.x;
   const int32_t *st = store + (size_t)pic * store_stride;
   const int32_t *qi = qidx + (size_t)pic * ys * xs;
   const int bh = llh / ys, bw = llw / xs; // LL block of one slice
@@ -1566,6 +1565,36 @@ __global__ __launch_bounds__(1024) void k_ld_ll_lds(const int32_t *store, long l
   for (int i = threadIdx.x; i < llh * llw; i += blockDim.x) ll[i] = rs[i];
 }
 
+__global__ __launch_bounds__(1024) void k_ld_ll_lds(const int32_t *store, long long store_stride,
+                                                    int slice_coefs, int coef_off, int llh, int llw,
+                                                    int ys, int xs, const int32_t *qidx, int qm0,
+                                                    int32_t *ll_plane, long long ll_stride, unsigned *err) {
+  ld_ll_lds_body(blockIdx.x, store, store_stride, slice_coefs, coef_off, llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
+}
+// the three components of a picture in one launch (grid y): the wavefront is a chain of barriers, not work
+__global__ __launch_bounds__(1024) void k_ld_ll_lds3(const LdLl3Params p) {
+  const int c = blockIdx.y;
+  ld_ll_lds_body(blockIdx.x, p.store, p.store_stride, p.slice_coefs, c == 0 ? p.coef_off[0] : c == 1 ? p.coef_off[1] : p.coef_off[2],
+                 c == 0 ? p.llh[0] : c == 1 ? p.llh[1] : p.llh[2], c == 0 ? p.llw[0] : c == 1 ? p.llw[1] : p.llw[2], p.ys, p.xs,
+                 p.qidx, p.qm0, c == 0 ? p.ll_plane[0] : c == 1 ? p.ll_plane[1] : p.ll_plane[2],
+                 c == 0 ? p.ll_stride[0] : c == 1 ? p.ll_stride[1] : p.ll_stride[2], p.err);
+}
+bool vc2_launch_ld_ll3(Launcher &L, const LdLl3Params &p, int n_pictures, hipStream_t s) {
+  size_t bytes = 0;
+  int reach = 0;
+  for (int c = 0; c < 3; ++c) {
+    if (p.llh[c] < 1 || p.llw[c] < 1) return false;
+    bytes = std::max(bytes, (size_t)p.llh[c] * p.llw[c] * 4);
+    reach = std::max(reach, std::min(p.llh[c], p.llw[c]));
+  }
+  if (bytes > 150 * 1024) return false;
+  vc2_prof_begin(L, "ld_ll_predict", s);
+  vc2_allow_lds((const void *)k_ld_ll_lds3, 150 * 1024);
+  const int threads = reach <= 256 ? 256 : reach <= 512 ? 512 : 1024; // an anti-diagonal never has more samples; fewer wavefronts, cheaper barriers
+  hipLaunchKernelGGL(k_ld_ll_lds3, dim3(n_pictures, 3), dim3(threads), bytes, s, p);
+  vc2_prof_end(L, s);
+  return true;
+}
 void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride, int slice_coefs,
                       int coef_off, int n0, int llh, int llw, int ys, int xs, const int32_t *qidx,
                       int qm0, int32_t *ll_plane, long long ll_stride, int n_pictures, unsigned *err,
