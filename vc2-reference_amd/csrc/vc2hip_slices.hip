@@ -2083,9 +2083,58 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   auto ly = [&](int j) -> int { return rec[p.comp_off[0] + j]; };
   auto lc = [&](int j) -> int { return rec[p.comp_off[1 + (j & 1)] + (j >> 1)]; };
+  const int split = intlog2_dev(8 * size - 7);
+  const int n_y = p.comp_n[0], n_uv = 2 * p.comp_n[1];
+  if (n_y <= 512 && n_uv <= 512) { // one round per stream: codes and lengths once, in registers
+    // codes + lengths of eight values of a stream, computed (LD magnitudes are small, a table would cost more to load)
+    auto codes = [&](Coef8 &c, const int (&raw)[8], int j0, int n) {
+      c.sum = 0; c.last_end = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int v = raw[k], nb = svlc_bits(v);
+        unsigned code = svlc_code(v);
+        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; code = 1; v = 0; }
+        c.nb[k] = j0 + k < n ? nb : 0;
+        c.code[k] = code;
+        c.sum += c.nb[k];
+        if (v != 0 && c.nb[k]) c.last_end = c.sum;
+      }
+    };
+    const int j0 = lane * 8;
+    int raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = 0;
+    if (j0 < n_y) { const int4 a = *(const int4 *)(rec + p.comp_off[0] + j0); raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; }
+    if (j0 + 4 < n_y) { const int4 a = *(const int4 *)(rec + p.comp_off[0] + j0 + 4); raw[4] = a.x; raw[5] = a.y; raw[6] = a.z; raw[7] = a.w; }
+    Coef8 cy, cc;
+    codes(cy, raw, j0, n_y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = 0;
+    if (j0 < n_uv) { // U and V alternate (n_uv is a multiple of 8)
+      const int4 a = *(const int4 *)(rec + p.comp_off[1] + j0 / 2), b = *(const int4 *)(rec + p.comp_off[2] + j0 / 2);
+      raw[0] = a.x; raw[1] = b.x; raw[2] = a.y; raw[3] = b.y; raw[4] = a.z; raw[5] = b.z; raw[6] = a.w; raw[7] = b.w;
+    }
+    codes(cc, raw, j0, n_uv);
+    const int iy = wave_incl_scan(cy.sum, lane), ic = wave_incl_scan(cc.sum, lane);
+    const int ybits = wave_max(cy.last_end ? iy - cy.sum + cy.last_end : 0);
+    const int cbits = wave_max(cc.last_end ? ic - cc.sum + cc.last_end : 0);
+    const int uvbits = 8 * size - 7 - split - ybits;
+    if (uvbits < cbits) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_LD_TOOBIG); return; }
+    if (lane == 0) {
+      put_code(img, 0, (unsigned)p.qidx[(size_t)pic * p.n_slices + slice] & 127u, 7);
+      if (split > 0) put_code(img, 7, (unsigned)ybits, split);
+    }
+    // bounded writes: codes wholly past the bound are 1-bits of trailing zeros and are dropped
+    // (VLC.cpp:151-172); flush pads the bound with 0 bits, which the zeroed image already holds
+    write8(img, 7 + split + iy - cy.sum, 7 + split + ybits, cy);
+    write8(img, 7 + split + ybits + ic - cc.sum, 7 + split + ybits + uvbits, cc);
+    wave_lds_sync();
+    uint8_t *out = p.payload + (size_t)pic * p.payload_stride + p.offsets[slice];
+    for (int k = lane; k < size; k += 64) out[k] = (uint8_t)(img[k >> 2] >> (24 - 8 * (k & 3)));
+    return;
+  }
   const int ybits = component_bits<false, false>(ly, p.comp_n[0], 1, 0, nullptr, lane, nullptr, 0, p.err);
   const int cbits = component_bits<false, false>(lc, 2 * p.comp_n[1], 1, 0, nullptr, lane, nullptr, 0, p.err);
-  const int split = intlog2_dev(8 * size - 7);
   const int uvbits = 8 * size - 7 - split - ybits;
   if (uvbits < cbits) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_LD_TOOBIG); return; }
   if (lane == 0) {
