@@ -1778,11 +1778,17 @@ __global__ __launch_bounds__(256) void k_ld_tables(const LdEncParams p) {
 // until the index is final.
 constexpr int LD_SLOTS = 16; // candidates of round r: 4 r + (0: trial, 1: trial - step, 2: trial + step); 15: an index that was no trial
 
-template <int CPL, bool DUAL>
+// ROWS: one workgroup per row of slices of a picture walks the row (d = pictures in the batch, see k_ld_search_rows)
+template <int CPL, bool DUAL, bool ROWS>
 __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs_pad) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int pic = blockIdx.y;
+  // ROWS: workgroup = row * P8 + picture with P8 = pictures rounded up to the 8 XCDs.  Workgroups go round-robin to the
+  // XCDs and each XCD starts its share in order, so all rows of a picture run on one XCD (the hand-over between rows
+  // stays in that XCD's L2: measured 3.2 ms against 3.7 ms with rows scattered) and the row above always started first.
+  const int p8 = (d + 7) & ~7;
+  const int pic = ROWS ? (int)blockIdx.x % p8 : (int)blockIdx.y;
+  if (ROWS && pic >= d) return;
   const int n_y = p.comp_n[0], n_c = p.comp_n[1], n_uv = 2 * n_c, n0y = p.comp_n0[0], n0c = p.comp_n0[1];
   const unsigned char *band_y = (const unsigned char *)lds_i, *band_uv = band_y + 512;
   const uint4 *qs = (const uint4 *)(lds_i + 256);
@@ -1792,14 +1798,26 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
   int *llq = rsS + LD_SLOTS * rs_pad;      // per candidate: quantised LL residuals, laid out like llv
   int *llpack = llq + LD_SLOTS * 16;       // per candidate and component: code lengths of the residuals, a byte each
   int *acres = llpack + LD_SLOTS * 8;      // per candidate: luma count, chroma count (behind the LL blocks), bad index
-  const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x, sh = d - sv, slice = sv * p.xs + sh;
-  int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  const int sv = ROWS ? (int)blockIdx.x / p8 : max(0, d - (p.xs - 1)) + (int)blockIdx.x;
+  const int sh_first = ROWS ? 0 : d - sv, sh_end = ROWS ? p.xs : sh_first + 1;
   constexpr bool dual = DUAL; // n_y, n_uv <= 32 CPL: luma on lanes 0-31, chroma on lanes 32-63, one pass per candidate
   const bool ch = dual && lane >= 32;
   // slot A: luma (dual: chroma on the upper lanes); slot B: chroma when not dual
   const int j0 = (dual ? lane & 31 : lane) * CPL;
   const int nA = ch ? n_uv : n_y, nB = dual ? 0 : n_uv;
   const int llA = ch ? 2 * n0c : n0y, llB = 2 * n0c; // stream indices below these are LL
+  for (int i = threadIdx.x * 4; i < LD_TAB_INTS; i += blockDim.x * 4) *(int4 *)(lds_i + i) = *(const int4 *)(p.tab + i);
+  __syncthreads();
+  int qmA[CPL], qmB[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    qmA[k] = qmt[(ch ? band_uv : band_y)[min(j0 + k, 511)]];
+    qmB[k] = qmt[band_uv[min(j0 + k, 511)]];
+  }
+  const int qm0 = qmt[0];
+  for (int sh = sh_first; sh < sh_end; ++sh) {
+  const int slice = sv * p.xs + sh;
+  int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   int vA[CPL], vB[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) vA[k] = vB[k] = 0;
@@ -1824,6 +1842,14 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
   int bytes = 0, qfix = 0;
   if (p.search) bytes = p.slice_bytes[slice]; else qfix = p.qidx[(size_t)pic * p.n_slices + slice];
   if (wave == 0) { // reconstructed LL samples around the slice's blocks (row above: bw + 1 samples, then the column to the left), into every candidate's copy
+    if (ROWS && sv > 0) { // the slice above (and with it the one above-left) is final once its index is published
+      const int32_t *flag = p.qidx + (size_t)pic * p.n_slices + (size_t)(sv - 1) * p.xs + sh;
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 18)) { atomicOr(p.err, VC2_DEVERR_QINDEX); break; } // never on a live GPU; no hang if the row above died
+      }
+    }
     const int h0 = p.bh[0] + p.bw[0] + 1, h1 = p.bh[1] + p.bw[1] + 1, h2 = p.bh[2] + p.bw[2] + 1;
     const int o1 = (p.bh[0] + 1) * (p.bw[0] + 1), o2 = o1 + (p.bh[1] + 1) * (p.bw[1] + 1);
     for (int e = lane; e < h0 + h1 + h2; e += 64) { // one load per lane, all components in flight together
@@ -1834,7 +1860,9 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
       const int bh = c == 0 ? p.bh[0] : c == 1 ? p.bh[1] : p.bh[2], bw = c == 0 ? p.bw[0] : c == 1 ? p.bw[1] : p.bw[2];
       const int yy = i <= bw ? 0 : i - bw, xx = i <= bw ? i : 0;
       const int y = sv * bh - 1 + yy, x = sh * bw - 1 + xx;
-      const int val = (y >= 0 && x >= 0) ? res[(size_t)y * llw + x] : 0;
+      int val = 0;
+      if (y >= 0 && x >= 0) // ROWS: written by other workgroups of this launch -- device-coherent accesses, no cache maintenance
+        val = ROWS ? __hip_atomic_load(res + (size_t)y * llw + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : res[(size_t)y * llw + x];
       const int at = (c == 0 ? 0 : c == 1 ? o1 : o2) + yy * (bw + 1) + xx;
       for (int sl = 0; sl < LD_SLOTS; ++sl) rsS[sl * rs_pad + at] = val;
     }
@@ -1847,15 +1875,7 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
       }
     }
   }
-  for (int i = threadIdx.x * 4; i < LD_TAB_INTS; i += blockDim.x * 4) *(int4 *)(lds_i + i) = *(const int4 *)(p.tab + i);
   __syncthreads();
-  int qmA[CPL], qmB[CPL];
-#pragma unroll
-  for (int k = 0; k < CPL; ++k) {
-    qmA[k] = qmt[(ch ? band_uv : band_y)[min(j0 + k, 511)]];
-    qmB[k] = qmt[band_uv[min(j0 + k, 511)]];
-  }
-  const int qm0 = qmt[0];
 
   // component c's LL chain of candidate slot sl at index tq: raster scan, prediction from the reconstructed samples
   auto chain = [&](int sl, int c, int tq) {
@@ -2010,7 +2030,7 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
         else { trial += delta; cand = 2; }
       }
     }
-    if (threadIdx.x == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
+    if (!ROWS && threadIdx.x == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
   } else {
     q = qfix;
   }
@@ -2019,8 +2039,13 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
     run_round(slot, 1, q, 0);
     if (acres[slot * 4 + 2]) bad = true;
   }
-  if (bad) { if (threadIdx.x == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); return; }
-  if (wave == 1) { // the quantised slice: LL residuals from the chains, everything else through the table
+  if (bad) {
+    if (threadIdx.x == 0) atomicOr(p.err, VC2_DEVERR_QINDEX);
+    if (!ROWS) return;
+    q = 0; // the rows below still get their flag
+  }
+  if (bad) {
+  } else if (wave == 1) { // the quantised slice: LL residuals from the chains, everything else through the table
     auto quant8 = [&](const int (&v)[CPL], const int (&qm)[CPL], int n_ll, const int *ll, int (&out)[CPL]) {
 #pragma unroll
       for (int k = 0; k < CPL; ++k) {
@@ -2061,15 +2086,27 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
       const int llw = p.ll_w[c], bh = p.bh[c], bw = p.bw[c], pitch = bw + 1;
       for (int i = lane; i < bh * bw; i += 64) {
         const int yy = i / bw, xx = i - yy * bw;
-        res[(size_t)(sv * bh + yy) * llw + sh * bw + xx] = r0[(yy + 1) * pitch + xx + 1];
+        int32_t *at = res + (size_t)(sv * bh + yy) * llw + sh * bw + xx;
+        if (ROWS) __hip_atomic_store(at, r0[(yy + 1) * pitch + xx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *at = r0[(yy + 1) * pitch + xx + 1];
       }
       r0 += (bh + 1) * pitch;
     }
   }
+  if (ROWS && wave == 0) { // publish: the reconstructed samples first, then the index as the row's progress flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the coherent stores above are acknowledged (no cache write-back: they went through)
+    if (lane == 0) __hip_atomic_store(p.qidx + (size_t)pic * p.n_slices + slice, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  } // next slice of the row
 }
 
 template <int CPL, bool DUAL>
-__global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams p, int d, int rs_pad) { ld_diag_body<CPL, DUAL>(p, d, rs_pad); }
+__global__ __launch_bounds__(256) void k_ld_quantise_diag_fast(const LdEncParams p, int d, int rs_pad) { ld_diag_body<CPL, DUAL, false>(p, d, rs_pad); }
+// The whole search in one launch: workgroup (row sv, picture) walks its row of slices left to right; slice (sv, sh) starts
+// when row sv - 1 has published slice sh (p.qidx doubles as the progress flag: -1 until the slice is final).  A workgroup
+// only ever waits for one that was dispatched before it; the wait is bounded all the same (error flag, no hang).
+template <int CPL, bool DUAL>
+__global__ __launch_bounds__(256) void k_ld_search_rows(const LdEncParams p, int n_pictures, int rs_pad) { ld_diag_body<CPL, DUAL, true>(p, n_pictures, rs_pad); }
 // LD slice writer: one wavefront per slice, image assembled in LDS as big-endian words
 __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   extern __shared__ unsigned lds_u[];
@@ -2162,13 +2199,28 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     const int reach = small ? 128 : 256;
     const bool dual = p.comp_n[0] <= reach && 2 * p.comp_n[1] <= reach; // half a wavefront covers a stream
     hipLaunchKernelGGL(k_ld_tables, dim3(1), dim3(256), 0, s, p);
+    static const int rows = [] { const char *e = getenv("VC2HIP_LD_ROWS"); return e ? atoi(e) : 1; }();
+    if (rows && p.search) {
+      // 3 wavefronts (LL chains + 2 x subbands) measured fastest: 3.2 ms per 16 HD pictures, 4 wavefronts 3.6, one launch per anti-diagonal 3.7-3.9
+      static const int nwr = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : v > 4 ? 4 : v; }();
+      (void)hipMemsetAsync(p.qidx, 0xFF, (size_t)n_pictures * p.n_slices * sizeof(int32_t), s); // progress flags: -1 = not final
+      const dim3 grid(p.ys * ((n_pictures + 7) & ~7)), blk(64 * nwr);
+      if (small && dual) hipLaunchKernelGGL((k_ld_search_rows<4, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      else if (small) hipLaunchKernelGGL((k_ld_search_rows<4, false>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      else if (dual) hipLaunchKernelGGL((k_ld_search_rows<8, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      else hipLaunchKernelGGL((k_ld_search_rows<8, false>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      vc2_prof_end(L, s);
+      return;
+    }
     for (int d = 0; d < p.ys + p.xs - 1; ++d) {
       const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
       const dim3 grid(cnt, n_pictures);
-      if (small && dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, true>), grid, dim3(256), lds, s, p, d, rs_pad); // 75 registers: forcing 64 for full residency of a 16-picture diagonal spills and measured slower
-      else if (small) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, false>), grid, dim3(256), lds, s, p, d, rs_pad);
-      else if (dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, true>), grid, dim3(256), lds, s, p, d, rs_pad);
-      else hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, false>), grid, dim3(256), lds, s, p, d, rs_pad);
+      static const int nwv = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > 4 ? 4 : v; }();
+      const dim3 blk(64 * nwv);
+      if (small && dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, true>), grid, blk, lds, s, p, d, rs_pad); // 75 registers: forcing 64 for full residency of a 16-picture diagonal spills and measured slower
+      else if (small) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, false>), grid, blk, lds, s, p, d, rs_pad);
+      else if (dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, true>), grid, blk, lds, s, p, d, rs_pad);
+      else hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, false>), grid, blk, lds, s, p, d, rs_pad);
     }
     vc2_prof_end(L, s);
     return;
