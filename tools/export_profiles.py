@@ -4,6 +4,7 @@ HBM traffic per launch from the two PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950 c
 /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-byte request of wide coalesced reads).
 
   python tools/export_profiles.py <tag> <stats_dir> <fetch_dir> <write_dir>
+  python tools/export_profiles.py <tag> <stats_dir>                          (kernel statistics only)
 """
 import csv, json, sqlite3, sys
 
@@ -20,7 +21,7 @@ def short(name):
     return None
 
 
-def main(tag, stats, fetch, write):
+def main(tag, stats, fetch=None, write=None):
     c = sqlite3.connect(f'gpurun_out/{stats}/run_results.db')
     rows = c.execute("select name,count(*),sum(duration),avg(duration),min(duration),max(duration) from kernels "
                      "group by name order by sum(duration) desc").fetchall()
@@ -30,6 +31,8 @@ def main(tag, stats, fetch, write):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r[0], r[1], int(r[2]), round(r[3], 1), round(100 * r[2] / tot, 2), int(r[4]), int(r[5])])
+    if fetch is None:
+        return
     out = {}
     for name, d in (('FETCH_SIZE', fetch), ('WRITE_SIZE', write)):
         c = sqlite3.connect(f'gpurun_out/{d}/run_results.db')

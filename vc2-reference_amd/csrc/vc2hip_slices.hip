@@ -1081,7 +1081,7 @@ __device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, 
 
 // UNP_N coefficients are staged per lane and round: 16 = 64-byte runs, 32 = whole 128-byte lines (no
 // read-for-ownership of the other half line, but twice the LDS).
-template <int UNP_N>
+template <int UNP_N, bool NT = true>
 __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   constexpr int UNP_PITCH = UNP_N + 4; // ints per staging row, 16-byte aligned rows
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
@@ -1137,8 +1137,10 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
       if (dst && c < room) {
         const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
         int *d = dst + base + c;
-        __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
-        __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+        if constexpr (NT) {
+          __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
+          __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+        } else *(int4 *)d = v;
       }
     }
     wave_lds_sync();
@@ -1148,7 +1150,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "hq_unpack", s);
   static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 0; }(); // A/B on MI355X: 64-byte runs 0.59 ms, 128-byte runs 0.64 ms per 16 UHD pictures (twice the staging LDS)
-  if (wide) hipLaunchKernelGGL(k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  static const int nt = [] { const char *e = getenv("VC2HIP_UNPACK_NT"); return e ? atoi(e) : 1; }();
+  if (!nt) hipLaunchKernelGGL((k_hq_unpack<16, false>), dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  else if (wide) hipLaunchKernelGGL(k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_hq_unpack<16>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
