@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, 
 }
 
 // UNP_N coefficients are staged per lane and round: 16 = 64-byte runs, 32 = whole 128-byte lines (no
-// read-for-ownership of the other half line, but twice the LDS).
+// read-for-ownership of the other half line, but twice the LDS: 4 instead of 6 wavefronts per SIMD).
 template <int UNP_N, bool NT = true>
 __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   constexpr int UNP_PITCH = UNP_N + 4; // ints per staging row, 16-byte aligned rows
@@ -1149,7 +1149,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "hq_unpack", s);
-  static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 0; }(); // A/B on MI355X: 64-byte runs 0.59 ms, 128-byte runs 0.64 ms per 16 UHD pictures (twice the staging LDS)
+  // A/B on MI355X, 16 UHD pictures: whole 128-byte lines (32 coefficients per round) 0.48 ms, 64-byte runs 0.52 ms (the other
+  // half of every line is fetched back: FETCH_SIZE ~1 GB for 0.15 GB of payload), plain instead of non-temporal stores 0.69 ms
+  static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 1; }();
   static const int nt = [] { const char *e = getenv("VC2HIP_UNPACK_NT"); return e ? atoi(e) : 1; }();
   if (!nt) hipLaunchKernelGGL((k_hq_unpack<16, false>), dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   else if (wide) hipLaunchKernelGGL(k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
