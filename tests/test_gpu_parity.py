@@ -445,6 +445,38 @@ LD_CASES = [  # w, h, cf, bits, word_bytes, kernel, depth, u, a, bytes
 ]
 
 
+@pytest.mark.parametrize("n", [3, 11])
+def test_ld_batch_device_resident(hip, oracle, n):
+    """LD batches whose size is no multiple of the 8 XCDs (the index search numbers its workgroups row * 8k + picture):
+    every picture of the batch equals the oracle's stream payload, and the batch decodes to the oracle's pictures."""
+    import torch
+    w, h, depth, nbytes = 256, 120, 3, 12000
+    raw = b"".join(synth(w, h, "422", 8, 100 + k, word_bytes=1) for k in range(n))
+    p = make_params(w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=nbytes, word_bytes=1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=nbytes, word_bytes=1)
+    rb = hip.raw_picture_bytes(fmt)
+    assert rb * n == len(raw)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    assert d_len.cpu().tolist() == [nbytes] * n
+    pay = d_pay.cpu().numpy()
+    out = d_out.cpu().numpy().tobytes()
+    for k in range(n):
+        one = raw[k * rb:(k + 1) * rb]
+        stream = oracle.encode_stream(p, one, 1)
+        assert bytes(pay[k * stride:k * stride + nbytes]) == stream[-13 - nbytes:-13], f"picture {k}"
+        dec, _ = oracle.decode_stream(p, stream, 1)
+        assert out[k * rb:(k + 1) * rb] == dec, f"picture {k}"
+
+
 @pytest.mark.parametrize("case", LD_CASES, ids=lambda c: f"{c[5]}_{c[2]}_{c[0]}x{c[1]}")
 def test_ld_encode_matches_oracle(hip, oracle, case):
     w, h, cf, bits, wb, kernel, depth, u, a, nbytes = case
