@@ -426,6 +426,9 @@ __device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const 
 __device__ __forceinline__ void put_byte(unsigned *img, int off, unsigned b) { atomicOr(&img[off >> 2], b << (24 - 8 * (off & 3))); }
 
 
+__device__ __forceinline__ void bits8_tab(const int *src, int j0, int n, const unsigned char *band_lut, const uint4 *qtab,
+                                          unsigned *err, int &sum, int &last_end);
+
 // W lanes work on one slice: 64 (a wavefront per slice, any geometry) or, for small slices, 32 / 16 with two / four
 // slices per wavefront, so that a slice of e.g. 128 + 2 x 64 coefficients (1080p, -u 2 -a 4) still fills its lanes.
 template <int W>
@@ -449,6 +452,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   unsigned *lut = lds_u + 4 * S * img_words;
   unsigned char *band_y = (unsigned char *)(lut + VLC_LUT_N), *band_c = band_y + 512;
   uint4 *qtab = (uint4 *)(band_c + 256) + (wave * S + seg) * 32;
+  // slices of up to 2048 coefficients per component (more than one round of 512): the same tables, longer (launcher: big_lut)
+  unsigned char *big_y = (unsigned char *)((uint4 *)(band_c + 256) + 4 * S * 32), *big_c = big_y + 2048;
   const bool active = slice < p.n_slices;
   const bool fast = p.comp_n[0] <= 8 * W && p.comp_n[1] <= 4 * W && p.comp_n[1] == p.comp_n[2];
   for (int i = sl; i < img_words; i += W) img[i] = 0;
@@ -458,6 +463,15 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
     for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
     for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+  }
+  const bool mid = W == 64 && !fast && p.quantise && p.big_lut;
+  if (mid) {
+    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
+    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
+    for (int j = threadIdx.x; j < 2048; j += blockDim.x) {
+      big_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
+      big_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+    }
   }
   if (p.quantise) {
     if (active && sl < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
@@ -527,22 +541,25 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int32_t *src = rec + p.comp_off[cc];
         Coef8 c;
         int run = 0, count = 0;
+        const unsigned char *band_lut = cc ? big_c : big_y;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          if (mid) bits8_tab(src, r0 + lane * 8, n, band_lut, qtab, p.err, c.sum, c.last_end); // lengths only
+          else if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           count = max(count, wave_max(c.last_end ? run + incl - c.sum + c.last_end : 0));
-          run += __shfl(incl, 63);
+          run += __builtin_amdgcn_readlane(incl, 63);
         }
         bytes[cc] = comp_len(count);
         if (cc == 2) bytes[2] = cbr_v(bytes[2]);
         run = 0;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          if (mid) load8_tab(c, src, r0 + lane * 8, n, band_lut, qtab, p.err, lut);
+          else if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           write8(img, 8 * (base + 1) + run + incl - c.sum, 8 * (base + 1 + bytes[cc]), c);
-          run += __shfl(incl, 63);
+          run += __builtin_amdgcn_readlane(incl, 63);
         }
         if (lane == 0) put_byte(img, base, (unsigned)(bytes[cc] / p.scalar));
         base += 1 + bytes[cc];
@@ -624,9 +641,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
 }
 
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
-static size_t pack_lds(int prefix, int scalar, int slices_per_wave) {
+static size_t pack_lds(int prefix, int scalar, int slices_per_wave, bool big_lut = false) {
   const size_t img_words = ((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2;
-  return 4 * slices_per_wave * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * (size_t)slices_per_wave * 32 * 16;
+  return 4 * slices_per_wave * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * (size_t)slices_per_wave * 32 * 16 + (big_lut ? 4096 : 0);
 }
 size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
@@ -642,7 +659,10 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
     else if (p.comp_n[0] <= 256 && p.comp_n[1] <= 128 && bands <= 32 && pack_lds(p.prefix, p.scalar, 2) <= 144 * 1024) W = 32;
   }
   const int S = 64 / W;
-  const size_t lds = pack_lds(p.prefix, p.scalar, S);
+  const bool one_round = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && same_c;
+  p.big_lut = W == 64 && !one_round && same_c && p.comp_n[0] <= 2048 && p.comp_n[1] <= 2048 && 3 * p.depth + 1 <= 32 &&
+              pack_lds(p.prefix, p.scalar, 1, true) <= 144 * 1024;
+  const size_t lds = pack_lds(p.prefix, p.scalar, S, p.big_lut);
   const int tiles = (p.n_slices + 4 * S - 1) / (4 * S);
   vc2_prof_begin(L, "hq_pack", s);
   if (W == 16) {
