@@ -1162,8 +1162,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
         int *d = dst + base + c;
         if constexpr (NT) {
-          __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
-          __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+          typedef int v4i __attribute__((ext_vector_type(4)));
+          const v4i vv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)d); // one 16-byte streaming global store per lane
         } else *(int4 *)d = v;
       }
     }
@@ -1481,8 +1482,9 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
       if (rec && c < room) {
         const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
         int *d = rec + p.comp_off[0] + base + c;
-        __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
-        __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i vv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)d);
       }
     }
     wave_lds_sync();
