@@ -40,53 +40,52 @@ struct Launcher {
   const char *last_name = nullptr;
   std::string launch_error;
   std::vector<ProfEntry> entries;
-  // One event after every launch; a launch that directly follows another on the same stream takes the previous
-  // launch's end event as its start (half the event records, and the stream never idles between two records).
-  struct Pending { int entry, a, b; }; // indices into `used`
+  // A start / stop event pair per kernel launch, attached to the launch itself (see VC2_LAUNCH)
+  struct Pending { int entry; hipEvent_t a, b; };
   std::vector<Pending> pending;
-  std::vector<hipEvent_t> used, pool;
-  int last_end = -1;
-  hipStream_t last_stream = nullptr;
-  int record(hipStream_t s) {
+  std::vector<hipEvent_t> pool;
+  int cur_entry = -1;
+  hipEvent_t get() {
     hipEvent_t e;
     if (!pool.empty()) { e = pool.back(); pool.pop_back(); }
     else (void)hipEventCreate(&e);
-    (void)hipEventRecord(e, s);
-    used.push_back(e);
-    return (int)used.size() - 1;
+    return e;
   }
   void collect() {
     for (auto &p : pending) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, used[p.a], used[p.b]) == hipSuccess) { entries[p.entry].ms += ms; entries[p.entry].launches++; }
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { entries[p.entry].ms += ms; entries[p.entry].launches++; }
+      pool.push_back(p.a);
+      pool.push_back(p.b);
     }
     pending.clear();
-    pool.insert(pool.end(), used.begin(), used.end());
-    used.clear();
-    last_end = -1;
   }
 };
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
+  (void)s;
   L.last_name = name;
   if (!L.on) return;
   int idx = -1;
   for (size_t i = 0; i < L.entries.size(); ++i) if (L.entries[i].name == name) { idx = (int)i; break; }
   if (idx < 0) { L.entries.push_back(ProfEntry{name, 0, 0}); idx = (int)L.entries.size() - 1; }
-  const int a = (L.last_end >= 0 && L.last_stream == s) ? L.last_end : L.record(s);
-  L.pending.push_back(Launcher::Pending{idx, a, -1});
+  L.cur_entry = idx;
+}
+void vc2_prof_pair(Launcher &L, hipEvent_t *a, hipEvent_t *b) {
+  *a = *b = nullptr;
+  if (!L.on || L.cur_entry < 0) return;
+  *a = L.get();
+  *b = L.get();
+  L.pending.push_back(Launcher::Pending{L.cur_entry, *a, *b});
 }
 void vc2_prof_end(Launcher &L, hipStream_t s) {
-  // every launcher calls this right after hipLaunchKernelGGL: catch launch failures (bad grid / LDS size)
+  (void)s;
+  // every launcher calls this right after its launches: catch launch failures (bad grid / LDS size)
   const hipError_t le = hipGetLastError();
   if (le != hipSuccess && L.launch_error.empty())
     L.launch_error = std::string("kernel launch failed (") + (L.last_name ? L.last_name : "?") + "): " + hipGetErrorString(le);
-  if (!L.on) return;
-  L.pending.back().b = L.record(s);
-  L.last_end = L.pending.back().b;
-  L.last_stream = s;
+  L.cur_entry = -1;
 }
-// operations enqueued outside the launchers (copies, memsets) must not be billed to the next kernel
-void vc2_prof_break(Launcher &L) { L.last_end = -1; }
+void vc2_prof_break(Launcher &L) { (void)L; }
 
 // ------------------------------------------------------------------------------------------
 // context

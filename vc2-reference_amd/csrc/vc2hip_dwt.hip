@@ -334,11 +334,11 @@ static void launch_level(Launcher &L, const LevelParams &p, int n_pictures, hipS
   if constexpr (INV) {
     vc2_allow_lds((const void *)k_inv_level<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
-    hipLaunchKernelGGL((k_inv_level<K, EDGE>), grid, block, lds, s, p);
+    VC2_LAUNCH(L, (k_inv_level<K, EDGE>), grid, block, lds, s, p);
   } else {
     vc2_allow_lds((const void *)k_fwd_level<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
-    hipLaunchKernelGGL((k_fwd_level<K, EDGE>), grid, block, lds, s, p);
+    VC2_LAUNCH(L, (k_fwd_level<K, EDGE>), grid, block, lds, s, p);
   }
   vc2_prof_end(L, s);
 }

@@ -760,15 +760,15 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
     if (small) {
       vc2_allow_lds((const void *)k_inv_fast<K, EDGE, true>, 160 * 1024);
-      hipLaunchKernelGGL((k_inv_fast<K, EDGE, true>), grid, block, lds, s, p);
+      VC2_LAUNCH(L, (k_inv_fast<K, EDGE, true>), grid, block, lds, s, p);
     } else {
       vc2_allow_lds((const void *)k_inv_fast<K, EDGE, false>, 160 * 1024);
-      hipLaunchKernelGGL((k_inv_fast<K, EDGE, false>), grid, block, lds, s, p);
+      VC2_LAUNCH(L, (k_inv_fast<K, EDGE, false>), grid, block, lds, s, p);
     }
   } else {
     vc2_allow_lds((const void *)k_fwd_fast<K, EDGE>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
-    hipLaunchKernelGGL((k_fwd_fast<K, EDGE>), grid, block, lds, s, p);
+    VC2_LAUNCH(L, (k_fwd_fast<K, EDGE>), grid, block, lds, s, p);
   }
   vc2_prof_end(L, s);
 }

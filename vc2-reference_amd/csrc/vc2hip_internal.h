@@ -10,6 +10,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -165,6 +166,16 @@ struct CbrParams {
 // launchers (implemented in the kernel TUs)
 // ------------------------------------------------------------------------------------------
 struct Launcher; // profiling hook, defined in vc2hip_api.hip
+// Every kernel launch goes through VC2_LAUNCH between vc2_prof_begin / vc2_prof_end.  With profiling on it carries
+// its own start / stop events (hipExtLaunchKernelGGL: the timestamps of the dispatch packet itself, no extra packets
+// on the stream between kernels); off, the events are null and it is a plain launch.
+void vc2_prof_pair(Launcher &L, hipEvent_t *a, hipEvent_t *b);
+#define VC2_LAUNCH(L, kernel, grid, block, lds, s, ...)                                        \
+  do {                                                                                         \
+    hipEvent_t vc2_ev_a_, vc2_ev_b_;                                                           \
+    vc2_prof_pair(L, &vc2_ev_a_, &vc2_ev_b_);                                                  \
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, s, vc2_ev_a_, vc2_ev_b_, 0, __VA_ARGS__);  \
+  } while (0)
 
 // Raise a kernel's dynamic-LDS limit to `bytes`, once per (kernel, device): the attribute belongs to the
 // function on the CURRENT device, and one process may drive several GPUs (the tools' --gpus N).

@@ -667,16 +667,16 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
   vc2_prof_begin(L, "hq_pack", s);
   if (W == 16) {
     vc2_allow_lds((const void *)k_hq_pack<16>, 144 * 1024);
-    hipLaunchKernelGGL(k_hq_pack<16>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+    VC2_LAUNCH(L, k_hq_pack<16>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
   } else if (W == 32) {
     vc2_allow_lds((const void *)k_hq_pack<32>, 144 * 1024);
-    hipLaunchKernelGGL(k_hq_pack<32>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+    VC2_LAUNCH(L, k_hq_pack<32>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
   } else if (p.big_lut) {
     vc2_allow_lds((const void *)k_hq_pack<64, true>, 144 * 1024);
-    hipLaunchKernelGGL((k_hq_pack<64, true>), dim3(tiles, n_pictures), dim3(256), lds, s, p);
+    VC2_LAUNCH(L, (k_hq_pack<64, true>), dim3(tiles, n_pictures), dim3(256), lds, s, p);
   } else {
     vc2_allow_lds((const void *)k_hq_pack<64>, 144 * 1024);
-    hipLaunchKernelGGL(k_hq_pack<64>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+    VC2_LAUNCH(L, k_hq_pack<64>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
   }
   vc2_prof_end(L, s);
 }
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const uint32_t *sizes, uint
 void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets,
                            unsigned long long *totals, int n_slices, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "slice_offsets_scan", s);
-  hipLaunchKernelGGL(k_scan_sizes, dim3(n_pictures), dim3(1024), 0, s, sizes, offsets, totals, n_slices);
+  VC2_LAUNCH(L, k_scan_sizes, dim3(n_pictures), dim3(1024), 0, s, sizes, offsets, totals, n_slices);
   vc2_prof_end(L, s);
 }
 
@@ -748,9 +748,9 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
   const int W = force ? force : (slot_bytes <= 800 ? 16 : (slot_bytes <= 1600 ? 32 : 64));
   const int per_wg = 256 / W;
   const dim3 grid((n_slices + per_wg - 1) / per_wg, n_pictures);
-  if (W == 16) hipLaunchKernelGGL(k_compact<16>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
-  else if (W == 32) hipLaunchKernelGGL(k_compact<32>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
-  else hipLaunchKernelGGL(k_compact<64>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  if (W == 16) VC2_LAUNCH(L, k_compact<16>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  else if (W == 32) VC2_LAUNCH(L, k_compact<32>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  else VC2_LAUNCH(L, k_compact<64>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
   vc2_prof_end(L, s);
 }
 
@@ -937,7 +937,7 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t
   const int wpw = std::max(1, std::min(4, (int)((160 * 1024 - tables) / per_wave)));
   vc2_allow_lds((const void *)k_cbr_search, 160 * 1024);
   vc2_prof_begin(L, "cbr_search", s);
-  hipLaunchKernelGGL(k_cbr_search, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
+  VC2_LAUNCH(L, k_cbr_search, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
   vc2_prof_end(L, s);
 }
 
@@ -1178,9 +1178,9 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipSt
   // half of every line is fetched back: FETCH_SIZE ~1 GB for 0.15 GB of payload), plain instead of non-temporal stores 0.69 ms
   static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 1; }();
   static const int nt = [] { const char *e = getenv("VC2HIP_UNPACK_NT"); return e ? atoi(e) : 1; }();
-  if (!nt) hipLaunchKernelGGL((k_hq_unpack<16, false>), dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
-  else if (wide) hipLaunchKernelGGL(k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(k_hq_unpack<16>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  if (!nt) VC2_LAUNCH(L, (k_hq_unpack<16, false>), dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  else if (wide) VC2_LAUNCH(L, k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+  else VC2_LAUNCH(L, k_hq_unpack<16>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
 
@@ -1392,7 +1392,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   (void)workspace_bytes;
   if (E > IDX_MAX_E) {
     vc2_prof_begin(L, "slice_index_serial", s);
-    hipLaunchKernelGGL(k_index_serial, dim3((n_pictures + 63) / 64), dim3(64), 0, s, payload, payload_stride, lens,
+    VC2_LAUNCH(L, k_index_serial, dim3((n_pictures + 63) / 64), dim3(64), 0, s, payload, payload_stride, lens,
                        offsets, n_slices, prefix, scalar, err, n_pictures);
     vc2_prof_end(L, s);
     return;
@@ -1411,11 +1411,11 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     const size_t lds = stage_bytes + (size_t)ch * 2;
     if (ch == 16384) {
       vc2_allow_lds((const void *)k_index_tables_nx<16384>, lds);
-      hipLaunchKernelGGL((k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
+      VC2_LAUNCH(L, (k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
                          lens, tables, n_chunks, E, prefix, scalar, dbg);
     } else {
       vc2_allow_lds((const void *)k_index_tables_nx<32768>, lds);
-      hipLaunchKernelGGL((k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
+      VC2_LAUNCH(L, (k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
                          lens, tables, n_chunks, E, prefix, scalar, dbg);
     }
   }
@@ -1423,11 +1423,11 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 256 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
-  hipLaunchKernelGGL(k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, tables, groups, n_chunks, n_groups, E, ch);
-  hipLaunchKernelGGL(k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, tables, groups, entries, n_chunks, n_groups, E, ch);
+  VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, tables, groups, n_chunks, n_groups, E, ch);
+  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, tables, groups, entries, n_chunks, n_groups, E, ch);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
-  hipLaunchKernelGGL(k_index_emit, dim3(n_chunks, n_pictures), dim3(256), stage_bytes, s, payload,
+  VC2_LAUNCH(L, k_index_emit, dim3(n_chunks, n_pictures), dim3(256), stage_bytes, s, payload,
                      payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch);
   vc2_prof_end(L, s);
 }
@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
 
 void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "ld_unpack", s);
-  hipLaunchKernelGGL(k_ld_unpack, dim3((p.n_slices + 255) / 256, n_pictures), dim3(256), 0, s, p);
+  VC2_LAUNCH(L, k_ld_unpack, dim3((p.n_slices + 255) / 256, n_pictures), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
 
@@ -1623,7 +1623,7 @@ bool vc2_launch_ld_ll3(Launcher &L, const LdLl3Params &p, int n_pictures, hipStr
   vc2_prof_begin(L, "ld_ll_predict", s);
   vc2_allow_lds((const void *)k_ld_ll_lds3, 150 * 1024);
   const int threads = reach <= 256 ? 256 : reach <= 512 ? 512 : 1024; // an anti-diagonal never has more samples; fewer wavefronts, cheaper barriers
-  hipLaunchKernelGGL(k_ld_ll_lds3, dim3(n_pictures, 3), dim3(threads), bytes, s, p);
+  VC2_LAUNCH(L, k_ld_ll_lds3, dim3(n_pictures, 3), dim3(threads), bytes, s, p);
   vc2_prof_end(L, s);
   return true;
 }
@@ -1635,10 +1635,10 @@ void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride,
   const size_t plane_bytes = (size_t)llh * llw * 4;
   if (plane_bytes <= 150 * 1024) {
     vc2_allow_lds((const void *)k_ld_ll_lds, 150 * 1024);
-    hipLaunchKernelGGL(k_ld_ll_lds, dim3(n_pictures), dim3(1024), plane_bytes, s, store, store_stride, slice_coefs, coef_off,
+    VC2_LAUNCH(L, k_ld_ll_lds, dim3(n_pictures), dim3(1024), plane_bytes, s, store, store_stride, slice_coefs, coef_off,
                        llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
   } else {
-    hipLaunchKernelGGL(k_ld_ll, dim3(n_pictures), dim3(1024), 0, s, store, store_stride, slice_coefs, coef_off, n0,
+    VC2_LAUNCH(L, k_ld_ll, dim3(n_pictures), dim3(1024), 0, s, store, store_stride, slice_coefs, coef_off, n0,
                        llh, llw, ys, xs, qidx, qm0, ll_plane, ll_stride, err);
   }
   vc2_prof_end(L, s);
@@ -2230,17 +2230,17 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     const bool small = p.comp_n[0] <= 256 && 2 * p.comp_n[1] <= 256; // four coefficients per lane cover a stream
     const int reach = small ? 128 : 256;
     const bool dual = p.comp_n[0] <= reach && 2 * p.comp_n[1] <= reach; // half a wavefront covers a stream
-    hipLaunchKernelGGL(k_ld_tables, dim3(1), dim3(256), 0, s, p);
+    VC2_LAUNCH(L, k_ld_tables, dim3(1), dim3(256), 0, s, p);
     static const int rows = [] { const char *e = getenv("VC2HIP_LD_ROWS"); return e ? atoi(e) : 1; }();
     if (rows && p.search) {
       // 3 wavefronts (LL chains + 2 x subbands) measured fastest: 3.2 ms per 16 HD pictures, 4 wavefronts 3.6, one launch per anti-diagonal 3.7-3.9
       static const int nwr = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : v > 4 ? 4 : v; }();
       (void)hipMemsetAsync(p.qidx, 0xFF, (size_t)n_pictures * p.n_slices * sizeof(int32_t), s); // progress flags: -1 = not final
       const dim3 grid(p.ys * ((n_pictures + 7) & ~7)), blk(64 * nwr);
-      if (small && dual) hipLaunchKernelGGL((k_ld_search_rows<4, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
-      else if (small) hipLaunchKernelGGL((k_ld_search_rows<4, false>), grid, blk, lds, s, p, n_pictures, rs_pad);
-      else if (dual) hipLaunchKernelGGL((k_ld_search_rows<8, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
-      else hipLaunchKernelGGL((k_ld_search_rows<8, false>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      if (small && dual) VC2_LAUNCH(L, (k_ld_search_rows<4, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      else if (small) VC2_LAUNCH(L, (k_ld_search_rows<4, false>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      else if (dual) VC2_LAUNCH(L, (k_ld_search_rows<8, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
+      else VC2_LAUNCH(L, (k_ld_search_rows<8, false>), grid, blk, lds, s, p, n_pictures, rs_pad);
       vc2_prof_end(L, s);
       return;
     }
@@ -2249,10 +2249,10 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
       const dim3 grid(cnt, n_pictures);
       static const int nwv = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > 4 ? 4 : v; }();
       const dim3 blk(64 * nwv);
-      if (small && dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, true>), grid, blk, lds, s, p, d, rs_pad); // 75 registers: forcing 64 for full residency of a 16-picture diagonal spills and measured slower
-      else if (small) hipLaunchKernelGGL((k_ld_quantise_diag_fast<4, false>), grid, blk, lds, s, p, d, rs_pad);
-      else if (dual) hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, true>), grid, blk, lds, s, p, d, rs_pad);
-      else hipLaunchKernelGGL((k_ld_quantise_diag_fast<8, false>), grid, blk, lds, s, p, d, rs_pad);
+      if (small && dual) VC2_LAUNCH(L, (k_ld_quantise_diag_fast<4, true>), grid, blk, lds, s, p, d, rs_pad); // 75 registers: forcing 64 for full residency of a 16-picture diagonal spills and measured slower
+      else if (small) VC2_LAUNCH(L, (k_ld_quantise_diag_fast<4, false>), grid, blk, lds, s, p, d, rs_pad);
+      else if (dual) VC2_LAUNCH(L, (k_ld_quantise_diag_fast<8, true>), grid, blk, lds, s, p, d, rs_pad);
+      else VC2_LAUNCH(L, (k_ld_quantise_diag_fast<8, false>), grid, blk, lds, s, p, d, rs_pad);
     }
     vc2_prof_end(L, s);
     return;
@@ -2262,7 +2262,7 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
   vc2_allow_lds((const void *)k_ld_quantise_diag, 160 * 1024);
   for (int d = 0; d < p.ys + p.xs - 1; ++d) {
     const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
-    hipLaunchKernelGGL(k_ld_quantise_diag, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
+    VC2_LAUNCH(L, k_ld_quantise_diag, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
   }
   vc2_prof_end(L, s);
 }
@@ -2271,7 +2271,7 @@ void vc2_launch_ld_pack(Launcher &L, const LdEncParams &p, int n_pictures, hipSt
   const int wpw = vc2_waves_for_lds(per_wave);
   vc2_allow_lds((const void *)k_ld_pack, 160 * 1024);
   vc2_prof_begin(L, "ld_pack", s);
-  hipLaunchKernelGGL(k_ld_pack, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p);
+  VC2_LAUNCH(L, k_ld_pack, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p);
   vc2_prof_end(L, s);
 }
 
@@ -2338,7 +2338,7 @@ void vc2_launch_plane_to_store(Launcher &L, const int32_t *plane, int ph, int pw
                                int xs, int32_t *store, int slice_coefs, int coef_off, hipStream_t s) {
   const size_t n = (size_t)ph * pw;
   vc2_prof_begin(L, "plane_to_store", s);
-  hipLaunchKernelGGL(k_plane_to_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, plane, ph, pw, depth, ys, xs,
+  VC2_LAUNCH(L, k_plane_to_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, plane, ph, pw, depth, ys, xs,
                      store, slice_coefs, coef_off);
   vc2_prof_end(L, s);
 }
@@ -2348,7 +2348,7 @@ void vc2_launch_store_to_plane(Launcher &L, const int32_t *store, int slice_coef
                                hipStream_t s) {
   const size_t n = (size_t)ph * pw;
   vc2_prof_begin(L, "store_to_plane", s);
-  hipLaunchKernelGGL(k_store_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, store, slice_coefs, coef_off,
+  VC2_LAUNCH(L, k_store_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, store, slice_coefs, coef_off,
                      plane, ph, pw, depth, ys, xs, qidx, qmatrix, mode, err);
   vc2_prof_end(L, s);
 }
@@ -2357,7 +2357,7 @@ void vc2_launch_quantise_store(Launcher &L, int32_t *store, int n_slices, int sl
                                unsigned *err, hipStream_t s) {
   const size_t n = (size_t)n_slices * comp_n;
   vc2_prof_begin(L, "quantise_store", s);
-  hipLaunchKernelGGL(k_quantise_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, store, n_slices, slice_coefs,
+  VC2_LAUNCH(L, k_quantise_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, store, n_slices, slice_coefs,
                      comp_n, comp_off, n0, qidx, qmatrix, err);
   vc2_prof_end(L, s);
 }
@@ -2372,11 +2372,11 @@ __global__ void k_fill_u64(unsigned long long *p, unsigned long long v, size_t n
 }
 void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s) {
   vc2_prof_begin(L, "fill", s);
-  hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+  VC2_LAUNCH(L, k_fill_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
   vc2_prof_end(L, s);
 }
 void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s) {
   vc2_prof_begin(L, "fill", s);
-  hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+  VC2_LAUNCH(L, k_fill_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
   vc2_prof_end(L, s);
 }
