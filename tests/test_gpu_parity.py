@@ -584,6 +584,38 @@ def test_multi_stream_batches_are_identical(oracle):
     hip.set_streams(1)
 
 
+def test_multi_stream_ld_batches(oracle):
+    """LD through three streams: the lanes' row-walking index searches (each a single launch whose workgroups wait on
+    one another) run side by side; payloads and pictures equal the oracle's."""
+    import torch
+    import vc2hip_py
+    hip = vc2hip_py.Vc2Hip(0)
+    hip.set_streams(3)
+    w, h, depth, nbytes, n = 256, 120, 3, 12000, 7
+    raw = b"".join(synth(w, h, "422", 8, 300 + k, word_bytes=1) for k in range(n))
+    p = make_params(w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=nbytes, word_bytes=1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=nbytes, word_bytes=1)
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):  # repeated: the flags of a previous batch must not leak into the next
+        hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    pay = d_pay.cpu().numpy()
+    out = d_out.cpu().numpy().tobytes()
+    for k in range(n):
+        stream = oracle.encode_stream(p, raw[k * rb:(k + 1) * rb], 1)
+        assert bytes(pay[k * stride:k * stride + nbytes]) == stream[-13 - nbytes:-13], f"picture {k}"
+        assert out[k * rb:(k + 1) * rb] == oracle.decode_stream(p, stream, 1)[0], f"picture {k}"
+    hip.set_streams(1)
+
+
 @pytest.mark.parametrize("scalar", [11, 30, 45])
 def test_large_slice_scalars(hip, oracle, scalar):
     """Slices that may exceed 8191 bytes use 32 KiB index chunks, beyond 32767 bytes a serial walk: any slice size
