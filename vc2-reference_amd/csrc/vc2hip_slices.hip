@@ -1439,7 +1439,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
 __device__ __forceinline__ int intlog2_dev(int value) { int l = 0; --value; while (value > 0) { value >>= 1; ++l; } return l; }
 
 __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
-  constexpr int UNP_N = 16, UNP_PITCH = UNP_N + 4;
+  constexpr int UNP_N = 32, UNP_PITCH = UNP_N + 4, LPR = UNP_N / 4; // whole 128-byte lines per flush (see k_hq_unpack)
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
   __shared__ unsigned long long outp[4][64];
   __shared__ unsigned short vlut[1024];
@@ -1447,6 +1447,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slice = blockIdx.x * 256 + threadIdx.x, pic = blockIdx.y;
+  const bool chroma = blockIdx.z != 0; // the two streams of a slice are independent once the header is read: a lane each
   const bool active = slice < p.n_slices;
   int *st = stage[wave] + lane * UNP_PITCH;
   const int *sw = stage[wave];
@@ -1457,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
     data = p.payload + (size_t)pic * p.payload_stride + p.offsets[slice];
     unsigned head = 0; // 7 bits of quantiser index, then intlog2(8*size-7) bits of luma length: at most 30 bits
     for (int k = 0; k < 4; ++k) head = (head << 8) | (k < size ? data[k] : 0xFFu);
-    p.qidx[(size_t)pic * p.n_slices + slice] = (int)(head >> 25);
+    if (!chroma) p.qidx[(size_t)pic * p.n_slices + slice] = (int)(head >> 25);
     const int split = intlog2_dev(8 * size - 7);
     ybits = split ? (int)((head << 7) >> (32 - split)) : 0;
     ystart = 7 + split;
@@ -1466,18 +1467,18 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
   } else outp[wave][lane] = 0;
   WordReader br;
   // luma: ybits bits from ystart; bits past the slice read as 1 like bits past the bound (VLC.cpp:182-185)
-  {
+  if (!chroma) {
     const int nb = min(ybits, total - ystart);
     if (active && nb > 0) br.init_bits(data + (ystart >> 3), ystart & 7, nb); else br.init_ones();
   }
-  const int ny = p.comp_n[0];
+  const int ny = chroma ? 0 : p.comp_n[0];
   for (int base = 0; base < ny; base += UNP_N) {
     const int room = min(UNP_N, ny - base);
     decode_round<UNP_N>(br, room, st, vlut);
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 16 + lane / 4, c = (lane % 4) * 4;
+    for (int j = 0; j < LPR; ++j) {
+      const int r = j * (64 / LPR) + lane / LPR, c = (lane % LPR) * 4;
       int32_t *rec = (int32_t *)outp[wave][r];
       if (rec && c < room) {
         const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
@@ -1490,19 +1491,19 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
     wave_lds_sync();
   }
   // chroma: the rest of the slice, U and V coefficients alternating
-  {
+  if (chroma) {
     const int cstart = ystart + ybits;
     const int nb = total - cstart;
     if (active && nb > 0 && ybits >= 0) br.init_bits(data + (cstart >> 3), cstart & 7, nb); else br.init_ones();
   }
-  const int nc = 2 * p.comp_n[1];
+  const int nc = chroma ? 2 * p.comp_n[1] : 0;
   for (int base = 0; base < nc; base += UNP_N) {
     const int room = min(UNP_N, nc - base);
     decode_round<UNP_N>(br, room, st, vlut);
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 16 + lane / 4, c = (lane % 4) * 4;
+    for (int j = 0; j < LPR; ++j) {
+      const int r = j * (64 / LPR) + lane / LPR, c = (lane % LPR) * 4;
       int32_t *rec = (int32_t *)outp[wave][r];
       if (rec && c < room) { // room is even: (u, v) pairs
         const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
@@ -1517,7 +1518,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
 
 void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "ld_unpack", s);
-  VC2_LAUNCH(L, k_ld_unpack, dim3((p.n_slices + 255) / 256, n_pictures), dim3(256), 0, s, p);
+  VC2_LAUNCH(L, k_ld_unpack, dim3((p.n_slices + 255) / 256, n_pictures, 2), dim3(256), 0, s, p);
   vc2_prof_end(L, s);
 }
 
