@@ -1569,30 +1569,85 @@ __device__ __forceinline__ void ld_ll_lds_body(int pic, const int32_t *store, lo
   const int32_t *st = store + (size_t)pic * store_stride;
   const int32_t *qi = qidx + (size_t)pic * ys * xs;
   const int bh = llh / ys, bw = llw / xs; // LL block of one slice
-  for (int i = threadIdx.x; i < llh * llw; i += blockDim.x) {
-    const int y = i / llw, x = i - y * llw;
-    const int sv = y / bh, sh = x / bw;
-    const int qv = st[(size_t)(sv * xs + sh) * slice_coefs + coef_off + (y - sv * bh) * bw + (x - sh * bw)];
-    // slice whose index quantises this LL sample: Quantisation.cpp:298-299
-    const int yb = ((y + 1) * ys - 1) / llh, xb = ((x + 1) * xs - 1) / llw;
-    const int aq = max(qi[yb * xs + xb] - qm0, 0);
-    if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
-    rs[i] = scale_dev(qv, min(aq, 119));
+  // quantiser factor / offset by adjusted index behind the plane: a per-lane index into the constant tables is a
+  // dependent trip to memory per sample
+  int *qft = rs + llh * llw, *qot = qft + 120;
+  for (int i = threadIdx.x; i < 120; i += blockDim.x) { qft[i] = c_qs.qf[i]; qot[i] = c_qs.off[i]; }
+  __syncthreads();
+  // slice by slice: one index per slice (the slice whose index quantises a sample of its own block, Quantisation.cpp:298-299,
+  // is the slice itself when the blocks tile the band, which the geometry check guarantees), no divisions per sample
+  auto scale_tab = [&](int v, int qf, int qo) -> int { // scale(), Quantisation.cpp:86-95
+    const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    int a = (int)(mag * (unsigned)qf);
+    if (a > 0) a = (int)((unsigned)a + (unsigned)qo);
+    a = (int)((unsigned)a + 2u);
+    a /= 4;
+    return v < 0 ? (int)(0u - (unsigned)a) : a;
+  };
+  const int n0 = bh * bw, ns = ys * xs;
+  if (n0 <= 4) { // four slices per thread and turn, their loads in flight together: the records are 2 KB apart, every load a trip to memory
+    for (int s0 = threadIdx.x; s0 < ns; s0 += 4 * blockDim.x) {
+      int q4[4], v4[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sl = min(s0 + k * (int)blockDim.x, ns - 1);
+        q4[k] = qi[sl];
+        const int32_t *src = st + (size_t)sl * slice_coefs + coef_off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[k][e] = e < n0 ? src[e] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sl = s0 + k * (int)blockDim.x;
+        if (sl >= ns) break;
+        const int sv = sl / xs, sh = sl - sv * xs;
+        const int aq = max(q4[k] - qm0, 0);
+        if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
+        const int qf = qft[min(aq, 119)], qo = qot[min(aq, 119)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < n0) { const int yy = e / bw, xx = e - yy * bw; rs[(sv * bh + yy) * llw + sh * bw + xx] = scale_tab(v4[k][e], qf, qo); }
+      }
+    }
+  } else {
+    for (int sl = threadIdx.x; sl < ns; sl += blockDim.x) {
+      const int sv = sl / xs, sh = sl - sv * xs;
+      const int aq = max(qi[sl] - qm0, 0);
+      if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
+      const int qf = qft[min(aq, 119)], qo = qot[min(aq, 119)];
+      const int32_t *src = st + (size_t)sl * slice_coefs + coef_off;
+      for (int yy = 0; yy < bh; ++yy)
+        for (int xx = 0; xx < bw; ++xx) rs[(sv * bh + yy) * llw + sh * bw + xx] = scale_tab(src[yy * bw + xx], qf, qo);
+    }
   }
   __syncthreads();
-  for (int d = 1; d < llh + llw - 1; ++d) { // (0,0) has no prediction
-    const int ylo = max(0, d - (llw - 1)), yhi = min(llh - 1, d);
-    for (int y = ylo + (int)threadIdx.x; y <= yhi; y += blockDim.x) {
-      const int x = d - y;
-      int pred; // predictDC, Quantisation.cpp:191-208
-      if (y > 0 && x > 0) {
-        const int r = rs[(y - 1) * llw + x - 1] + rs[(y - 1) * llw + x] + rs[y * llw + x - 1];
-        pred = r >= 0 ? (r + 1) / 3 : (r - 1) / 3;
-      } else if (y > 0) pred = rs[(y - 1) * llw + x];
-      else pred = rs[y * llw + x - 1];
-      rs[y * llw + x] = (int)((unsigned)rs[y * llw + x] + (unsigned)pred);
+  // The wavefront over anti-diagonals is a chain of dependent steps, each a barrier and an LDS round trip: it runs over
+  // 2 x 2 blocks (half the steps; the four samples of a block follow one another in registers).
+  {
+    auto pred = [&](int y, int x, int ul, int up, int lf) -> int { // predictDC, Quantisation.cpp:191-208
+      if (y > 0 && x > 0) { const int r = ul + up + lf; return r >= 0 ? (r + 1) / 3 : (r - 1) / 3; }
+      if (y > 0) return up;
+      if (x > 0) return lf;
+      return 0;
+    };
+    const int nby = (llh + 1) / 2, nbx = (llw + 1) / 2;
+    for (int d = 0; d < nby + nbx - 1; ++d) {
+      const int blo = max(0, d - (nbx - 1)), bhi = min(nby - 1, d);
+      for (int by = blo + (int)threadIdx.x; by <= bhi; by += blockDim.x) {
+        const int y0 = 2 * by, x0 = 2 * (d - by);
+        const bool has_x = x0 + 1 < llw, has_y = y0 + 1 < llh;
+        int *q = rs + y0 * llw + x0;
+        const int w00 = y0 > 0 && x0 > 0 ? q[-llw - 1] : 0, w01 = y0 > 0 ? q[-llw] : 0, w02 = y0 > 0 && has_x ? q[-llw + 1] : 0;
+        const int w10 = x0 > 0 ? q[-1] : 0, w20 = x0 > 0 && has_y ? q[llw - 1] : 0;
+        const int a = (int)((unsigned)q[0] + (unsigned)pred(y0, x0, w00, w01, w10));
+        q[0] = a;
+        int b = 0, c = 0;
+        if (has_x) { b = (int)((unsigned)q[1] + (unsigned)pred(y0, x0 + 1, w01, w02, a)); q[1] = b; }
+        if (has_y) { c = (int)((unsigned)q[llw] + (unsigned)pred(y0 + 1, x0, w10, a, w20)); q[llw] = c; }
+        if (has_x && has_y) q[llw + 1] = (int)((unsigned)q[llw + 1] + (unsigned)pred(y0 + 1, x0 + 1, a, b, c));
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   int32_t *ll = ll_plane + (size_t)pic * ll_stride;
   for (int i = threadIdx.x; i < llh * llw; i += blockDim.x) ll[i] = rs[i];
@@ -1617,13 +1672,14 @@ bool vc2_launch_ld_ll3(Launcher &L, const LdLl3Params &p, int n_pictures, hipStr
   int reach = 0;
   for (int c = 0; c < 3; ++c) {
     if (p.llh[c] < 1 || p.llw[c] < 1) return false;
-    bytes = std::max(bytes, (size_t)p.llh[c] * p.llw[c] * 4);
+    bytes = std::max(bytes, (size_t)p.llh[c] * p.llw[c] * 4 + 960); // + factor / offset tables
     reach = std::max(reach, std::min(p.llh[c], p.llw[c]));
   }
   if (bytes > 150 * 1024) return false;
   vc2_prof_begin(L, "ld_ll_predict", s);
   vc2_allow_lds((const void *)k_ld_ll_lds3, 150 * 1024);
-  const int threads = reach <= 256 ? 256 : reach <= 512 ? 512 : 1024; // an anti-diagonal never has more samples; fewer wavefronts, cheaper barriers
+  const int blocks = (reach + 1) / 2; // 2 x 2 blocks on the longest anti-diagonal: never more are busy in a step
+  const int threads = blocks <= 256 ? 256 : 512; // measured for 1080p (68 blocks): 128 threads 0.167 ms, 256 0.148, 512 0.153 (barriers cost more)
   VC2_LAUNCH(L, k_ld_ll_lds3, dim3(n_pictures, 3), dim3(threads), bytes, s, p);
   vc2_prof_end(L, s);
   return true;
@@ -1633,7 +1689,7 @@ void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride,
                       int qm0, int32_t *ll_plane, long long ll_stride, int n_pictures, unsigned *err,
                       hipStream_t s) {
   vc2_prof_begin(L, "ld_ll_predict", s);
-  const size_t plane_bytes = (size_t)llh * llw * 4;
+  const size_t plane_bytes = (size_t)llh * llw * 4 + 960; // + factor / offset tables
   if (plane_bytes <= 150 * 1024) {
     vc2_allow_lds((const void *)k_ld_ll_lds, 150 * 1024);
     VC2_LAUNCH(L, k_ld_ll_lds, dim3(n_pictures), dim3(1024), plane_bytes, s, store, store_stride, slice_coefs, coef_off,
