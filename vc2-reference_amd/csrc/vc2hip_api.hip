@@ -22,8 +22,8 @@ bool vc2_slice_index_supported(int prefix, int scalar);
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
 void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
 bool vc2_fast_level_applicable(LevelParams &p);
-int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, hipStream_t s);
-int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, hipStream_t s);
+int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, hipStream_t s);
+int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, hipStream_t s);
 void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s);
 void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 
@@ -94,7 +94,7 @@ struct Buf {
   void *p = nullptr;
   size_t cap = 0;
 };
-enum { B_RAW, B_STORE, B_LL0, B_LL1, B_LL2, B_QIDX, B_SLOTS, B_SIZES, B_OFFS, B_LENS, B_PAYLOAD,
+enum { B_RAW, B_STORE, B_STOREW, B_LL0, B_LLW, B_QIDX, B_SLOTS, B_SIZES, B_OFFS, B_LENS, B_PAYLOAD,
        B_INDEX, B_PLANE, B_PLANE2, B_CBRB, B_CBRO, B_QM, B_COUNT };
 
 struct vc2hip_ctx {
@@ -116,6 +116,7 @@ struct vc2hip_ctx {
   // critical path and the kernel is latency-bound), kept as a tested alternative.
   bool two_pass_vbr = true;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
+  bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
   // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
   // sub-batches overlap: the tail of one launch is filled by the next stream's work.
@@ -267,7 +268,10 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   vc2hip_ctx *c = new vc2hip_ctx;
   c->device = device;
   { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
+  { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
+#ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
+#endif
   { const char *e = getenv("VC2HIP_SINGLE_PASS_VBR"); c->two_pass_vbr = !(e && e[0] == '1'); }
   if (hipSetDevice(device) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
@@ -546,26 +550,32 @@ extern "C" size_t vc2hip_max_payload_bytes(const vc2hip_picture_format *f, const
 // level sequencing
 // ------------------------------------------------------------------------------------------
 struct LLPlanes { // per level l >= 1: compact LL_l planes for the three components
-  int32_t *p[VC2_MAX_DEPTH + 1][3];
+  void *p[VC2_MAX_DEPTH + 1][3];    // int32_t elements, or int16_t with ...
+  int32_t *w[VC2_MAX_DEPTH + 1][3]; // ... their wide planes (vc2hip_store.h); null for int32 planes
   long long stride[VC2_MAX_DEPTH + 1][3];
 };
 
-static size_t ll_bytes(const Geom &g, int n) {
+// planes start on 16-byte boundaries whatever the element size: sizes are rounded up to 8 elements
+static size_t ll_elems(const Geom &g, int n) {
   size_t e = 0;
   for (int l = 1; l <= g.depth; ++l)
-    for (int c = 0; c < 3; ++c) e += (size_t)(g.c[c].ph >> l) * (g.c[c].pw >> l);
-  return e * n * sizeof(int32_t);
+    for (int c = 0; c < 3; ++c) e += (((size_t)(g.c[c].ph >> l) * (g.c[c].pw >> l) * n + 7) & ~(size_t)7);
+  return e;
 }
-static void ll_layout(const Geom &g, int n, int32_t *base, LLPlanes &ll) {
+static size_t ll_bytes(const Geom &g, int n) { return ll_elems(g, n) * sizeof(int32_t); }
+static void ll_layout(const Geom &g, int n, void *base, int elem_bytes, int32_t *wide, LLPlanes &ll) {
   size_t off = 0;
+  memset(&ll, 0, sizeof ll);
   for (int l = 1; l <= g.depth; ++l)
     for (int c = 0; c < 3; ++c) {
       const size_t e = (size_t)(g.c[c].ph >> l) * (g.c[c].pw >> l);
-      ll.p[l][c] = base + off;
+      ll.p[l][c] = (char *)base + off * elem_bytes;
+      ll.w[l][c] = wide ? wide + off : nullptr;
       ll.stride[l][c] = (long long)e;
-      off += e * n;
+      off += (e * n + 7) & ~(size_t)7;
     }
 }
+static void ll_layout(const Geom &g, int n, int32_t *base, LLPlanes &ll) { ll_layout(g, n, base, 4, nullptr, ll); }
 
 static void fill_level(LevelParams &p, const Geom &g, int level, int kernel, const int32_t *qm) {
   const int D = g.depth, Lv = D - level;
@@ -596,21 +606,23 @@ static void fill_level(LevelParams &p, const Geom &g, int level, int kernel, con
 }
 
 // forward transform of n pictures: raw words (first level fused) or int32 LL_0 planes -> store
+// s16: 16-bit store and level planes with their wide planes (only with the fast kernels: use_store16)
 static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const void *const src[3],
                        const long long src_stride[3], bool src_raw, const vc2hip_picture_format *f,
-                       int32_t *store, const LLPlanes &ll) {
+                       void *store, const LLPlanes &ll, bool s16 = false, int32_t *store_wide = nullptr) {
   for (int level = 0; level < g.depth; ++level) {
     LevelParams p;
     memset(&p, 0, sizeof p);
     fill_level(p, g, level, kernel, nullptr);
     p.store = store; p.store_stride = (long long)g.ys * g.xs * g.slice_coefs;
+    p.store_wide = store_wide;
     p.err = c->d_err;
     p.ll_to_store = (level == g.depth - 1);
     const bool first = (level == 0) && src_raw;
     for (int k = 0; k < 3; ++k) {
       if (level == 0) { p.plane[k] = (void *)src[k]; p.plane_stride[k] = src_stride[k]; }
-      else { p.plane[k] = ll.p[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
-      p.ll[k] = ll.p[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
+      else { p.plane[k] = ll.p[level][k]; p.plane_wide[k] = ll.w[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
+      p.ll[k] = ll.p[level + 1][k]; p.ll_wide[k] = ll.w[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
     }
     if (first) {
       p.word_bytes = f->word_bytes;
@@ -620,10 +632,11 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
-      int rc = vc2_launch_forward_fast(c->L, kernel, first, pf, n, c->stream);
+      int rc = vc2_launch_forward_fast(c->L, kernel, first, pf, n, s16, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");
       continue;
     }
+    if (s16) return set_err(c, VC2HIP_EINVAL, "internal: 16-bit store without the fast level kernels");
     if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for one LDS tile");
     int rc = vc2_launch_forward_level(c->L, kernel, first, p, n, c->stream);
     if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -632,21 +645,23 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
 }
 
 // inverse transform of n pictures: store (optionally dequantised on load) -> int32 planes or raw words
-static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, int32_t *store, const int32_t *qidx,
+static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *store, const int32_t *qidx,
                        const int32_t *qm, bool dequant, bool ll_ready, const LLPlanes &ll, void *const dst[3],
-                       const long long dst_stride[3], bool dst_raw, const vc2hip_picture_format *f) {
+                       const long long dst_stride[3], bool dst_raw, const vc2hip_picture_format *f,
+                       bool s16 = false, int32_t *store_wide = nullptr) {
   for (int level = g.depth - 1; level >= 0; --level) {
     LevelParams p;
     memset(&p, 0, sizeof p);
     fill_level(p, g, level, kernel, qm);
     p.store = store; p.store_stride = (long long)g.ys * g.xs * g.slice_coefs;
+    p.store_wide = store_wide;
     p.qidx = qidx; p.err = c->d_err; p.dequant = dequant;
     p.ll_from_store = (level == g.depth - 1) && !ll_ready;
     const bool fin = (level == 0) && dst_raw;
     for (int k = 0; k < 3; ++k) {
       if (level == 0) { p.plane[k] = dst[k]; p.plane_stride[k] = dst_stride[k]; }
-      else { p.plane[k] = ll.p[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
-      p.ll[k] = ll.p[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
+      else { p.plane[k] = ll.p[level][k]; p.plane_wide[k] = ll.w[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
+      p.ll[k] = ll.p[level + 1][k]; p.ll_wide[k] = ll.w[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
     }
     if (fin) {
       p.word_bytes = f->word_bytes;
@@ -658,10 +673,11 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, int32_t 
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
-      int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, c->stream);
+      int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, s16, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");
       continue;
     }
+    if (s16) return set_err(c, VC2HIP_EINVAL, "internal: 16-bit store without the fast level kernels");
     if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for one LDS tile");
     int rc = vc2_launch_inverse_level(c->L, kernel, fin, p, n, c->stream);
     if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -669,19 +685,38 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, int32_t 
   return VC2HIP_OK;
 }
 
+// The HQ batch path keeps the store and the level planes as 16-bit elements + wide planes (vc2hip_store.h) when every
+// level runs through the fast kernels and every component record can be moved eight coefficients at a time.
+static bool use_store16(const vc2hip_ctx *c, const Geom &g, int kernel) {
+  if (!c->allow_store16 || c->force_generic) return false;
+  for (int k = 0; k < 3; ++k) {
+    if (!g.c[k].ph) continue;
+    if ((g.c[k].sh * g.c[k].sw) % 8 || g.c[k].coef_off % 8) return false;
+  }
+  if (g.slice_coefs % 8) return false;
+  for (int level = 0; level < g.depth; ++level) {
+    LevelParams p;
+    memset(&p, 0, sizeof p);
+    fill_level(p, g, level, kernel, nullptr);
+    if (!vc2_fast_level_applicable(p)) return false;
+  }
+  return true;
+}
+
 static void fill_comp_arrays(const Geom &g, int n[3], int off[3], int n0[3]) {
   for (int c = 0; c < 3; ++c) { n[c] = g.c[c].sh * g.c[c].sw; off[c] = g.c[c].coef_off; n0[c] = g.c[c].n0 ? g.c[c].n0 : 1; }
 }
 
 // pack n pictures from the store into d_payload; VBR goes through slots + scan + compaction
-static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const int32_t *store, const int32_t *d_qidx,
+static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const void *store, const int32_t *d_qidx,
                     const int32_t *qm, bool quantise, int prefix, int scalar, const int32_t *d_cbr_bytes,
                     const uint32_t *d_cbr_offs, uint64_t cbr_total, uint8_t *d_payload, long long stride,
-                    unsigned long long *d_lens) {
+                    unsigned long long *d_lens, bool s16 = false, const int32_t *store_wide = nullptr) {
   const int ns = g.ys * g.xs;
   PackParams p;
   memset(&p, 0, sizeof p);
   p.store = store; p.store_stride = (long long)ns * g.slice_coefs;
+  p.store16 = s16; p.store_wide = store_wide;
   p.qidx = d_qidx; p.n_slices = ns; p.slice_coefs = g.slice_coefs;
   fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
   p.depth = g.depth; p.prefix = prefix; p.scalar = scalar;
@@ -1065,7 +1100,7 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
   p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
   p.slice_bytes = d_sb; p.offsets = d_so;
   for (int k = 0; k < 3; ++k) {
-    p.restored[k] = ll.p[g.depth][k]; p.restored_stride[k] = ll.stride[g.depth][k];
+    p.restored[k] = (int32_t *)ll.p[g.depth][k]; p.restored_stride[k] = ll.stride[g.depth][k];
     p.ll_w[k] = g.c[k].pw >> g.depth;
     p.bh[k] = (g.c[k].ph >> g.depth) / g.ys; p.bw[k] = (g.c[k].pw >> g.depth) / g.xs;
   }
@@ -1213,15 +1248,20 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
   const int ns = g.ys * g.xs;
   int32_t qm[VC2_MAX_BANDS];
   if ((rc = vc2hip_quant_matrix(cp->kernel, cp->depth, qm))) return set_err(c, rc);
-  int32_t *d_store, *d_ll, *d_q;
-  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store);
+  const bool s16 = cp->mode != VC2HIP_LD && use_store16(c, g, cp->kernel);
+  int32_t *d_store, *d_ll, *d_q, *d_storew = nullptr, *d_llw = nullptr;
+  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store); // 16-bit elements use the first half
   NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
+  if (s16) { // touched only by values outside 16 bits
+    NEED(c, B_STOREW, (size_t)n * ns * g.slice_coefs * 4, d_storew);
+    NEED(c, B_LLW, ll_bytes(g, n) + 16, d_llw);
+  }
   NEED(c, B_QIDX, (size_t)n * ns * 4, d_q);
   LLPlanes ll;
-  ll_layout(g, n, d_ll, ll);
+  ll_layout(g, n, d_ll, s16 ? 2 : 4, d_llw, ll);
   const void *src[3]; long long ss[3];
   raw_planes(f, d_raw, src, ss);
-  if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll))) return rc;
+  if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll, s16, d_storew))) return rc;
   int32_t *d_cb = nullptr; uint32_t *d_co = nullptr; uint64_t total = 0;
   if (cp->mode == VC2HIP_LD) {
     // EncodeStream.cpp:509-512 (slice_bytes with scalar 1), :141-245, :195-244
@@ -1259,6 +1299,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     CbrParams p;
     memset(&p, 0, sizeof p);
     p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q; p.slice_bytes = d_cb;
+    p.store16 = s16; p.store_wide = d_storew;
     p.n_slices = ns; p.slice_coefs = g.slice_coefs;
     fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
     p.scalar = cp->scalar; p.err = c->d_err;
@@ -1271,7 +1312,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     vc2_launch_fill_i32(c->L, d_q, cp->q_index, (size_t)n * ns, c->stream);
   }
   return run_pack(c, g, n, d_store, d_q, qm, true, cp->prefix, cp->scalar, d_cb, d_co, total, (uint8_t *)d_payload,
-                  (long long)payload_stride, (unsigned long long *)d_lens);
+                  (long long)payload_stride, (unsigned long long *)d_lens, s16, d_storew);
 }
 
 static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens, int n,
@@ -1287,12 +1328,17 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
   const int ns = g.ys * g.xs;
   int32_t qm[VC2_MAX_BANDS];
   if ((rc = vc2hip_quant_matrix(cp->kernel, cp->depth, qm))) return set_err(c, rc);
-  int32_t *d_store, *d_ll, *d_q;
+  const bool s16 = !ld && use_store16(c, g, cp->kernel);
+  int32_t *d_store, *d_ll, *d_q, *d_storew = nullptr, *d_llw = nullptr;
   NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store);
   NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
+  if (s16) {
+    NEED(c, B_STOREW, (size_t)n * ns * g.slice_coefs * 4, d_storew);
+    NEED(c, B_LLW, ll_bytes(g, n) + 16, d_llw);
+  }
   NEED(c, B_QIDX, (size_t)n * ns * 4, d_q);
   LLPlanes ll;
-  ll_layout(g, n, d_ll, ll);
+  ll_layout(g, n, d_ll, s16 ? 2 : 4, d_llw, ll);
   if (!ld) {
     if (!d_lens || cp->scalar < 1 || cp->prefix < 0) return set_err(c, VC2HIP_EINVAL);
     uint32_t *d_offs;
@@ -1303,6 +1349,7 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     p.payload = (const uint8_t *)d_payload; p.payload_stride = (long long)payload_stride;
     p.lens = (const unsigned long long *)d_lens; p.offsets = d_offs;
     p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
+    p.store16 = s16; p.store_wide = d_storew;
     p.n_slices = ns; p.slice_coefs = g.slice_coefs;
     int n0[3];
     fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
@@ -1329,18 +1376,18 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     lp.ys = g.ys; lp.xs = g.xs; lp.qidx = d_q; lp.qm0 = qm[0]; lp.err = c->d_err;
     for (int k = 0; k < 3; ++k) {
       lp.coef_off[k] = g.c[k].coef_off; lp.llh[k] = g.c[k].ph >> g.depth; lp.llw[k] = g.c[k].pw >> g.depth;
-      lp.ll_plane[k] = ll.p[g.depth][k]; lp.ll_stride[k] = ll.stride[g.depth][k];
+      lp.ll_plane[k] = (int32_t *)ll.p[g.depth][k]; lp.ll_stride[k] = ll.stride[g.depth][k];
     }
     if (!vc2_launch_ld_ll3(c->L, lp, n, c->stream))
     for (int k = 0; k < 3; ++k)
       vc2_launch_ld_ll(c->L, d_store, (long long)ns * g.slice_coefs, g.slice_coefs, g.c[k].coef_off, g.c[k].n0,
-                       g.c[k].ph >> g.depth, g.c[k].pw >> g.depth, g.ys, g.xs, d_q, qm[0], ll.p[g.depth][k],
+                       g.c[k].ph >> g.depth, g.c[k].pw >> g.depth, g.ys, g.xs, d_q, qm[0], (int32_t *)ll.p[g.depth][k],
                        ll.stride[g.depth][k], n, c->d_err, c->stream);
   }
   const void *dstc[3]; long long ds[3];
   raw_planes(f, d_raw_out, dstc, ds);
   void *dst[3] = {(void *)dstc[0], (void *)dstc[1], (void *)dstc[2]};
-  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f);
+  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew);
 }
 
 extern "C" int vc2hip_decode_batch_dev(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens,

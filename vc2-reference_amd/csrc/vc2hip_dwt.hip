@@ -164,12 +164,12 @@ __global__ __launch_bounds__(256) void k_fwd_level(const LevelParams p) {
   const int tsx = p.tsx[comp], tsy = p.tsy[comp];
   const int items = tsy * tsx * blk;
   const int s_y0 = blockIdx.y * tsy, s_x0 = blockIdx.x * tsx;
-  int32_t *store = p.store + (size_t)pic * p.store_stride;
+  int32_t *store = (int32_t *)p.store + (size_t)pic * p.store_stride;
   for (int band = 0; band < 4; ++band) {
     const int *src = w.plane(band >> 1, band & 1) + (HY / 2) * w.wxp + HX / 2;
     if (band == 0 && !p.ll_to_store) {
       // compact LL plane for the next level
-      int32_t *ll = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+      int32_t *ll = (int32_t *)p.ll[comp] + (size_t)pic * p.ll_stride[comp];
       const int oh = in_h / 2, ow = in_w / 2, th = TY / 2, tw = TX / 2;
       for (int e = threadIdx.x; e < th * tw; e += blockDim.x) {
         const int i = e / tw, j = e - i * tw;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_inv_level(const LevelParams p) {
   const int npy = out_h / 2, npx = out_w / 2;
   const int ky_base = (y0 - HY) / 2, kx_base = (x0 - HX) / 2;
   const int bsh = fh / 2, bsw = fw / 2;
-  const int32_t *store = p.store + (size_t)pic * p.store_stride;
+  const int32_t *store = (int32_t *)p.store + (size_t)pic * p.store_stride;
   const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * p.xs : nullptr;
 
   // ---- gather the four bands of tile + halo (fused dequantisation)
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_inv_level(const LevelParams p) {
     int v = 0;
     if (by >= 0 && by < npy && bx >= 0 && bx < npx) {
       if (band == 0 && !p.ll_from_store) {
-        v = p.ll[comp][(size_t)pic * p.ll_stride[comp] + (size_t)by * npx + bx];
+        v = ((const int32_t *)p.ll[comp])[(size_t)pic * p.ll_stride[comp] + (size_t)by * npx + bx];
       } else {
         const int sv = by / bsh, sh = bx / bsw;
         const int r = by - sv * bsh, c = bx - sh * bsw;

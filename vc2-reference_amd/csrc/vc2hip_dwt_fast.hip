@@ -14,6 +14,7 @@
 
 #include "vc2hip_internal.h"
 #include "vc2hip_wavelets.h"
+#include "vc2hip_store.h"
 
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
 void vc2_prof_end(Launcher &L, hipStream_t s);
@@ -322,8 +323,9 @@ __device__ __forceinline__ bool tile_of_block(int tiles_x, int tiles_y, int &tx,
 // ------------------------------------------------------------------------------------------
 // forward level
 // ------------------------------------------------------------------------------------------
-template <int K, bool FIRST>
+template <int K, bool FIRST, class ST>
 __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
+  using S_ = St<ST>;
   using C = Cfg<K>;
   extern __shared__ __attribute__((aligned(16))) int lds[];
   const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
@@ -338,9 +340,11 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
   // latency per tile instead of one per item.
   {
     const int pic_h = p.pic_h[comp], pic_w = p.pic_w[comp];
-    const bool vec_ok = FIRST ? (p.word_bytes == 2 && (pic_w & 7) == 0) : ((in_w & 3) == 0);
+    const bool vec_ok = FIRST ? (p.word_bytes == 2 && (pic_w & 7) == 0) : ((in_w & 7) == 0);
     constexpr int NLD = (WY * (WX / 8) + NT - 1) / NT;
-    uint4 va[NLD], vb[NLD]; // FIRST: va = 8 samples; else va, vb = 4 + 4 coefficients
+    uint4 va[NLD], vb[NLD]; // FIRST: va = 8 samples; else va (, vb) = 8 coefficients of the level plane
+    const ST *lvl = FIRST ? nullptr : (const ST *)p.plane[comp] + (size_t)pic * p.plane_stride[comp];
+    const int32_t *lvl_w = (FIRST || !S_::narrow) ? nullptr : p.plane_wide[comp] + (size_t)pic * p.plane_stride[comp];
     int kind[NLD];          // 0 skip, 1 vector data loaded, 2 element-wise path
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
       kind[it] = 0;
       va[it] = make_uint4(0, 0, 0, 0);
       vb[it] = make_uint4(0, 0, 0, 0);
-      if (id >= WY * (WX / 8) || (p.debug_skip & 1)) continue;
+      if (id >= WY * (WX / 8) || VC2_SKIP(p, 1)) continue;
       const int r = id / (WX / 8), ch = id - r * (WX / 8);
       const int gy = y0 - HY + r, gx0 = x0 - HX + 8 * ch;
       if (gy < 0 || gy >= in_h || gx0 + 8 <= 0 || gx0 >= in_w) continue;
@@ -361,9 +365,9 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
         } else kind[it] = 2;
       } else {
         if (vec_ok && gx0 >= 0 && gx0 + 8 <= in_w) {
-          const int32_t *row = (const int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w;
+          const ST *row = lvl + (size_t)gy * in_w;
           va[it] = *(const uint4 *)(row + gx0);
-          vb[it] = *(const uint4 *)(row + gx0 + 4);
+          if constexpr (!S_::narrow) vb[it] = *(const uint4 *)(row + gx0 + 4);
           kind[it] = 1;
         } else kind[it] = 2;
       }
@@ -400,12 +404,17 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
         for (int k = 0; k < 8; ++k) s[k] = (int)((unsigned)((int)((unsigned)s[k] >> p.sample_shift) - p.sample_offset) << ACC);
       } else {
         if (kind[it] == 1) {
-          s[0] = (int)va[it].x; s[1] = (int)va[it].y; s[2] = (int)va[it].z; s[3] = (int)va[it].w;
-          s[4] = (int)vb[it].x; s[5] = (int)vb[it].y; s[6] = (int)vb[it].z; s[7] = (int)vb[it].w;
+          if constexpr (S_::narrow) S_::unpack8(va[it], lvl_w + (size_t)gy * in_w + gx0, s);
+          else {
+            s[0] = (int)va[it].x; s[1] = (int)va[it].y; s[2] = (int)va[it].z; s[3] = (int)va[it].w;
+            s[4] = (int)vb[it].x; s[5] = (int)vb[it].y; s[6] = (int)vb[it].z; s[7] = (int)vb[it].w;
+          }
         } else {
-          const int32_t *row = (const int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) s[k] = row[min(max(gx0 + k, 0), in_w - 1)];
+          for (int k = 0; k < 8; ++k) {
+            const size_t at = (size_t)gy * in_w + min(max(gx0 + k, 0), in_w - 1);
+            s[k] = S_::load1(lvl + at, lvl_w + at);
+          }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) s[k] = (int)((unsigned)s[k] << ACC);
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
     // window rows gy in [0,in_h): stack index rr = rp*WYP + i, row r = 2*i + rp.  Rows outside the
     // plane are skipped (the vertical pass replicates across the plane edge itself).
     constexpr int NITH = (2 * C::WYP * TXQ + NT - 1) / NT;
-    if (!(p.debug_skip & 2)) {
+    if (!VC2_SKIP(p, 2)) {
     if constexpr (stepwise<K>()) {
       steps_h<K, false>(lds, 0, 2 * C::WYP, (x0 - HX) / 2, in_w / 2);
       steps_v<K, false>(lds, HX / 8, TXQ, (y0 - HY) / 2, in_h / 2);
@@ -439,9 +448,10 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
   const int lbsw = ilog2(bsw), lblk = ilog2(bsh) + lbsw;
   const int tsx_l = ilog2(TX / fw);           // slices per tile row (log2)
   const int s_y0 = y0 / fh, s_x0 = x0 / fw;
-  int32_t *store = p.store + (size_t)pic * p.store_stride;
+  ST *store = (ST *)p.store + (size_t)pic * p.store_stride;
+  int32_t *wide = S_::narrow ? p.store_wide + (size_t)pic * p.store_stride : nullptr;
   const int *core = lds + (HY / 2) * WXP + HX / 2;
-  if (p.debug_skip & 4) return;
+  if (VC2_SKIP(p, 4)) return;
   // Deep levels (band blocks narrower than four coefficients): the level's bands of one slice are one short contiguous
   // run of its record ([LL |] HL | LH | HH), written slice by slice with 16-byte stores assembled from the planes.
   const bool by_slice = lbsw < 2;
@@ -462,11 +472,11 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
         const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
         e[k] = core[band * C::PLANE + ((si << (lblk - lbsw)) + (rem >> lbsw)) * WXP + (sj << lbsw) + (rem & (bsw - 1))];
       }
-      int32_t *d = store + (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + chunk0 + 4 * qd;
-      if (al && 4 * qd + 4 <= chunk_n) *(int4 *)d = make_int4(e[0], e[1], e[2], e[3]);
+      const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + chunk0 + 4 * qd;
+      if (al && 4 * qd + 4 <= chunk_n) S_::store4(store + at, wide + at, e[0], e[1], e[2], e[3]);
       else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (4 * qd + k < chunk_n) d[k] = e[k];
+        for (int k = 0; k < 4; ++k) if (4 * qd + k < chunk_n) S_::store1(store + at + k, wide + at + k, e[k]);
       }
     }
   }
@@ -475,15 +485,17 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
     const int *src = core + band * C::PLANE;
     if (by_slice && !(band == 0 && !p.ll_to_store)) continue; // written above
     if (band == 0 && !p.ll_to_store) {
-      int32_t *ll = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+      ST *ll = (ST *)p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+      int32_t *ll_w = S_::narrow ? p.ll_wide[comp] + (size_t)pic * p.ll_stride[comp] : nullptr;
       const int ow = in_w >> 1;
       const bool v4 = (ow & 3) == 0;
       for (int id = threadIdx.x; id < (TY / 2) * (TX / 8); id += NT) {
         const int i = id / TXQ, jq = id % TXQ;
         const I4 v = lds_ld4(src + i * WXP + 4 * jq);
-        int32_t *d = ll + (size_t)(y0 / 2 + i) * ow + x0 / 2 + 4 * jq;
-        if (v4) *(int4 *)d = make_int4(v.x, v.y, v.z, v.w);
-        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        const size_t at = (size_t)(y0 / 2 + i) * ow + x0 / 2 + 4 * jq;
+        if (v4) S_::store4(ll + at, ll_w + at, v.x, v.y, v.z, v.w);
+        else { S_::store1(ll + at, ll_w + at, v.x); S_::store1(ll + at + 1, ll_w + at + 1, v.y);
+               S_::store1(ll + at + 2, ll_w + at + 2, v.z); S_::store1(ll + at + 3, ll_w + at + 3, v.w); }
       }
       continue;
     }
@@ -495,16 +507,16 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
         const int si = s >> tsx_l, sj = s & ((1 << tsx_l) - 1);
         const int r = rem >> lbsw, c = rem & (bsw - 1);
         const I4 v = lds_ld4(src + ((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c);
-        int32_t *d = store + (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem;
-        *(int4 *)d = make_int4(v.x, v.y, v.z, v.w);
+        const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem;
+        S_::store4(store + at, wide + at, v.x, v.y, v.z, v.w);
       }
     } else {
       for (int e = threadIdx.x; e < (TY / 2) * (TX / 2); e += NT) {
         const int s = e >> lblk, rem = e & ((1 << lblk) - 1);
         const int si = s >> tsx_l, sj = s & ((1 << tsx_l) - 1);
         const int r = rem >> lbsw, c = rem & (bsw - 1);
-        store[(size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem] =
-            src[((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c];
+        const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem;
+        S_::store1(store + at, wide + at, src[((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c]);
       }
     }
   }
@@ -515,8 +527,9 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
 // ------------------------------------------------------------------------------------------
 // SMALL: the band blocks of a slice are narrower than four coefficients (deep levels); the store bands are then
 // gathered slice by slice (see below) instead of window position by window position.
-template <int K, bool FINAL, bool SMALL>
+template <int K, bool FINAL, bool SMALL, class ST>
 __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
+  using S_ = St<ST>;
   using C = Cfg<K>;
   extern __shared__ __attribute__((aligned(16))) int lds[];
   const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
@@ -530,7 +543,8 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   const int fh = p.fh[comp], fw = p.fw[comp];
   const int bsh = fh >> 1, bsw = fw >> 1;
   const int lbsh = ilog2(bsh), lbsw = ilog2(bsw);
-  const int32_t *store = p.store + (size_t)pic * p.store_stride;
+  const ST *store = (const ST *)p.store + (size_t)pic * p.store_stride;
+  const int32_t *wide = S_::narrow ? p.store_wide + (size_t)pic * p.store_stride : nullptr;
   const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * p.xs : nullptr;
 
   // quant_factor / quant_offset by adjusted index, copied next to the planes: the look-up that follows the
@@ -549,9 +563,14 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   // the first one is consumed.
   {
     constexpr int NQI = (WYP * (WXP / 4) + NT - 1) / NT;
-    int4 val[4][NQI];
+    int4 val[4][NQI];             // int16 store / planes: four values in .x, .y
     int qv[4][NQI], kind[4][NQI]; // kind: 0 skip, 1 vector loaded, 2 element-wise path
-    const int32_t *llp = p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+    const ST *llp = (const ST *)p.ll[comp] + (size_t)pic * p.ll_stride[comp];
+    const int32_t *llp_w = S_::narrow ? p.ll_wide[comp] + (size_t)pic * p.ll_stride[comp] : nullptr;
+    auto ldq = [](const ST *q) -> int4 { // the raw 4-element load; unpacked (and escapes resolved) when consumed
+      if constexpr (S_::narrow) { const uint2 v = *(const uint2 *)q; return make_int4((int)v.x, (int)v.y, 0, 0); }
+      else return *(const int4 *)q;
+    };
 #pragma unroll
     for (int band = 0; band < 4; ++band) {
       const bool from_plane = (band == 0 && !p.ll_from_store);
@@ -564,17 +583,17 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         qv[band][it] = 0;
         val[band][it] = make_int4(0, 0, 0, 0);
         if (SMALL && !from_plane) continue; // the store bands come slice by slice, below
-        if (id >= WYP * (WXP / 4) || (p.debug_skip & 1)) continue;
+        if (id >= WYP * (WXP / 4) || VC2_SKIP(p, 1)) continue;
         const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
         const int by = ky_base + i, bx0 = kx_base + 4 * jq;
         if (by < 0 || by >= npy || bx0 + 4 <= 0 || bx0 >= npx) continue;
         const bool inside = vec && bx0 >= 0 && bx0 + 4 <= npx;
         kind[band][it] = inside ? 1 : 2;
         if (!inside) continue;
-        if (from_plane) val[band][it] = *(const int4 *)(llp + (size_t)by * npx + bx0);
+        if (from_plane) val[band][it] = ldq(llp + (size_t)by * npx + bx0);
         else {
           const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
-          val[band][it] = *(const int4 *)(store + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c);
+          val[band][it] = ldq(store + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c);
           if (p.dequant) qv[band][it] = qidx[sv * p.xs + sh];
         }
       }
@@ -592,8 +611,24 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         const int i = id / (WXP / 4), jq = id - i * (WXP / 4);
         const int by = ky_base + i, bx0 = kx_base + 4 * jq;
         int e[4] = {val[band][it].x, val[band][it].y, val[band][it].z, val[band][it].w};
+        if constexpr (S_::narrow) {
+          if (kind[band][it] == 1) {
+            const unsigned w0 = (unsigned)val[band][it].x, w1 = (unsigned)val[band][it].y;
+            e[0] = vc2_lo16(w0); e[1] = vc2_hi16(w0); e[2] = vc2_lo16(w1); e[3] = vc2_hi16(w1);
+            if (min(min(e[0], e[1]), min(e[2], e[3])) == VC2_ST_SENTINEL) { // values that did not fit 16 bits: the wide plane
+              const int32_t *wq;
+              if (from_plane) wq = llp_w + (size_t)by * npx + bx0;
+              else {
+                const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
+                wq = wide + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c;
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) if (e[k] == VC2_ST_SENTINEL) e[k] = wq[k];
+            }
+          }
+        }
         if (kind[band][it] == 1) {
-          if (!from_plane && p.dequant && !(p.debug_skip & 8)) {
+          if (!from_plane && p.dequant && !VC2_SKIP(p, 8)) {
             const int aq = max(qv[band][it] - qm, 0);
             if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
             const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)], lim = qtab[240 + min(aq, 119)];
@@ -614,16 +649,19 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
             }
           }
         } else if (from_plane) {
-          const int32_t *row = llp + (size_t)by * npx;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) e[k] = row[min(max(bx0 + k, 0), npx - 1)];
+          for (int k = 0; k < 4; ++k) {
+            const size_t at = (size_t)by * npx + min(max(bx0 + k, 0), npx - 1);
+            e[k] = S_::load1(llp + at, llp_w + at);
+          }
         } else {
           const int sv = by >> lbsh, r = by & (bsh - 1);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int bx = min(max(bx0 + k, 0), npx - 1);
             const int sh = bx >> lbsw, c = bx & (bsw - 1);
-            int t = store[(size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c];
+            const size_t at = (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c;
+            int t = S_::load1(store + at, wide + at);
             if (p.dequant) {
               const int aq = max(qidx[sv * p.xs + sh] - qm, 0);
               if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
@@ -650,17 +688,15 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
     const int nsc = sc1 - sc0 + 1, nsl = (sr1 - sr0 + 1) * nsc, nq = (chunk_n + 3) >> 2;
     const bool al = ((chunk0 | p.slice_coefs) & 3) == 0;
     const int qm0 = p.qmatrix[0], qm1 = p.qmatrix[p.band], qm2 = p.qmatrix[p.band + 1], qm3 = p.qmatrix[p.band + 2];
-    for (int id = threadIdx.x; id < nsl * nq && !(p.debug_skip & 1); id += NT) {
+    for (int id = threadIdx.x; id < nsl * nq && !VC2_SKIP(p, 1); id += NT) {
       const int sidx = id / nq, qd = id - sidx * nq;
       const int sr = sidx / nsc, sv = sr0 + sr, sh = sc0 + (sidx - sr * nsc);
-      const int32_t *rec = store + (size_t)(sv * p.xs + sh) * p.slice_coefs + chunk0;
+      const size_t at = (size_t)(sv * p.xs + sh) * p.slice_coefs + chunk0 + 4 * qd;
       int e[4];
-      if (al && 4 * qd + 4 <= chunk_n) {
-        const int4 v = *(const int4 *)(rec + 4 * qd);
-        e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
-      } else {
+      if (al && 4 * qd + 4 <= chunk_n) S_::load4(store + at, wide + at, e);
+      else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = 4 * qd + k < chunk_n ? rec[4 * qd + k] : 0;
+        for (int k = 0; k < 4; ++k) e[k] = 4 * qd + k < chunk_n ? S_::load1(store + at + k, wide + at + k) : 0;
       }
       const int q = p.dequant ? qidx[sv * p.xs + sh] : 0;
 #pragma unroll
@@ -671,7 +707,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
         if (i < 0 || i >= WYP || j < 0 || j >= WXP) continue;
         int v = e[k];
-        if (p.dequant && !(p.debug_skip & 8)) {
+        if (p.dequant && !VC2_SKIP(p, 8)) {
           const int aq = max(q - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
           if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
           v = dequant_f(v, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
@@ -686,7 +722,7 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
   {
     constexpr int NQ = WXP / 4;
     constexpr int NITV = (NQ * 2 * (TY / 8) + NT - 1) / NT;
-    if (!(p.debug_skip & 2)) {
+    if (!VC2_SKIP(p, 2)) {
     if constexpr (stepwise<K>()) {
       steps_v<K, true>(lds, 0, NQ, ky_base, npy);
       steps_h<K, true>(lds, HY / 2, TY / 2, kx_base, npx);
@@ -701,11 +737,11 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
     }
     }
   }
-  if (p.debug_skip & 4) return;
+  if (VC2_SKIP(p, 4)) return;
 
   // ---- interleave, round, write (FINAL: clip + offset + justify + big-endian 16-bit words)
   const int lim_h = FINAL ? p.pic_h[comp] : out_h, lim_w = FINAL ? p.pic_w[comp] : out_w;
-  const bool vec_out = FINAL ? (p.word_bytes == 2 && (lim_w & 7) == 0) : ((out_w & 3) == 0);
+  const bool vec_out = FINAL ? (p.word_bytes == 2 && (lim_w & 7) == 0) : ((out_w & 7) == 0);
   for (int id = threadIdx.x; id < TY * (TX / 8); id += NT) {
     const int r = id / TXQ, ch = id % TXQ;
     const int gy = y0 + r, gx0 = x0 + 8 * ch;
@@ -735,19 +771,19 @@ __global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
         }
       }
     } else {
-      int32_t *row = (int32_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)gy * out_w;
-      if (vec_out) {
-        *(int4 *)(row + gx0) = make_int4(s[0], s[1], s[2], s[3]);
-        *(int4 *)(row + gx0 + 4) = make_int4(s[4], s[5], s[6], s[7]);
-      } else {
+      const size_t at = (size_t)pic * p.plane_stride[comp] + (size_t)gy * out_w + gx0;
+      ST *row = (ST *)p.plane[comp] + at;
+      int32_t *row_w = S_::narrow ? p.plane_wide[comp] + at : nullptr;
+      if (vec_out) S_::store8(row, row_w, s);
+      else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) row[gx0 + k] = s[k];
+        for (int k = 0; k < 8; ++k) S_::store1(row + k, row_w + k, s[k]);
       }
     }
   }
 }
 
-template <int K, bool EDGE, bool INV>
+template <int K, bool EDGE, bool INV, class ST>
 void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t s) {
   int gx = 0, gy = 0;
   for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.tiles_x[c]); gy = std::max(gy, p.tiles_y[c]); }
@@ -759,25 +795,25 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
     for (int c = 0; c < 3; ++c) if (p.tiles_x[c] && p.fw[c] / 2 < 4) small = true;
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
     if (small) {
-      vc2_allow_lds((const void *)k_inv_fast<K, EDGE, true>, 160 * 1024);
-      VC2_LAUNCH(L, (k_inv_fast<K, EDGE, true>), grid, block, lds, s, p);
+      vc2_allow_lds((const void *)k_inv_fast<K, EDGE, true, ST>, 160 * 1024);
+      VC2_LAUNCH(L, (k_inv_fast<K, EDGE, true, ST>), grid, block, lds, s, p);
     } else {
-      vc2_allow_lds((const void *)k_inv_fast<K, EDGE, false>, 160 * 1024);
-      VC2_LAUNCH(L, (k_inv_fast<K, EDGE, false>), grid, block, lds, s, p);
+      vc2_allow_lds((const void *)k_inv_fast<K, EDGE, false, ST>, 160 * 1024);
+      VC2_LAUNCH(L, (k_inv_fast<K, EDGE, false, ST>), grid, block, lds, s, p);
     }
   } else {
-    vc2_allow_lds((const void *)k_fwd_fast<K, EDGE>, 160 * 1024);
+    vc2_allow_lds((const void *)k_fwd_fast<K, EDGE, ST>, 160 * 1024);
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
-    VC2_LAUNCH(L, (k_fwd_fast<K, EDGE>), grid, block, lds, s, p);
+    VC2_LAUNCH(L, (k_fwd_fast<K, EDGE, ST>), grid, block, lds, s, p);
   }
   vc2_prof_end(L, s);
 }
 
-template <bool INV> int dispatch_fast(Launcher &L, int kernel, bool edge, const LevelParams &p, int n, hipStream_t s) {
+template <bool INV, class ST> int dispatch_fast(Launcher &L, int kernel, bool edge, const LevelParams &p, int n, hipStream_t s) {
 #define VC2_CASE(KK)                                                   \
   case KK:                                                             \
-    if (edge) launch_fast<KK, true, INV>(L, p, n, s);                  \
-    else launch_fast<KK, false, INV>(L, p, n, s);                      \
+    if (edge) launch_fast<KK, true, INV, ST>(L, p, n, s);              \
+    else launch_fast<KK, false, INV, ST>(L, p, n, s);                  \
     return 0;
   switch (kernel) {
     VC2_CASE(VC2HIP_DD97)
@@ -813,9 +849,10 @@ bool vc2_fast_level_applicable(LevelParams &p) {
   }
   return true;
 }
-int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, hipStream_t s) {
-  return dispatch_fast<false>(L, kernel, first, p, n, s);
+// store16: the store and the level planes hold int16 elements with their wide planes (vc2hip_store.h)
+int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, hipStream_t s) {
+  return store16 ? dispatch_fast<false, int16_t>(L, kernel, first, p, n, s) : dispatch_fast<false, int32_t>(L, kernel, first, p, n, s);
 }
-int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, hipStream_t s) {
-  return dispatch_fast<true>(L, kernel, final_level, p, n, s);
+int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, hipStream_t s) {
+  return store16 ? dispatch_fast<true, int16_t>(L, kernel, final_level, p, n, s) : dispatch_fast<true, int32_t>(L, kernel, final_level, p, n, s);
 }

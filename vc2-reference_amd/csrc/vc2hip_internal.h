@@ -79,12 +79,15 @@ struct QuantTables {
 // ------------------------------------------------------------------------------------------
 struct LevelParams {
   // input of a forward level / output of an inverse level
-  void *plane[3];             // FIRST/FINAL: raw sample words, else int32 LL_l plane
+  void *plane[3];             // FIRST/FINAL: raw sample words, else LL_l plane (ST elements)
   long long plane_stride[3];  // per picture, in bytes (raw) or elements (int32)
-  int32_t *ll[3];             // LL_{l+1} plane (forward: output unless LAST; inverse: input)
+  void *ll[3];                // LL_{l+1} plane, ST elements (forward: output unless LAST; inverse: input)
   long long ll_stride[3];     // per picture, elements
-  int32_t *store;             // coefficient store
+  void *store;                // coefficient store (int32_t or int16_t elements: the kernels' ST parameter)
   long long store_stride;     // per picture, elements
+  int32_t *store_wide;        // int16 store: values outside 16 bits, same element index (vc2hip_store.h)
+  int32_t *plane_wide[3];     // the same for the level planes (not FIRST / FINAL) ...
+  int32_t *ll_wide[3];        // ... and the LL_{l+1} planes
   const int32_t *qidx;        // inverse: per-slice quantiser indices, n_pictures * ys * xs
   int in_h[3], in_w[3];       // plane size at this level (padded >> level)
   int pic_h[3], pic_w[3];     // FIRST/FINAL: unpadded picture size
@@ -103,12 +106,22 @@ struct LevelParams {
   int dequant;                // inverse: apply scale() to store values
   unsigned *err;              // device error flags
   int big_lut;                // set by the launcher: LDS holds subband tables for components of up to 2048 coefficients
-  int debug_skip;             // timing experiments only (VC2HIP_DEBUG_SKIP): 1 no loads, 2 no lifting, 4 no stores
+  int debug_skip;             // -DVC2HIP_ABLATE builds only (tools/ablate_*.py): 1 no loads, 2 no lifting, 4 no stores
   int qmatrix[VC2_MAX_BANDS];
 };
 
+// Work-skipping switches for the timing experiments of tools/ablate_*.py exist only in a library built with
+// -DVC2HIP_ABLATE (the tools build their own); the release kernels carry no such test.
+#ifdef VC2HIP_ABLATE
+#define VC2_SKIP(p, bit) (((p).debug_skip & (bit)) != 0)
+#else
+#define VC2_SKIP(p, bit) false
+#endif
+
 struct PackParams {
-  const int32_t *store;
+  const void *store;          // int32_t or int16_t elements (store16)
+  const int32_t *store_wide;
+  int store16;
   long long store_stride;
   const int32_t *qidx;        // n_pictures * n_slices (ConstQ: filled by host)
   int n_slices, slice_coefs;
@@ -140,7 +153,9 @@ struct UnpackParams {
   long long payload_stride;
   const unsigned long long *lens; // per picture
   const uint32_t *offsets;    // n_pictures * n_slices slice start offsets
-  int32_t *store;
+  void *store;                // int32_t or int16_t elements (store16)
+  int32_t *store_wide;
+  int store16;
   long long store_stride;
   int32_t *qidx;
   int n_slices, slice_coefs;
@@ -150,7 +165,9 @@ struct UnpackParams {
 };
 
 struct CbrParams {
-  const int32_t *store;
+  const void *store;          // int32_t or int16_t elements (store16)
+  const int32_t *store_wide;
+  int store16;
   long long store_stride;
   int32_t *qidx;
   const int32_t *slice_bytes;
@@ -183,7 +200,7 @@ void vc2_allow_lds(const void *kernel, size_t bytes);
 
 void vc2_upload_tables(const QuantTables &t, hipStream_t s);
 int vc2_launch_forward_level(Launcher &L, int kernel, bool first, const LevelParams &p, int n_pictures,
-                             hipStream_t s);
+                             hipStream_t s); // generic kernels: int32 store and planes only
 int vc2_launch_inverse_level(Launcher &L, int kernel, bool final_level, const LevelParams &p,
                              int n_pictures, hipStream_t s);
 size_t vc2_level_lds_bytes(int kernel, const LevelParams &p);

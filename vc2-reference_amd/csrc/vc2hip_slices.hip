@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "vc2hip_internal.h"
+#include "vc2hip_store.h"
 
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
 void vc2_prof_end(Launcher &L, hipStream_t s);
@@ -273,19 +274,17 @@ void vc2_upload_vlc_lut(hipStream_t s) {
 __device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, unsigned *err, const unsigned *lut);
 
 // load (and quantise) the 8 coefficients [j0, j0+8) of a component record
-template <bool QUANT>
-__device__ __forceinline__ void load8(Coef8 &c, const int32_t *src, int j0, int n, int n0, int n0_shift, const uint4 *qtab,
-                                      unsigned *err, const unsigned *lut) {
+template <bool QUANT, class ST>
+__device__ __forceinline__ void load8(Coef8 &c, const ST *src, const int32_t *wide, int j0, int n, int n0, int n0_shift,
+                                      const uint4 *qtab, unsigned *err, const unsigned *lut) {
   c.sum = 0;
   c.last_end = 0;
   int raw[8];
   const bool full = j0 + 8 <= n;
-  if (full) {
-    const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
-    raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w;
-  } else {
+  if (full) St<ST>::load8(src + j0, wide + j0, raw);
+  else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) raw[k] = j0 + k < n ? src[j0 + k] : 0;
+    for (int k = 0; k < 8; ++k) raw[k] = j0 + k < n ? St<ST>::load1(src + j0 + k, wide + j0 + k) : 0;
   }
   if (QUANT) { // quantiser constants of the slice's index per subband: qtab (LDS), see k_hq_pack
     const int b0 = band_of_index_fast(min(j0, n - 1), n0, n0_shift), b7 = band_of_index_fast(min(j0 + 7, n - 1), n0, n0_shift);
@@ -342,14 +341,14 @@ __device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, u
 // coefficient index comes from a per-workgroup byte table, the quantiser constants of every subband
 // from a per-slice table, both in LDS -- no per-coefficient band arithmetic, no divergence between
 // lanes whose eight coefficients straddle subbands and lanes whose do not.
-__device__ __forceinline__ void load8_tab(Coef8 &c, const int32_t *src, int j0, int n, const unsigned char *band_lut,
+template <class ST>
+__device__ __forceinline__ void load8_tab(Coef8 &c, const ST *src, const int32_t *wide, int j0, int n, const unsigned char *band_lut,
                                           const uint4 *qtab, unsigned *err, const unsigned *lut) {
   c.sum = 0;
   c.last_end = 0;
   int raw[8];
   if (j0 + 8 <= n) {
-    const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
-    raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w;
+    St<ST>::load8(src + j0, wide + j0, raw);
     const uint2 bands = *(const uint2 *)(band_lut + j0);
     // quant(), Quantisation.cpp:69-76, eight at a time: the reciprocal multiply for all, then ONE test whether any of
     // them left its domain (factor <= 1 or |v| << 2 overflowed: sign bit of `a | (factor - 2)`, the table's 4th word)
@@ -394,7 +393,7 @@ __device__ __forceinline__ void load8_tab(Coef8 &c, const int32_t *src, int j0, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       raw[k] = 0;
-      if (j0 + k < n) { const uint4 t = qtab[band_lut[j0 + k]]; raw[k] = quant_core(src[j0 + k], (int)t.z, t.x, (int)t.y); }
+      if (j0 + k < n) { const uint4 t = qtab[band_lut[j0 + k]]; raw[k] = quant_core(St<ST>::load1(src + j0 + k, wide + j0 + k), (int)t.z, t.x, (int)t.y); }
     }
   }
   codes8(c, raw, j0, n, err, lut);
@@ -426,12 +425,13 @@ __device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const 
 __device__ __forceinline__ void put_byte(unsigned *img, int off, unsigned b) { atomicOr(&img[off >> 2], b << (24 - 8 * (off & 3))); }
 
 
-__device__ __forceinline__ void bits8_tab(const int *src, int j0, int n, const unsigned char *band_lut, const uint4 *qtab,
-                                          unsigned *err, int &sum, int &last_end);
+template <class ST>
+__device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, int j0, int n, const unsigned char *band_lut,
+                                          const uint4 *qtab, unsigned *err, int &sum, int &last_end);
 
 // W lanes work on one slice: 64 (a wavefront per slice, any geometry) or, for small slices, 32 / 16 with two / four
 // slices per wavefront, so that a slice of e.g. 128 + 2 x 64 coefficients (1080p, -u 2 -a 4) still fills its lanes.
-template <int W, bool MID = false>
+template <int W, bool MID, class ST>
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   constexpr int S = 64 / W;
   extern __shared__ unsigned lds_u[];
@@ -488,7 +488,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   bool bad_cbr = false;
   if (active) {
     q = p.qidx[(size_t)pic * p.n_slices + slice];
-    const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+    const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+    const ST *rec = (const ST *)p.store + rec_at;
+    const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
     const int cbr_total = p.cbr_bytes ? p.cbr_bytes[slice] : 0;
     auto comp_len = [&](int count) -> int {
       int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
@@ -508,12 +510,12 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       { // luma: one round
         const int n = p.comp_n[0], n0 = p.comp_n0[0];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        if (p.quantise) load8_tab(c, rec + p.comp_off[0], sl * 8, n, band_y, qtab, p.err, lut);
-        else load8<false>(c, rec + p.comp_off[0], sl * 8, n, n0, n0s, qtab, p.err, lut);
+        if (p.quantise) load8_tab(c, rec + p.comp_off[0], recw + p.comp_off[0], sl * 8, n, band_y, qtab, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[0], recw + p.comp_off[0], sl * 8, n, n0, n0s, qtab, p.err, lut);
         const int incl = seg_incl_scan<W>(c.sum, sl);
         const int count = seg_max<W>(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
-        write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, p.debug_skip & 1);
+        write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, VC2_SKIP(p, 1));
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
         base += 1 + bytes[0];
       }
@@ -521,8 +523,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int n = p.comp_n[1], n0 = p.comp_n0[1];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
         const int half = sl >= W / 2 ? 1 : 0, cc = 1 + half;
-        if (p.quantise) load8_tab(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, band_c, qtab, p.err, lut);
-        else load8<false>(c, rec + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, n0, n0s, qtab, p.err, lut);
+        if (p.quantise) load8_tab(c, rec + p.comp_off[cc], recw + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, band_c, qtab, p.err, lut);
+        else load8<false>(c, rec + p.comp_off[cc], recw + p.comp_off[cc], (sl & (W / 2 - 1)) * 8, n, n0, n0s, qtab, p.err, lut);
         const int incl = seg_incl_scan<W>(c.sum, sl);
         const int total_u = __shfl(incl, seg * W + W / 2 - 1);
         const int rel = incl - c.sum - (half ? total_u : 0);
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         bytes[1] = comp_len(__shfl(cnt, seg * W));
         bytes[2] = cbr_v(comp_len(__shfl(cnt, seg * W + W / 2)));
         const int base_c = half ? base + 1 + bytes[1] : base;
-        write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, p.debug_skip & 1);
+        write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, VC2_SKIP(p, 1));
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
         if (sl == W / 2) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
       }
@@ -538,14 +540,15 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       for (int cc = 0; cc < 3; ++cc) {
         const int n = p.comp_n[cc], n0 = p.comp_n0[cc];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        const int32_t *src = rec + p.comp_off[cc];
+        const ST *src = rec + p.comp_off[cc];
+        const int32_t *srcw = recw + p.comp_off[cc];
         Coef8 c;
         int run = 0, count = 0;
         const unsigned char *band_lut = cc ? big_c : big_y;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (mid) bits8_tab(src, r0 + lane * 8, n, band_lut, qtab, p.err, c.sum, c.last_end); // lengths only
-          else if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
-          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          if (mid) bits8_tab(src, srcw, r0 + lane * 8, n, band_lut, qtab, p.err, c.sum, c.last_end); // lengths only
+          else if (p.quantise) load8<true>(c, src, srcw, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          else load8<false>(c, src, srcw, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           count = max(count, wave_max(c.last_end ? run + incl - c.sum + c.last_end : 0));
           run += __builtin_amdgcn_readlane(incl, 63);
@@ -554,9 +557,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         if (cc == 2) bytes[2] = cbr_v(bytes[2]);
         run = 0;
         for (int r0 = 0; r0 < n; r0 += 512) {
-          if (mid) load8_tab(c, src, r0 + lane * 8, n, band_lut, qtab, p.err, lut);
-          else if (p.quantise) load8<true>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
-          else load8<false>(c, src, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          if (mid) load8_tab(c, src, srcw, r0 + lane * 8, n, band_lut, qtab, p.err, lut);
+          else if (p.quantise) load8<true>(c, src, srcw, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
+          else load8<false>(c, src, srcw, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
           const int incl = wave_incl_scan(c.sum, lane);
           write8(img, 8 * (base + 1) + run + incl - c.sum, 8 * (base + 1 + bytes[cc]), c);
           run += __builtin_amdgcn_readlane(incl, 63);
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     }
     __syncthreads();
   }
-  if (!active || (p.debug_skip & 2)) return;
+  if (!active || VC2_SKIP(p, 2)) return;
 
   if (p.lookback) {
     unsigned long long off = s_base;
@@ -648,7 +651,9 @@ static size_t pack_lds(int prefix, int scalar, int slices_per_wave, bool big_lut
 size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
+#ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
+#endif
   // lanes per slice: as few as still hold the slice (8 luma / 4 chroma coefficients and one subband constant per lane)
   int W = 64;
   const bool same_c = p.comp_n[1] == p.comp_n[2];
@@ -665,19 +670,23 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
   const size_t lds = pack_lds(p.prefix, p.scalar, S, p.big_lut);
   const int tiles = (p.n_slices + 4 * S - 1) / (4 * S);
   vc2_prof_begin(L, "hq_pack", s);
-  if (W == 16) {
-    vc2_allow_lds((const void *)k_hq_pack<16>, 144 * 1024);
-    VC2_LAUNCH(L, k_hq_pack<16>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
-  } else if (W == 32) {
-    vc2_allow_lds((const void *)k_hq_pack<32>, 144 * 1024);
-    VC2_LAUNCH(L, k_hq_pack<32>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
-  } else if (p.big_lut) {
-    vc2_allow_lds((const void *)k_hq_pack<64, true>, 144 * 1024);
-    VC2_LAUNCH(L, (k_hq_pack<64, true>), dim3(tiles, n_pictures), dim3(256), lds, s, p);
+#define VC2_PACK_LAUNCH(WW, MM, TT)                                                                   \
+  do {                                                                                                \
+    vc2_allow_lds((const void *)k_hq_pack<WW, MM, TT>, 144 * 1024);                                   \
+    VC2_LAUNCH(L, (k_hq_pack<WW, MM, TT>), dim3(tiles, n_pictures), dim3(256), lds, s, p);            \
+  } while (0)
+  if (p.store16) {
+    if (W == 16) VC2_PACK_LAUNCH(16, false, int16_t);
+    else if (W == 32) VC2_PACK_LAUNCH(32, false, int16_t);
+    else if (p.big_lut) VC2_PACK_LAUNCH(64, true, int16_t);
+    else VC2_PACK_LAUNCH(64, false, int16_t);
   } else {
-    vc2_allow_lds((const void *)k_hq_pack<64>, 144 * 1024);
-    VC2_LAUNCH(L, k_hq_pack<64>, dim3(tiles, n_pictures), dim3(256), lds, s, p);
+    if (W == 16) VC2_PACK_LAUNCH(16, false, int32_t);
+    else if (W == 32) VC2_PACK_LAUNCH(32, false, int32_t);
+    else if (p.big_lut) VC2_PACK_LAUNCH(64, true, int32_t);
+    else VC2_PACK_LAUNCH(64, false, int32_t);
   }
+#undef VC2_PACK_LAUNCH
   vc2_prof_end(L, s);
 }
 
@@ -755,12 +764,13 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
 }
 
 // bits of eight coefficients of one component, quantised through the tables: total and end of the last non-zero code
-__device__ __forceinline__ void bits8_tab(const int *src, int j0, int n, const unsigned char *band_lut, const uint4 *qtab,
-                                        unsigned *err, int &sum, int &last_end) {
+template <class ST>
+__device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, int j0, int n, const unsigned char *band_lut,
+                                          const uint4 *qtab, unsigned *err, int &sum, int &last_end) {
   sum = 0; last_end = 0;
   if (j0 + 8 <= n) {
-    const int4 a = *(const int4 *)(src + j0), b = *(const int4 *)(src + j0 + 4);
-    const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int v[8];
+    St<ST>::load8(src + j0, wide + j0, v);
     const uint2 bands = *(const uint2 *)(band_lut + j0);
     // the reciprocal multiply for all eight, one test whether any left its domain (see load8_tab)
     unsigned a8[8], qf8[8], dom = 0;
@@ -790,7 +800,7 @@ __device__ __forceinline__ void bits8_tab(const int *src, int j0, int n, const u
   } else {
     for (int k = 0; k < 8 && j0 + k < n; ++k) {
       const uint4 t = qtab[band_lut[j0 + k]];
-      const int c = quant_core(src[j0 + k], (int)t.z, t.x, (int)t.y);
+      const int c = quant_core(St<ST>::load1(src + j0 + k, wide + j0 + k), (int)t.z, t.x, (int)t.y);
       int nb = svlc_bits(c);
       if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
       sum += nb;
@@ -802,6 +812,7 @@ __device__ __forceinline__ void bits8_tab(const int *src, int j0, int n, const u
 // ------------------------------------------------------------------------------------------
 // HQ_CBR quantiser search: one wavefront per slice, slice coefficients staged in LDS
 // ------------------------------------------------------------------------------------------
+template <class ST>
 __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6; // 1..4 wavefronts per workgroup
@@ -822,8 +833,21 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   __syncthreads();
   if (slice >= p.n_slices) return; // no workgroup barriers below
   int *co = lds_i + wave * p.slice_coefs;
-  const int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-  for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
+  {
+    const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+    const ST *rec = (const ST *)p.store + rec_at;
+    const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
+    if ((p.slice_coefs & 7) == 0 && (rec_at & 7) == 0) {
+      for (int i = lane * 8; i < p.slice_coefs; i += 512) {
+        int e[8];
+        St<ST>::load8(rec + i, recw + i, e);
+        *(int4 *)(co + i) = make_int4(e[0], e[1], e[2], e[3]);
+        *(int4 *)(co + i + 4) = make_int4(e[4], e[5], e[6], e[7]);
+      }
+    } else {
+      for (int i = lane; i < p.slice_coefs; i += 64) co[i] = St<ST>::load1(rec + i, recw + i);
+    }
+  }
   wave_lds_sync(); // no cross-wave sharing of `co`
 
   const int avail = p.slice_bytes[slice] - 4;
@@ -850,11 +874,11 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
     if (fast) {
       if (!set_q(tq)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); }
       int sum, last_end;
-      bits8_tab(co + p.comp_off[0], lane * 8, p.comp_n[0], band_y, qtab, p.err, sum, last_end); // luma: one round
+      bits8_tab<int32_t>(co + p.comp_off[0], nullptr, lane * 8, p.comp_n[0], band_y, qtab, p.err, sum, last_end); // luma: one round
       int incl = wave_incl_scan(sum, lane);
       need += comp_bytes(wave_max(last_end ? incl - sum + last_end : 0), bad);
       const int half = lane >> 5;                                               // lanes 0-31 U, lanes 32-63 V
-      bits8_tab(co + p.comp_off[1 + half], (lane & 31) * 8, p.comp_n[1], band_c, qtab, p.err, sum, last_end);
+      bits8_tab<int32_t>(co + p.comp_off[1 + half], nullptr, (lane & 31) * 8, p.comp_n[1], band_c, qtab, p.err, sum, last_end);
       incl = wave_incl_scan(sum, lane);
       const int total_u = __shfl(incl, 31); // every lane takes part in the shuffle
       const int rel = incl - sum - (half ? total_u : 0);
@@ -935,9 +959,14 @@ int vc2_waves_for_lds(size_t per_wave) {
 void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
   const size_t per_wave = (size_t)p.slice_coefs * 4 + 32 * 16, tables = 768; // + the wavefront's quantiser table; + band tables
   const int wpw = std::max(1, std::min(4, (int)((160 * 1024 - tables) / per_wave)));
-  vc2_allow_lds((const void *)k_cbr_search, 160 * 1024);
   vc2_prof_begin(L, "cbr_search", s);
-  VC2_LAUNCH(L, k_cbr_search, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
+  if (p.store16) {
+    vc2_allow_lds((const void *)k_cbr_search<int16_t>, 160 * 1024);
+    VC2_LAUNCH(L, k_cbr_search<int16_t>, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
+  } else {
+    vc2_allow_lds((const void *)k_cbr_search<int32_t>, 160 * 1024);
+    VC2_LAUNCH(L, k_cbr_search<int32_t>, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
+  }
   vc2_prof_end(L, s);
 }
 
@@ -1023,20 +1052,29 @@ __device__ __forceinline__ void vlut_init(unsigned short *vlut) {
 }
 
 // One round of the exp-Golomb decoder: `room` (<= UNP_N) coefficients from br into the lane's staging row st.
-template <int UNP_N>
-__device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, const unsigned short *vlut) {
+// T = int: the values as they are.  T = short (16-bit store): a value outside 16 bits leaves the sentinel in the row and
+// goes to wide[position in the round] (vc2hip_store.h); only codes beyond the 10-bit table can be that large.
+template <int UNP_N, class T>
+__device__ __forceinline__ void decode_round(WordReader &br, int room, T *st, const unsigned short *vlut, int32_t *wide = nullptr) {
   // zero coefficients are the common case: clear the row, then only non-zero values are stored
 #pragma unroll
-  for (int k = 0; k < UNP_N; k += 4) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
+  for (int k = 0; k < UNP_N; k += 16 / (int)sizeof(T)) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
+  auto put = [&](int at, int v) {
+    if constexpr (sizeof(T) == 2) {
+      if (!St<int16_t>::fits(v)) { wide[at] = v; v = VC2_ST_SENTINEL; }
+    }
+    st[at] = (T)v;
+  };
   int cnt = 0;
   while (cnt < room) {
     const unsigned long long win = br.peek();
-    // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0)
-    const int z = min(__clzll((long long)~win), room - cnt);
+    // run of '1' bits = run of zero coefficients (VLC.cpp:283-295: a lone '1' is the value 0), at most 32 per turn so
+    // that the code behind it lies inside the window
+    const int lz = __clzll((long long)~win);
+    const int z = min(min(lz, room - cnt), 32);
     cnt += z;
-    // a non-zero coefficient follows unless the round is full (z <= room <= 32: the code lies inside the window);
-    // one code path for both cases
-    const bool nz = cnt < room;
+    // a non-zero coefficient follows unless the round is full or the run goes on; one code path for all cases
+    const bool nz = cnt < room && z == lz;
     // non-zero: (0 b)^K 1 s ; follow bits sit at even offsets from the code start
     const unsigned hi = (unsigned)((win << z) >> 32);
     const unsigned follow = hi & 0xAAAAAAAAu;
@@ -1056,13 +1094,15 @@ __device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, 
         r = (br.peek() >> 63) ? (int)(0u - value) : (int)value;
         br.skip(1);
       }
-      st[cnt++] = r;
+      put(cnt++, r);
       continue;
     }
     int val, len;
+    bool big1 = false; // beyond the table: may need the escape
     const unsigned e1 = vlut[hi >> 22];
     if (e1) { val = __builtin_amdgcn_sbfe((int)e1, 0, 8); len = (int)(e1 >> 8); }
     else {
+      big1 = true;
       const int K = __clz((int)(follow | 1u)) >> 1;              // 1..15 for a real code (bit 31 of hi is 0 there)
       const unsigned body = hi >> ((32 - 2 * K) & 31);           // top 2K bits: (0 b) pairs
       const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
@@ -1070,7 +1110,10 @@ __device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, 
       val = neg ? (int)(0u - mag) : (int)mag;
       len = 2 * K + 2;
     }
-    if (nz) st[cnt] = val;
+    if (nz) {
+      if (sizeof(T) == 2 && big1) put(cnt, val);
+      else st[cnt] = (T)val;
+    }
     cnt += nz ? 1 : 0;
     int n = nz ? z + len : z;
     // a second token from the same window when it lies wholly inside it (saves a window build, a refill test and a
@@ -1084,9 +1127,11 @@ __device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, 
       const bool take = nz && n + z2 <= 32 && cnt + z2 < room && follow2 != 0;
       if (take) {
         int val2, len2;
+        bool big2 = false;
         const unsigned e2 = vlut[hi2 >> 22];
         if (e2) { val2 = __builtin_amdgcn_sbfe((int)e2, 0, 8); len2 = (int)(e2 >> 8); }
         else {
+          big2 = true;
           const int K2 = __clz((int)follow2) >> 1;
           const unsigned body2 = hi2 >> ((32 - 2 * K2) & 31);
           const unsigned mag2 = ((1u << K2) | compact_even32(body2)) - 1u;
@@ -1095,7 +1140,9 @@ __device__ __forceinline__ void decode_round(WordReader &br, int room, int *st, 
           len2 = 2 * K2 + 2;
         }
         cnt += z2;
-        st[cnt++] = val2;
+        if (sizeof(T) == 2 && big2) put(cnt, val2);
+        else st[cnt] = (T)val2;
+        ++cnt;
         n += z2 + len2;
       }
     }
@@ -1127,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
     unsigned len = 0;
     if (active) {
       const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
-      const unsigned long long plen = p.lens[pic];
+      const unsigned long long plen = min(p.lens[pic], (unsigned long long)p.payload_stride); // never past the picture's slot
       unsigned long long pos = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
       auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay[a] : 0u; };
       if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(pos);
@@ -1140,14 +1187,14 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
         len = pos < plen ? (unsigned)(plen - pos) : 0;
       }
       data = pay + (pos < plen ? pos : 0);
-      out = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
+      out = (int32_t *)p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
     }
     outp[wave][lane] = (unsigned long long)out;
     if (active) br.init(data, (int)len); else br.init_ones();
   }
   for (int base = 0; base < n; base += UNP_N) {
     const int room = min(UNP_N, n - base);
-    decode_round<UNP_N>(br, room, st, vlut);
+    decode_round<UNP_N, int>(br, room, st, vlut);
     // flush: 4 lanes x 16 bytes per component run.  The staging rows are private to the wavefront, so only
     // its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup barrier,
     // the four wavefronts of the workgroup drift apart freely.
@@ -1172,8 +1219,77 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   }
 }
 
+// The same decoder writing the 16-bit store: 64 coefficients per lane and round staged as shorts (a row is one 128-byte
+// line of the store again), eight lanes flush one row with 16-byte streaming stores.  Needs component sizes that are
+// multiples of 8 (the host selects the 16-bit store only then).
+__global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
+  constexpr int UNP_N = 64, UNP_PITCH = UNP_N + 8; // shorts per staging row, 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) short stage[4][64 * UNP_PITCH];
+  __shared__ unsigned long long outp[4][64];
+  __shared__ unsigned short vlut[1024];
+  vlut_init(vlut);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pic = blockIdx.y, comp = blockIdx.z;
+  const int slice = blockIdx.x * 256 + threadIdx.x;
+  const bool active = slice < p.n_slices;
+  const int n = p.comp_n[comp];
+  short *st = stage[wave] + lane * UNP_PITCH;
+  int32_t *wide = nullptr;
+  WordReader br;
+  {
+    int16_t *out = nullptr;
+    const uint8_t *data = nullptr;
+    unsigned len = 0;
+    if (active) {
+      const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
+      const unsigned long long plen = min(p.lens[pic], (unsigned long long)p.payload_stride);
+      unsigned long long pos = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
+      auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay[a] : 0u; };
+      if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(pos);
+      pos += 1;
+      for (int c = 0; c < comp; ++c) pos += 1 + (unsigned long long)rd(pos) * p.scalar;
+      len = rd(pos) * p.scalar;
+      pos += 1;
+      if (pos + len > plen) {
+        atomicOr(p.err, VC2_DEVERR_STREAM);
+        len = pos < plen ? (unsigned)(plen - pos) : 0;
+      }
+      data = pay + (pos < plen ? pos : 0);
+      const size_t at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
+      out = (int16_t *)p.store + at;
+      wide = p.store_wide + at;
+    }
+    outp[wave][lane] = (unsigned long long)out;
+    if (active) br.init(data, (int)len); else br.init_ones();
+  }
+  for (int base = 0; base < n; base += UNP_N) {
+    const int room = min(UNP_N, n - base);
+    decode_round<UNP_N, short>(br, room, st, vlut, wide + base);
+    wave_lds_sync(); // staging rows are private to the wavefront (see k_hq_unpack)
+    const short *sw = stage[wave];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 8;
+      int16_t *dst = (int16_t *)outp[wave][r];
+      if (dst && c < room) {
+        const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i vv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)(dst + base + c));
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "hq_unpack", s);
+  if (p.store16) {
+    VC2_LAUNCH(L, k_hq_unpack16, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+    vc2_prof_end(L, s);
+    return;
+  }
   // A/B on MI355X, 16 UHD pictures: whole 128-byte lines (32 coefficients per round) 0.48 ms, 64-byte runs 0.52 ms (the other
   // half of every line is fetched back: FETCH_SIZE ~1 GB for 0.15 GB of payload), plain instead of non-temporal stores 0.69 ms
   static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 1; }();
@@ -1230,16 +1346,17 @@ static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
 template <int CH>
 __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *payload, long long stride,
                                                                  const unsigned long long *lens, uint2 *tables,
-                                                                 int n_chunks, int E, int prefix, int scalar, int dbg) {
+                                                                 int n_chunks, int E, int prefix, int scalar, unsigned *err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
-  const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * CH;
+  // a length beyond the picture's slot (hostile or uninitialised) is an error and is never followed out of the slot
+  if (chunk == 0 && threadIdx.x == 0 && lens[pic] > (unsigned long long)stride) atomicOr(err, VC2_DEVERR_STREAM);
+  const unsigned long long plen = min(lens[pic], (unsigned long long)stride), c0 = (unsigned long long)chunk * CH;
   if (c0 >= plen) return;
   const int nbytes = (CH + E + 16 + 15) & ~15;
   unsigned short *nx = (unsigned short *)(lds_b + nbytes); // >= CH: left the chunk at offset nx - CH
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
   __syncthreads();
-  if (dbg == 1) return;
   const int lim = (int)min((unsigned long long)CH, plen - c0); // never walk the zero fill behind the payload
   constexpr int PER = CH / IDX_THREADS;
   {
@@ -1262,13 +1379,12 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
     }
   }
   __syncthreads();
-  if (dbg == 2) return;
   uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
   for (int e = threadIdx.x; e < E; e += IDX_THREADS) {
     int pos = e, cnt = 0;
     if (e >= lim) pos = CH; // starts behind the payload end: no slice
     while (pos < CH) { pos = nx[pos]; ++cnt; }
-    if (dbg != 3) tab[e] = make_uint2((unsigned)(pos - CH), (unsigned)cnt);
+    tab[e] = make_uint2((unsigned)(pos - CH), (unsigned)cnt);
   }
 }
 
@@ -1278,10 +1394,10 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
 //   chain  : per picture, follow entry -> exit through the group functions, then expand every group
 static constexpr int IDX_GROUP = 16;
 
-__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, const uint2 *tables,
+__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const uint2 *tables,
                                                      uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH) {
   const int g = blockIdx.x, pic = blockIdx.y;
-  const unsigned long long plen = lens[pic];
+  const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
   if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) return;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     unsigned x = (unsigned)e, cnt = 0;
@@ -1296,12 +1412,13 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
   }
 }
 
-__global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *lens, const uint2 *tables,
+constexpr int IDX_MAX_GROUPS = 1024;
+__global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *lens, long long stride, const uint2 *tables,
                                                     const uint2 *groups, uint2 *entries, int n_chunks,
                                                     int n_groups, int E, int IDX_CH) {
-  __shared__ uint2 g_entry[64 * 16];
+  __shared__ uint2 g_entry[IDX_MAX_GROUPS]; // the launcher keeps n_groups within it (larger chunks for larger slots)
   const int pic = blockIdx.x;
-  const unsigned long long plen = lens[pic];
+  const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
   if (threadIdx.x == 0) {
     unsigned entry = 0, base = 0;
     for (int g = 0; g < n_groups; ++g) {
@@ -1333,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_index_emit(const uint8_t *payload, long
                                                    int prefix, int scalar, unsigned *err, int IDX_CH) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
-  const unsigned long long plen = lens[pic], c0 = (unsigned long long)chunk * IDX_CH;
+  const unsigned long long plen = min(lens[pic], (unsigned long long)stride), c0 = (unsigned long long)chunk * IDX_CH;
   if (c0 >= plen) return;
   const uint2 en = entries[(size_t)pic * n_chunks + chunk];
   if ((int)en.y >= n_slices || (int)en.x >= IDX_CH) return;
@@ -1361,7 +1478,8 @@ __global__ __launch_bounds__(64) void k_index_serial(const uint8_t *payload, lon
   const int pic = blockIdx.x * 64 + threadIdx.x;
   if (pic >= n_pictures) return;
   const uint8_t *pay = payload + (size_t)pic * stride;
-  const unsigned long long plen = lens[pic];
+  if (lens[pic] > (unsigned long long)stride) atomicOr(err, VC2_DEVERR_STREAM);
+  const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
   unsigned long long pos = 0;
   for (int k = 0; k < n_slices; ++k) {
     offsets[(size_t)pic * n_slices + k] = (uint32_t)pos;
@@ -1380,6 +1498,7 @@ size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix,
   if (E > (size_t)IDX_MAX_E) return 256;
   const size_t ch = (size_t)idx_chunk((int)E);
   const size_t n_chunks = (max_payload + ch - 1) / ch + 1;
+  if (n_chunks > (size_t)1024 * 16) return 256; // serial walk (see vc2_launch_slice_index)
   const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
   return (size_t)n_pictures * (n_chunks * (E + 1) + n_groups * E) * sizeof(uint2) + 256;
 }
@@ -1390,7 +1509,11 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
                             void *workspace, size_t workspace_bytes) {
   const int E = idx_entries(prefix, scalar);
   (void)workspace_bytes;
-  if (E > IDX_MAX_E) {
+  // the chain kernel holds one entry per group of 16 chunks in LDS: slots beyond IDX_MAX_GROUPS groups (256 MiB at
+  // 16 KiB chunks) take the serial walk like over-long slices do
+  const bool too_many = E <= IDX_MAX_E &&
+      ((size_t)payload_stride + idx_chunk(E) - 1) / idx_chunk(E) + 1 > (size_t)IDX_MAX_GROUPS * IDX_GROUP;
+  if (E > IDX_MAX_E || too_many) {
     vc2_prof_begin(L, "slice_index_serial", s);
     VC2_LAUNCH(L, k_index_serial, dim3((n_pictures + 63) / 64), dim3(64), 0, s, payload, payload_stride, lens,
                        offsets, n_slices, prefix, scalar, err, n_pictures);
@@ -1404,27 +1527,25 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   uint2 *entries = tables + (size_t)n_pictures * n_chunks * E;
   const size_t stage_bytes = (size_t)((ch + E + 16 + 15) & ~15);
   vc2_allow_lds((const void *)k_index_emit, stage_bytes);
-  const char *dbg_env = getenv("VC2HIP_DEBUG_INDEX");
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
   vc2_prof_begin(L, "slice_index_tables", s);
   {
     const size_t lds = stage_bytes + (size_t)ch * 2;
     if (ch == 16384) {
       vc2_allow_lds((const void *)k_index_tables_nx<16384>, lds);
       VC2_LAUNCH(L, (k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, dbg);
+                         lens, tables, n_chunks, E, prefix, scalar, err);
     } else {
       vc2_allow_lds((const void *)k_index_tables_nx<32768>, lds);
       VC2_LAUNCH(L, (k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, dbg);
+                         lens, tables, n_chunks, E, prefix, scalar, err);
     }
   }
   vc2_prof_end(L, s);
   const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 256 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
-  VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, tables, groups, n_chunks, n_groups, E, ch);
-  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, tables, groups, entries, n_chunks, n_groups, E, ch);
+  VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch);
+  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
   VC2_LAUNCH(L, k_index_emit, dim3(n_chunks, n_pictures), dim3(256), stage_bytes, s, payload,
@@ -1474,7 +1595,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
   const int ny = chroma ? 0 : p.comp_n[0];
   for (int base = 0; base < ny; base += UNP_N) {
     const int room = min(UNP_N, ny - base);
-    decode_round<UNP_N>(br, room, st, vlut);
+    decode_round<UNP_N, int>(br, room, st, vlut);
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < LPR; ++j) {
@@ -1499,7 +1620,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
   const int nc = chroma ? 2 * p.comp_n[1] : 0;
   for (int base = 0; base < nc; base += UNP_N) {
     const int room = min(UNP_N, nc - base);
-    decode_round<UNP_N>(br, room, st, vlut);
+    decode_round<UNP_N, int>(br, room, st, vlut);
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < LPR; ++j) {
