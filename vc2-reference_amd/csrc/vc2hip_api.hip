@@ -24,6 +24,10 @@ void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
 bool vc2_fast_level_applicable(LevelParams &p);
 int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, hipStream_t s);
 int vc2_launch_inverse_fast(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, hipStream_t s);
+void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s);
+size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool inverse, bool store16, int n_pictures);
+int vc2_launch_forward_stream(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s);
+int vc2_launch_inverse_stream(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s);
 void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s);
 void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 
@@ -117,6 +121,7 @@ struct vc2hip_ctx {
   bool two_pass_vbr = true;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
+  bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
   // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
   // sub-batches overlap: the tail of one launch is filled by the next stream's work.
@@ -269,6 +274,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   c->device = device;
   { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
   { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
+  { const char *e = getenv("VC2HIP_NO_STREAM"); c->allow_stream = !(e && e[0] == '1'); }
 #ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
 #endif
@@ -286,6 +292,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   vc2_upload_tables(t, c->stream);
   vc2_upload_tables_slices(t, c->stream);
   vc2_upload_tables_fast(t, c->stream);
+  vc2_upload_tables_stream(t, c->stream);
   vc2_upload_vlc_lut(c->stream);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   *out = c;
@@ -631,6 +638,15 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
     }
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;
+    if (!c->force_generic && c->allow_stream) {
+      LevelParams ps = p;
+      const size_t lds = vc2_stream_level_applicable(ps, kernel, first, false, s16, n);
+      if (lds) {
+        int rc = vc2_launch_forward_stream(c->L, kernel, first, ps, n, s16, lds, c->stream);
+        if (rc) return set_err(c, rc, "invalid wavelet kernel");
+        continue;
+      }
+    }
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
       int rc = vc2_launch_forward_fast(c->L, kernel, first, pf, n, s16, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -672,6 +688,15 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
     }
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;
+    if (!c->force_generic && c->allow_stream) {
+      LevelParams ps = p;
+      const size_t lds = vc2_stream_level_applicable(ps, kernel, fin, true, s16, n);
+      if (lds) {
+        int rc = vc2_launch_inverse_stream(c->L, kernel, fin, ps, n, s16, lds, c->stream);
+        if (rc) return set_err(c, rc, "invalid wavelet kernel");
+        continue;
+      }
+    }
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
       int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, s16, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");

@@ -1,0 +1,761 @@
+// Streaming DWT / IDWT level kernels: the hot configuration (planes at least 512 samples wide).
+//
+// One wavefront owns a strip of 64 chunks (8 samples each: one 16-byte load per lane and row, 1 KiB per wavefront) and
+// walks down the rows of its segment.  Nothing is shared between wavefronts and there is no workgroup barrier:
+//   * horizontal lifting runs in registers on the lane's 4 coefficient pairs; the taps beyond the chunk come from the
+//     neighbouring lanes with DPP wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1).  The first / last lane of
+//     a wavefront has no such neighbour and keeps the `old` operand, which is set to the lane's own edge pair: when
+//     the strip starts / ends at the plane edge that IS the reference's tap clamping (WaveletTransform.cpp:478-1265:
+//     even taps clamp to [0, n-2], odd taps to [1, n-1]); inside the plane those lanes are halo lanes whose results
+//     are not written (strips overlap by the halo).
+//   * vertical lifting is a line-based scheme: the rows still needed by a later lifting step stay in registers (a
+//     window of a few rows per step); every new row pair completes one output row pair a few rows higher up.
+//     Rows above / below the plane replicate the first / last pair (the same clamping).
+//   * rows are prefetched several pairs ahead into registers, so a wavefront always has ~8 KiB of loads in flight.
+//   * the coefficient store keeps every slice's coefficients together, so the three detail bands pass
+//     through a small wavefront-private LDS image laid out [band][row][slice][column]: rows are written / read by
+//     the lanes without bank conflicts and move to / from the slice records as whole 16-byte pieces of the
+//     contiguous [HL | LH | HH] run of a slice, one block row of slices at a time.
+// Same LevelParams and the same results as the tile kernels of vc2hip_dwt_fast.hip, which remain for every geometry
+// this scheme does not cover (narrow planes, deep levels, padded widths).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "vc2hip_internal.h"
+#include "vc2hip_store.h"
+#include "vc2hip_wavelets.h"
+
+void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
+void vc2_prof_end(Launcher &L, hipStream_t s);
+
+__constant__ QuantTables c_qst;
+void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s) {
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_qst), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
+}
+
+namespace {
+
+constexpr int PF = 2; // row pairs prefetched ahead (divides the ring length RL)
+
+// one row of a lane's chunk: elements 0..3 even columns, 4..7 odd columns
+struct Row {
+  int v[8];
+  __device__ __forceinline__ int &operator[](int i) { return v[i]; }
+  __device__ __forceinline__ const int &operator[](int i) const { return v[i]; }
+};
+__device__ __forceinline__ Row operator+(const Row &a, const Row &b) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+__device__ __forceinline__ Row operator-(const Row &a, const Row &b) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] - b.v[i]; return r; }
+__device__ __forceinline__ Row operator-(const Row &a) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = -a.v[i]; return r; }
+__device__ __forceinline__ Row operator+(const Row &a, int b) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] + b; return r; }
+__device__ __forceinline__ Row operator*(int b, const Row &a) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = b * a.v[i]; return r; }
+__device__ __forceinline__ Row operator>>(const Row &a, int b) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] >> b; return r; }
+
+template <int CTRL> __device__ __forceinline__ int dppm(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------
+// lifting step tables of wavelet K as constexpr functions of the step number
+// ------------------------------------------------------------------------------------------
+template <int K> constexpr int kdmin(int s) {
+  return s == 0 ? step_dmin<K, 0>() : s == 1 ? step_dmin<K, 1>() : s == 2 ? step_dmin<K, 2>() : step_dmin<K, 3>();
+}
+template <int K> constexpr int kdmax(int s) {
+  return s == 0 ? step_dmax<K, 0>() : s == 1 ? step_dmax<K, 1>() : s == 2 ? step_dmax<K, 2>() : step_dmax<K, 3>();
+}
+template <int K> constexpr bool kodd(int s) {
+  return s == 0 ? step_targets_odd<K, 0>() : s == 1 ? step_targets_odd<K, 1>() : s == 2 ? step_targets_odd<K, 2>() : step_targets_odd<K, 3>();
+}
+// halo lanes per strip side: the lifting steps of a row reach sum(|dmin|) pairs to the left and sum(dmax) to the right
+template <int K> constexpr int halo_lanes() {
+  int l = 0, r = 0;
+  for (int s = 0; s < WT<K>::nsteps; ++s) { l -= kdmin<K>(s); r += kdmax<K>(s); }
+  return ((l > r ? l : r) + 3) / 4;
+}
+
+// ------------------------------------------------------------------------------------------
+// horizontal lifting of one row in registers
+// ------------------------------------------------------------------------------------------
+template <int K, int S, bool INV> __device__ __forceinline__ void h_step(Row &r) {
+  constexpr bool odd = step_targets_odd<K, S>();
+  constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
+  constexpr int TO = odd ? 4 : 0, UO = odd ? 0 : 4; // target / source parity inside the row
+  int W[4 + dmax - dmin];
+#pragma unroll
+  for (int j = dmin; j <= 3 + dmax; ++j) {
+    if (j < 0) W[j - dmin] = dppm<0x138>(r[UO], r[UO + 4 + j]);           // left neighbour (wave_shr:1)
+    else if (j > 3) W[j - dmin] = dppm<0x130>(r[UO + 3], r[UO + j - 4]);  // right neighbour (wave_shl:1)
+    else W[j - dmin] = r[UO + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lift_delta<K, S>([&](int t) -> int { return W[i + t - dmin]; });
+    r[TO + i] = INV ? r[TO + i] - d : r[TO + i] + d;
+  }
+}
+template <int K, bool INV> __device__ __forceinline__ void h_lift(Row &r) {
+  constexpr int N = WT<K>::nsteps;
+  if constexpr (!INV) {
+    h_step<K, 0, false>(r);
+    h_step<K, 1, false>(r);
+    if constexpr (N == 4) { h_step<K, 2, false>(r); h_step<K, 3, false>(r); }
+  } else {
+    if constexpr (N == 4) { h_step<K, 3, true>(r); h_step<K, 2, true>(r); }
+    h_step<K, 1, true>(r);
+    h_step<K, 0, true>(r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// vertical lifting, line based.  Positions p = 0..N-1 are the lifting steps in processing order (forward: step p,
+// inverse: step N-1-p).  With row pairs up to index m loaded, position p is complete up to c_p = m - OFF_p,
+// OFF_p = dmax_0 + ... + dmax_p.  Sequences: the raw rows of either parity (complete to m) and X_p, the output of
+// position p (complete to c_p).  Position p reads X_{p-1} (raw for p = 0) at c_p + dmin_p .. c_p + dmax_p and
+// updates X_{p-2} (raw for p < 2) at c_p.  A sequence keeps the rows its consumers still need.
+// ------------------------------------------------------------------------------------------
+template <int K, bool INV> struct VT {
+  static constexpr int N = WT<K>::nsteps;
+  static constexpr int sid(int p) { return INV ? N - 1 - p : p; }
+  static constexpr int dmin(int p) { return kdmin<K>(sid(p)); }
+  static constexpr int dmax(int p) { return kdmax<K>(sid(p)); }
+  static constexpr bool odd(int p) { return kodd<K>(sid(p)); }
+  static constexpr int off(int p) { int s = 0; for (int t = 0; t <= p; ++t) s += dmax(t); return s; }
+  static constexpr int sum_dmin() { int s = 0; for (int t = 0; t < N; ++t) s += dmin(t); return s; }
+  static constexpr int OFFL = off(N - 1);
+  static constexpr int mx(int a, int b) { return a > b ? a : b; }
+  static constexpr int len_raw(bool parity_odd) {
+    if (parity_odd == odd(0)) return off(0) + 1;             // updated by position 0
+    return mx(dmax(0) - dmin(0), N >= 2 ? off(1) : 0) + 1;   // read by position 0, updated by position 1
+  }
+  static constexpr int len_x(int p) {
+    int d = 0;
+    if (p + 1 < N) d = mx(d, dmax(p + 1) - dmin(p + 1));
+    if (p + 2 < N) d = mx(d, dmax(p + 1) + dmax(p + 2));
+    if (p >= N - 2) d = mx(d, off(N - 1) - off(p));
+    return d + 1;
+  }
+};
+
+// Every sequence lives in a ring of RL register rows: the row of index i sits in slot i mod RL.  The walk is unrolled
+// RL times (phase U = (m - m0) mod RL is a compile-time constant inside each copy), so every slot number is a constant
+// and no row is ever moved; a new row overwrites the one RL indices older, which no consumer needs any more
+// (the window lengths of VT are at most RL for every wavelet but Fidelity).
+constexpr int RL = 4;
+template <int K, bool INV> struct VEng {
+  using T = VT<K, INV>;
+  static_assert(T::len_raw(false) <= RL && T::len_raw(true) <= RL && T::len_x(0) <= RL && T::len_x(1) <= RL &&
+                (T::N < 3 || (T::len_x(2) <= RL && T::len_x(3) <= RL)), "row ring too short for this wavelet");
+  Row rw[2][RL]; // raw rows: [0] even rows, [1] odd rows
+  Row x[4][RL];  // outputs of the positions
+  static constexpr int sl(int rel) { return ((rel % RL) + RL) % RL; } // slot of the row `rel` indices from row m, at phase 0
+
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j < RL; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { rw[0][j].v[k] = 0; rw[1][j].v[k] = 0; x[0][j].v[k] = 0; x[1][j].v[k] = 0; x[2][j].v[k] = 0; x[3][j].v[k] = 0; }
+  }
+  // put the row of index `first ? 0 : any` into its slot; index 0 also fills the ring (the rows above the plane replicate it)
+  template <int SLOT> static __device__ __forceinline__ void put(Row (&w)[RL], const Row &r, bool first) {
+    // (element by element, and no store common to two paths: a merged store or copy would address the ring through a
+    // variable and force all of it into scratch memory)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[SLOT].v[k] = r.v[k];
+    if (first) {
+#pragma unroll
+      for (int j = 0; j < RL; ++j)
+        if (j != SLOT) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w[j].v[k] = r.v[k];
+        }
+    }
+  }
+  template <int SRC, int DST> static __device__ __forceinline__ void copy(Row (&w)[RL]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[DST].v[k] = w[SRC].v[k];
+  }
+  // The steady state carries no edge handling: a conditional fill of a ring would be turned into selects that read every
+  // slot in every iteration and keep all of them alive.
+  // Walks start at multiples of RL and planes hold a multiple of RL row pairs (host check), so the phase is m mod RL
+  // everywhere and every edge decision is known at compile time:
+  // MODE 0: steady state.  MODE 1: the first RL iterations of a walk that starts at the plane's top (a sequence
+  // receives its index 0 in iteration off(P)).  MODE 2: the OFFL iterations below the plane's last pair (m = np + U:
+  // nothing is loaded; position P repeats its last row once U + 1 > off(P)).
+  template <int U, int P, int MODE> __device__ __forceinline__ void pos(int m, int np) {
+    if constexpr (P < T::N) {
+      constexpr int dst = sl(U - T::off(P));
+      constexpr int dmin = T::dmin(P), dmax = T::dmax(P);
+      const int c = m - T::off(P);
+      if constexpr (MODE == 2 && (U + 1 > T::off(P))) copy<sl(U - T::off(P) - 1), dst>(x[P]); // below the plane: the last pair again
+      else {
+        Row W[dmax - dmin + 1]; // rows c_P + dmin .. c_P + dmax of what position P reads
+#pragma unroll
+        for (int t = dmin; t <= dmax; ++t) {
+          if constexpr (P == 0) W[t - dmin] = rw[T::odd(0) ? 0 : 1][sl(U - T::off(P) + t)];
+          else W[t - dmin] = x[P - 1][sl(U - T::off(P) + t)];
+        }
+        const Row d = lift_delta<K, T::sid(P)>([&](int t) -> Row { return W[t - dmin]; });
+        Row o;
+        if constexpr (P < 2) o = rw[T::odd(P) ? 1 : 0][dst];
+        else o = x[P - 2][dst];
+        put<dst>(x[P], INV ? o - d : o + d, MODE == 1 && U == T::off(P));
+      }
+      pos<U, P + 1, MODE>(m, np);
+    }
+  }
+  // row pair m (even row re, odd row ro; ignored below the plane) enters at phase U; afterwards pair m - OFFL is complete
+  template <int U, int MODE> __device__ __forceinline__ void step(int m, int np, const Row &re, const Row &ro) {
+    if constexpr (MODE == 2) { copy<sl(U - 1), U>(rw[0]); copy<sl(U - 1), U>(rw[1]); }
+    else { put<U>(rw[0], re, MODE == 1 && U == 0); put<U>(rw[1], ro, MODE == 1 && U == 0); }
+    pos<U, 0, MODE>(m, np);
+  }
+  // the completed pair m - OFFL: its even / odd row in the latest version
+  template <int U> __device__ __forceinline__ const Row &out(bool odd_row) const {
+    constexpr int N = T::N, s = sl(U - T::OFFL);
+    if (T::odd(N - 1) == odd_row) return x[N - 1][s];
+    return x[N - 2][s];
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// strip / segment geometry of one wavefront
+// ------------------------------------------------------------------------------------------
+struct Strip {
+  int c0;           // first chunk of the wavefront
+  int lo, hi;       // lanes [lo, hi) own their results
+  int nsl, sx0;     // slices across the owned lanes, first slice
+  int kA, kB;       // output row pairs [kA, kB)
+};
+template <int K> __device__ __forceinline__ bool strip_of_block(const LevelParams &p, int comp, Strip &s) {
+  constexpr int HLN = halo_lanes<K>();
+  const int strip = blockIdx.x, seg = blockIdx.y;
+  if (strip >= p.st_strips[comp] || seg >= p.st_segs[comp]) return false;
+  const int nch = p.in_w[comp] >> 3, np = p.in_h[comp] >> 1, out = p.st_out[comp];
+  s.c0 = min(max(strip * out - HLN, 0), nch - 64);
+  s.lo = strip * out - s.c0;
+  s.hi = min((strip + 1) * out, nch) - s.c0;
+  s.nsl = (s.hi - s.lo) >> p.st_llps[comp];
+  s.sx0 = (strip * out) >> p.st_llps[comp];
+  s.kA = seg * p.st_py[comp];
+  s.kB = min(s.kA + p.st_py[comp], np);
+  return true;
+}
+
+__device__ __forceinline__ int ilog2d(int v) { return 31 - __clz(v); }
+
+// ------------------------------------------------------------------------------------------
+// forward level
+// ------------------------------------------------------------------------------------------
+template <int K, bool FIRST, class ST>
+__global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
+  using S_ = St<ST>;
+  using VE = VEng<K, false>;
+  using T = typename VE::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ST *stg = (ST *)smem;
+  const int lane = threadIdx.x;
+  const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
+  Strip sp;
+  if (!strip_of_block<K>(p, comp, sp)) return;
+  constexpr int ACC = WT<K>::accuracy;
+  const int in_h = p.in_h[comp], in_w = p.in_w[comp], np = in_h >> 1;
+  const int chunk = sp.c0 + lane;
+  const bool own = lane >= sp.lo && lane < sp.hi;
+
+  // ---- input rows
+  const uint8_t *raw = nullptr;
+  const ST *lvl = nullptr;
+  const int32_t *lvl_w = nullptr;
+  if constexpr (FIRST) raw = (const uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 16;
+  else {
+    lvl = (const ST *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 8;
+    if constexpr (S_::narrow) lvl_w = p.plane_wide[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 8;
+  }
+  const int pic_h = FIRST ? p.pic_h[comp] : in_h;
+  constexpr int NQ = (FIRST || S_::narrow) ? 1 : 2; // 16-byte loads per row
+  uint4 pf[PF][2][NQ];
+  auto fetch = [&](int m, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int y = min(2 * m + h, pic_h - 1); // waveletPad: rows below the picture replicate its last row
+      if constexpr (FIRST) pf[slot][h][0] = *(const uint4 *)(raw + (size_t)y * in_w * 2);
+      else {
+        const ST *q = lvl + (size_t)y * in_w;
+        pf[slot][h][0] = *(const uint4 *)q;
+        if constexpr (NQ == 2) pf[slot][h][1] = *(const uint4 *)(q + 4);
+      }
+    }
+  };
+  auto convert = [&](int m, int slot, int h, Row &r) __attribute__((always_inline)) {
+    if constexpr (FIRST) {
+      const unsigned w[4] = {pf[slot][h][0].x, pf[slot][h][0].y, pf[slot][h][0].z, pf[slot][h][0].w};
+      const int bias = -(p.sample_offset << ACC);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned b = __builtin_amdgcn_perm(w[k], w[k], 0x02030001u); // both big-endian 16-bit words to host order
+        r[k] = (int)(((b & 0xFFFFu) >> p.sample_shift) << ACC) + bias;
+        r[4 + k] = (int)((b >> (16 + p.sample_shift)) << ACC) + bias;
+      }
+    } else {
+      int s[8];
+      if constexpr (S_::narrow) S_::unpack8(pf[slot][h][0], lvl_w + (size_t)(2 * m + h) * in_w, s);
+      else {
+        s[0] = (int)pf[slot][h][0].x; s[1] = (int)pf[slot][h][0].y; s[2] = (int)pf[slot][h][0].z; s[3] = (int)pf[slot][h][0].w;
+        s[4] = (int)pf[slot][h][NQ - 1].x; s[5] = (int)pf[slot][h][NQ - 1].y; s[6] = (int)pf[slot][h][NQ - 1].z; s[7] = (int)pf[slot][h][NQ - 1].w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r[k] = (int)((unsigned)s[2 * k] << ACC); r[4 + k] = (int)((unsigned)s[2 * k + 1] << ACC); }
+    }
+  };
+
+  // ---- outputs
+  const int fh = p.fh[comp], fw = p.fw[comp];
+  const int bsh = fh >> 1, bsw = fw >> 1, lbsh = ilog2d(bsh), lbsw = ilog2d(bsw), bn = bsh * bsw;
+  const int nb = p.ll_to_store ? 4 : 3, b0 = p.ll_to_store ? 0 : 1; // bands through the LDS image; first of them
+  const int rs = p.st_out[comp] * 4;                                 // elements per image row (all owned slices)
+  const int si = (lane - sp.lo) >> p.st_llps[comp];                  // slice of the lane inside the strip
+  const int cc = ((lane - sp.lo) & ((1 << p.st_llps[comp]) - 1)) * 4; // its first column inside the slice's block
+  const int run0 = p.coef_off[comp] + (p.ll_to_store ? 0 : bn);      // [LL |] HL | LH | HH of a slice: one contiguous run
+  ST *store = (ST *)p.store + (size_t)pic * p.store_stride;
+  int32_t *wide = S_::narrow ? p.store_wide + (size_t)pic * p.store_stride : nullptr;
+  ST *llp = nullptr;
+  int32_t *llp_w = nullptr;
+  if (!p.ll_to_store) {
+    llp = (ST *)p.ll[comp] + (size_t)pic * p.ll_stride[comp] + (size_t)chunk * 4;
+    if constexpr (S_::narrow) llp_w = p.ll_wide[comp] + (size_t)pic * p.ll_stride[comp] + (size_t)chunk * 4;
+  }
+  const int ow = in_w >> 1;
+
+  // four band values of the lane into the image row (band b, block row r); values beyond 16 bits go to the wide plane
+  auto stage4 = [&](int b, int r, int sv, int a0, int a1, int a2, int a3) __attribute__((always_inline)) {
+    ST *d = stg + ((size_t)((b - b0) * bsh + r) * rs + si * bsw + cc);
+    if constexpr (S_::narrow) {
+      const int mx = max(max(a0, a1), max(a2, a3)), mn = min(min(a0, a1), min(a2, a3));
+      if (mx > 32767 || mn < -32767) {
+        int32_t *w = wide + (size_t)(sv * p.xs + sp.sx0 + si) * p.slice_coefs + run0 + (b - b0) * bn + r * bsw + cc;
+        if (!S_::fits(a0)) { w[0] = a0; a0 = VC2_ST_SENTINEL; }
+        if (!S_::fits(a1)) { w[1] = a1; a1 = VC2_ST_SENTINEL; }
+        if (!S_::fits(a2)) { w[2] = a2; a2 = VC2_ST_SENTINEL; }
+        if (!S_::fits(a3)) { w[3] = a3; a3 = VC2_ST_SENTINEL; }
+      }
+      *(uint2 *)d = make_uint2(vc2_pack16(a0, a1), vc2_pack16(a2, a3));
+    } else *(int4 *)d = make_int4(a0, a1, a2, a3);
+  };
+  // the image of one block row of slices to the slice records: 16-byte pieces of each slice's contiguous run
+  auto flush = [&](int sv) __attribute__((always_inline)) {
+    wave_sync();
+    constexpr int EP = 16 / (int)sizeof(ST);             // elements per piece
+    const int lpb = ilog2d(bn) - ilog2d(EP);             // log2 pieces per band block (bn >= EP: host check)
+    for (int b = 0; b < nb; ++b) {
+      for (int q = lane; q < (sp.nsl << lpb); q += 64) {
+        const int s2 = q >> lpb, e = (q & ((1 << lpb) - 1)) * EP; // slice, first element inside the band block
+        const int r = e >> lbsw, c = e & (bsw - 1);
+        const size_t at = (size_t)(sv * p.xs + sp.sx0 + s2) * p.slice_coefs + run0 + b * bn + e;
+        const ST *src = stg + ((size_t)(b * bsh + r) * rs + s2 * bsw + c);
+        if (bsw >= EP) *(uint4 *)(store + at) = *(const uint4 *)src;
+        else { // a piece spans two block rows (bsw == EP / 2)
+          const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + rs);
+          *(uint4 *)(store + at) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+    }
+    wave_sync();
+  };
+
+  // ---- the walk
+  VE eng;
+  eng.clear();
+  // Every iteration issues all its global memory operations in one place, right after the rows it consumes have
+  // arrived: the stores of the PREVIOUS iteration's results (the LL row; the LDS image when a block row is complete)
+  // and the load of the pair PF ahead.  The compiler's wait for the consumed rows (a wait for everything outstanding:
+  // the waits inside this loop are not counted ones) then finds operations that had a whole iteration to complete.
+  const int m0 = max(sp.kA + T::sum_dmin(), 0) & ~(RL - 1); // walks start at multiples of RL (a longer run-in is harmless)
+  const bool last = sp.kB == np;                            // the segment ends at the plane's bottom
+  const int mend = last ? np : sp.kB + T::OFFL;             // steady-state iterations: [m0, mend) in whole blocks of RL
+  const int mload = np - 1;                                 // loads beyond it repeat the last pair (their results are not used)
+#pragma unroll
+  for (int u = 0; u < PF; ++u) fetch(min(m0 + u, mload), u);
+  static_assert(RL % PF == 0, "the prefetch ring shares the unrolled walk of the row rings");
+  int ll_k = -1, flush_sv = -1; // deferred stores: LL row of pair ll_k (values in llv), image of block row flush_sv
+  int llv[4] = {0, 0, 0, 0};
+#define VC2_FWD_ITER(U, MODE)                                                                                \
+  if constexpr (MODE != 2 || U < T::OFFL) {                                                                  \
+    const int m = mb + U;                                                                                    \
+    Row re, ro;                                                                                              \
+    if constexpr (MODE != 2) {                                                                               \
+      convert(min(m, mload), U % PF, 0, re);                                                                 \
+      convert(min(m, mload), U % PF, 1, ro);                                                                 \
+    }                                                                                                        \
+    if (ll_k >= 0 && own) S_::store4(llp + (size_t)ll_k * ow, llp_w + (size_t)ll_k * ow, llv[0], llv[1], llv[2], llv[3]); \
+    if (flush_sv >= 0) { flush(flush_sv); flush_sv = -1; }                                                   \
+    if constexpr (MODE != 2) {                                                                               \
+      fetch(min(m + PF, mload), U % PF);                                                                     \
+      h_lift<K, false>(re);                                                                                  \
+      h_lift<K, false>(ro);                                                                                  \
+    }                                                                                                        \
+    eng.template step<U, MODE>(m, np, re, ro);                                                               \
+    const int k = m - T::OFFL;                                                                               \
+    if (k >= sp.kA && k < sp.kB) {                                                                           \
+      const Row &oe = eng.template out<U>(false), &oo = eng.template out<U>(true);                           \
+      const int r = k & (bsh - 1), sv = k >> lbsh;                                                           \
+      if (p.ll_to_store) { if (own) stage4(0, r, sv, oe[0], oe[1], oe[2], oe[3]); }                          \
+      else { ll_k = k; llv[0] = oe[0]; llv[1] = oe[1]; llv[2] = oe[2]; llv[3] = oe[3]; }                     \
+      if (own) {                                                                                             \
+        stage4(1, r, sv, oe[4], oe[5], oe[6], oe[7]);                                                        \
+        stage4(2, r, sv, oo[0], oo[1], oo[2], oo[3]);                                                        \
+        stage4(3, r, sv, oo[4], oo[5], oo[6], oo[7]);                                                        \
+      }                                                                                                      \
+      if (r == bsh - 1) flush_sv = sv;                                                                       \
+    } else ll_k = -1;                                                                                        \
+  }
+#define VC2_FWD_BLOCK(MODE) { VC2_FWD_ITER(0, MODE) VC2_FWD_ITER(1, MODE) VC2_FWD_ITER(2, MODE) VC2_FWD_ITER(3, MODE) }
+  int mb = m0;
+  if (m0 == 0) { // (the host admits planes of at least 2 * RL row pairs: this block lies inside the plane)
+    VC2_FWD_BLOCK(1)
+    mb += RL;
+  }
+  for (; mb < mend; mb += RL) VC2_FWD_BLOCK(0)
+  if (last) {
+    mb = np;
+    VC2_FWD_BLOCK(2)
+  }
+#undef VC2_FWD_BLOCK
+#undef VC2_FWD_ITER
+  if (ll_k >= 0 && own) S_::store4(llp + (size_t)ll_k * ow, llp_w + (size_t)ll_k * ow, llv[0], llv[1], llv[2], llv[3]);
+  if (flush_sv >= 0) flush(flush_sv);
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse level
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale(), Quantisation.cpp:86-95, literally
+  if (v == 0) return 0;
+  const unsigned mag = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+  int a = (int)(mag * (unsigned)qf);
+  if (a > 0) a = (int)((unsigned)a + (unsigned)off);
+  a = (int)((unsigned)a + 2u);
+  a /= 4;
+  return v < 0 ? (int)(0u - (unsigned)a) : a;
+}
+
+template <int K, bool FINAL, class ST>
+__global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
+  using S_ = St<ST>;
+  using VE = VEng<K, true>;
+  using T = typename VE::T;
+  __shared__ int qtab[360]; // quant_factor / quant_offset / domain limit by adjusted index
+  const int lane = threadIdx.x;
+  const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
+  Strip sp;
+  if (!strip_of_block<K>(p, comp, sp)) return;
+  for (int i = lane; i < 120; i += 64) {
+    const int qf = c_qst.qf[i], off = c_qst.off[i];
+    qtab[i] = qf; qtab[120 + i] = off;
+    qtab[240 + i] = qf > 0 ? (int)((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf) : -1;
+  }
+  wave_sync();
+  constexpr int ACC = WT<K>::accuracy;
+  const int out_h = p.in_h[comp], out_w = p.in_w[comp], np = out_h >> 1, ow = out_w >> 1;
+  const int chunk = sp.c0 + lane;
+  const bool own = lane >= sp.lo && lane < sp.hi;
+  const int fh = p.fh[comp], fw = p.fw[comp];
+  const int bsh = fh >> 1, bsw = fw >> 1, lbsh = ilog2d(bsh), bn = bsh * bsw;
+  const int b0 = p.ll_from_store ? 0 : 1;               // first band that comes from the store
+  const int llps = p.st_llps[comp];
+  const int sx = chunk >> llps, cc = (chunk & ((1 << llps) - 1)) * 4; // the lane's slice and first column of its block
+  const int run0 = p.coef_off[comp] + (p.ll_from_store ? 0 : bn);     // [LL |] HL | LH | HH of a slice
+  const ST *store = (const ST *)p.store + (size_t)pic * p.store_stride;
+  const int32_t *wide = S_::narrow ? p.store_wide + (size_t)pic * p.store_stride : nullptr;
+  const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * p.xs : nullptr;
+  const ST *llp = nullptr;
+  const int32_t *llp_w = nullptr;
+  if (!p.ll_from_store) {
+    llp = (const ST *)p.ll[comp] + (size_t)pic * p.ll_stride[comp] + (size_t)chunk * 4;
+    if constexpr (S_::narrow) llp_w = p.ll_wide[comp] + (size_t)pic * p.ll_stride[comp] + (size_t)chunk * 4;
+  }
+
+  // ---- input: per band row the lane's four coefficients of every band, straight from the slice records (a slice's
+  // band block row is bsw coefficients: neighbouring lanes read neighbouring 8 / 16 bytes), prefetched PF rows ahead
+  typedef typename std::conditional<S_::narrow, uint2, uint4>::type Q4; // four store elements
+  Q4 bq[PF][4];
+  auto rec_at = [&](int m, int b) __attribute__((always_inline)) -> size_t { // element index of the lane's four coefficients of band b in band row m
+    const int sv = m >> lbsh, r = m & (bsh - 1);
+    return (size_t)(sv * p.xs + sx) * p.slice_coefs + run0 + (b - b0) * bn + r * bsw + cc;
+  };
+  auto in_fetch = [&](int m, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b == 0 && !p.ll_from_store) bq[slot][0] = *(const Q4 *)(llp + (size_t)m * ow);
+      else bq[slot][b] = *(const Q4 *)(store + rec_at(m, b));
+    }
+  };
+  // quantiser constants of the lane's slice in block row sv, per band
+  int qf[4], qo[4], ql[4];
+  auto load_q = [&](int sv) __attribute__((always_inline)) {
+    const int q = p.dequant ? qidx[sv * p.xs + sx] : 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int qm = b == 0 ? p.qmatrix[0] : p.qmatrix[p.band + b - 1];
+      const int aq = max(q - qm, 0);
+      if (aq > 119 && p.dequant && b >= b0) atomicOr(p.err, VC2_DEVERR_QINDEX);
+      qf[b] = qtab[min(aq, 119)]; qo[b] = qtab[120 + min(aq, 119)]; ql[b] = qtab[240 + min(aq, 119)];
+    }
+  };
+  // unpack band b of row m (escapes resolved) and dequantise
+  auto band4 = [&](int m, int slot, int b) __attribute__((always_inline)) -> int4 {
+    const bool from_plane = b == 0 && !p.ll_from_store;
+    int v[4];
+    if constexpr (S_::narrow) {
+      const uint2 w = bq[slot][b];
+      v[0] = vc2_lo16(w.x); v[1] = vc2_hi16(w.x); v[2] = vc2_lo16(w.y); v[3] = vc2_hi16(w.y);
+      if (min(min(v[0], v[1]), min(v[2], v[3])) == VC2_ST_SENTINEL) {
+        const int32_t *wq = from_plane ? llp_w + (size_t)m * ow : wide + rec_at(m, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (v[k] == VC2_ST_SENTINEL) v[k] = wq[k];
+      }
+    } else {
+      const uint4 w = bq[slot][b];
+      v[0] = (int)w.x; v[1] = (int)w.y; v[2] = (int)w.z; v[3] = (int)w.w;
+    }
+    if (p.dequant && !from_plane) {
+      unsigned mg[4], any = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { mg[k] = v[k] < 0 ? 0u - (unsigned)v[k] : (unsigned)v[k]; any |= mg[k]; }
+      if ((int)any >= 0 && (int)any <= ql[b]) { // inside the domain: (|v| * factor + offset + 2) >> 2
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned t = mg[k] ? (mg[k] * (unsigned)qf[b] + (unsigned)(qo[b] + 2)) >> 2 : 0u;
+          v[k] = v[k] < 0 ? (int)(0u - t) : (int)t;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = dequant_full(v[k], qf[b], qo[b]);
+      }
+    }
+    return make_int4(v[0], v[1], v[2], v[3]);
+  };
+
+  // ---- output rows
+  const int lim_h = FINAL ? p.pic_h[comp] : out_h;
+  uint8_t *rawo = nullptr;
+  ST *lvl = nullptr;
+  int32_t *lvl_w = nullptr;
+  if constexpr (FINAL) rawo = (uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 16;
+  else {
+    lvl = (ST *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 8;
+    if constexpr (S_::narrow) lvl_w = p.plane_wide[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 8;
+  }
+  // an output row: horizontal inverse lifting, rounding, (FINAL) clip / offset / justify / big-endian words.  The row
+  // is kept as it will be stored (FINAL, or 16-bit planes: four words; int32 planes: eight) until the next iteration.
+  constexpr int OW = (FINAL || S_::narrow) ? 4 : 8;
+  struct Pend { unsigned w[OW]; };
+  auto make_out = [&](int y, Row &r, Pend &o) __attribute__((always_inline)) {
+    h_lift<K, true>(r);
+    int s[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[2 * k] = r[k]; s[2 * k + 1] = r[4 + k]; }
+    if (ACC) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] = (s[k] + (1 << (ACC > 0 ? ACC - 1 : 0))) >> ACC;
+    }
+    if constexpr (FINAL) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned a = (unsigned)(min(max(s[2 * k], p.clip_lo), p.clip_hi) + p.sample_offset) << p.sample_shift;
+        const unsigned b = (unsigned)(min(max(s[2 * k + 1], p.clip_lo), p.clip_hi) + p.sample_offset) << p.sample_shift;
+        const unsigned t = (a & 0xFFFFu) | (b << 16);
+        o.w[k] = __builtin_amdgcn_perm(t, t, 0x02030001u); // host order to big-endian 16-bit words
+      }
+    } else if constexpr (S_::narrow) {
+      const int mx = max(max(max(s[0], s[1]), max(s[2], s[3])), max(max(s[4], s[5]), max(s[6], s[7])));
+      const int mn = min(min(min(s[0], s[1]), min(s[2], s[3])), min(min(s[4], s[5]), min(s[6], s[7])));
+      if ((mx > 32767 || mn < -32767) && own && y < lim_h) { // beyond 16 bits: the wide plane, at once
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (!S_::fits(s[k])) { lvl_w[(size_t)y * out_w + k] = s[k]; s[k] = VC2_ST_SENTINEL; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.w[k] = vc2_pack16(s[2 * k], s[2 * k + 1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o.w[k] = (unsigned)s[k];
+    }
+  };
+  auto put_out = [&](int y, const Pend &o) __attribute__((always_inline)) {
+    if (!own || y >= lim_h) return;
+    if constexpr (FINAL) *(uint4 *)(rawo + (size_t)y * out_w * 2) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    else if constexpr (S_::narrow) *(uint4 *)(lvl + (size_t)y * out_w) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    else {
+      *(uint4 *)(lvl + (size_t)y * out_w) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+      *(uint4 *)(lvl + (size_t)y * out_w + 4) = make_uint4(o.w[OW - 4], o.w[OW - 3], o.w[OW - 2], o.w[OW - 1]);
+    }
+  };
+
+  // ---- the walk (global memory operations of an iteration in one place, as in the forward kernel)
+  VE eng;
+  eng.clear();
+  const int m0 = max(sp.kA + T::sum_dmin(), 0) & ~(RL - 1);
+  const bool last = sp.kB == np;
+  const int mend = last ? np : sp.kB + T::OFFL;
+  const int mload = np - 1;
+  int sv_have = -1;
+#pragma unroll
+  for (int u = 0; u < PF; ++u) in_fetch(min(m0 + u, mload), u);
+  static_assert(RL % PF == 0, "the prefetch ring shares the unrolled walk of the row rings");
+  int pend_k = -1;
+  Pend pe, po;
+#pragma unroll
+  for (int k = 0; k < OW; ++k) { pe.w[k] = 0; po.w[k] = 0; }
+#define VC2_INV_ITER(U, MODE)                                                                                \
+  if constexpr (MODE != 2 || U < T::OFFL) {                                                                  \
+    const int m = mb + U;                                                                                    \
+    Row re, ro;                                                                                              \
+    if constexpr (MODE != 2) {                                                                               \
+      const int ml = min(m, mload), sv = ml >> lbsh;                                                         \
+      if (sv != sv_have) { load_q(sv); sv_have = sv; }                                                       \
+      const int4 t0 = band4(ml, U % PF, 0), t1 = band4(ml, U % PF, 1), t2 = band4(ml, U % PF, 2), t3 = band4(ml, U % PF, 3); \
+      re = Row{{t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}};                                            \
+      ro = Row{{t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w}};                                            \
+    }                                                                                                        \
+    if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }                               \
+    if constexpr (MODE != 2) in_fetch(min(m + PF, mload), U % PF);                                           \
+    eng.template step<U, MODE>(m, np, re, ro);                                                               \
+    const int k = m - T::OFFL;                                                                               \
+    if (k >= sp.kA && k < sp.kB) {                                                                           \
+      Row oe = eng.template out<U>(false), oo = eng.template out<U>(true);                                   \
+      make_out(2 * k, oe, pe);                                                                               \
+      make_out(2 * k + 1, oo, po);                                                                           \
+      pend_k = k;                                                                                            \
+    } else pend_k = -1;                                                                                      \
+  }
+#define VC2_INV_BLOCK(MODE) { VC2_INV_ITER(0, MODE) VC2_INV_ITER(1, MODE) VC2_INV_ITER(2, MODE) VC2_INV_ITER(3, MODE) }
+  int mb = m0;
+  if (m0 == 0) {
+    VC2_INV_BLOCK(1)
+    mb += RL;
+  }
+  for (; mb < mend; mb += RL) VC2_INV_BLOCK(0)
+  if (last) {
+    mb = np;
+    VC2_INV_BLOCK(2)
+  }
+#undef VC2_INV_BLOCK
+#undef VC2_INV_ITER
+  if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------
+template <int K, bool EDGE, bool INV, class ST>
+void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds, hipStream_t s) {
+  int gx = 0, gy = 0;
+  for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.st_strips[c]); gy = std::max(gy, p.st_segs[c]); }
+  dim3 grid(gx, gy, 3 * n_pictures), block(64);
+  if constexpr (INV) {
+    vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
+    vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST>, 64 * 1024);
+    VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST>), grid, block, lds, s, p);
+  } else {
+    vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
+    vc2_allow_lds((const void *)k_fwd_stream<K, EDGE, ST>, 64 * 1024);
+    VC2_LAUNCH(L, (k_fwd_stream<K, EDGE, ST>), grid, block, lds, s, p);
+  }
+  vc2_prof_end(L, s);
+}
+
+template <bool INV, class ST> int dispatch_stream(Launcher &L, int kernel, bool edge, const LevelParams &p, int n, size_t lds, hipStream_t s) {
+#define VC2_CASE(KK)                                                        \
+  case KK:                                                                  \
+    if (edge) launch_stream<KK, true, INV, ST>(L, p, n, lds, s);            \
+    else launch_stream<KK, false, INV, ST>(L, p, n, lds, s);                \
+    return 0;
+  switch (kernel) {
+    VC2_CASE(VC2HIP_DD97)
+    VC2_CASE(VC2HIP_LEGALL)
+    VC2_CASE(VC2HIP_DD137)
+    VC2_CASE(VC2HIP_HAAR0)
+    VC2_CASE(VC2HIP_HAAR1)
+    VC2_CASE(VC2HIP_DAUB97)
+  }
+#undef VC2_CASE
+  return VC2HIP_EINVAL;
+}
+
+int halo_lanes_of(int kernel) {
+  switch (kernel) {
+    case VC2HIP_DD97: return halo_lanes<VC2HIP_DD97>();
+    case VC2HIP_LEGALL: return halo_lanes<VC2HIP_LEGALL>();
+    case VC2HIP_DD137: return halo_lanes<VC2HIP_DD137>();
+    case VC2HIP_HAAR0: return halo_lanes<VC2HIP_HAAR0>();
+    case VC2HIP_HAAR1: return halo_lanes<VC2HIP_HAAR1>();
+    case VC2HIP_DAUB97: return halo_lanes<VC2HIP_DAUB97>();
+  }
+  return -1;
+}
+bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+} // namespace
+
+// The streaming kernels apply when every active component has a plane at least 64 chunks wide without horizontal
+// padding, power-of-two slice footprints of at least one chunk, band blocks that move in whole 16-byte pieces, and
+// raw samples (edge levels) in 16-bit words.  Fills the st_* fields of p and returns the dynamic LDS bytes, 0 if not
+// applicable.  (Fidelity's 8-tap steps keep 20 rows of 8 values per lane alive: it stays with the tile kernels.)
+size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool inverse, bool store16, int n_pictures) {
+  const int hln = halo_lanes_of(kernel);
+  if (hln < 0) return 0;
+  const int elem = store16 ? 2 : 4, ep = 16 / elem;
+  size_t lds = 0;
+  long long waves = 0;
+  for (int c = 0; c < 3; ++c) {
+    p.st_strips[c] = p.st_segs[c] = 0;
+    if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
+    const int w = p.in_w[c], h = p.in_h[c], fw = p.fw[c], fh = p.fh[c];
+    if (w < 512 || (w & 7) || (h & 7) || h < 16) return 0; // whole blocks of four row pairs (see VEng)
+    if (edge && (p.word_bytes != 2 || p.pic_w[c] != w)) return 0;
+    if (!pow2i(fw) || !pow2i(fh) || fw < 8 || fh < 2 || fw > 64 * 8) return 0;
+    const int bsh = fh / 2, bsw = fw / 2;
+    if (bsh * bsw < ep || (bsw < ep && bsw * 2 != ep)) return 0;
+    if ((p.coef_off[c] % ep) || (p.slice_coefs % ep) || ((bsh * bsw) % ep)) return 0;
+    const int lps = fw / 8;
+    const int out = ((64 - 2 * hln) / lps) * lps;
+    if (out < lps) return 0;
+    const int nch = w / 8;
+    p.st_out[c] = out;
+    p.st_llps[c] = 31 - __builtin_clz((unsigned)lps);
+    p.st_strips[c] = (nch + out - 1) / out;
+    // image: forward out * 4 elements per row; inverse every slice the 64 chunks touch
+    const size_t rs = (size_t)out * 4;
+    const int nb = p.ll_to_store ? 4 : 3;
+    const size_t img = inverse ? 16 : nb * (size_t)bsh * rs * elem; // the inverse kernel reads the records directly
+    lds = std::max(lds, img);
+  }
+  if (lds > 40 * 1024) return 0;
+  // rows per segment: whole block rows, enough wavefronts to fill the chip (~8 per SIMD) but at least 16 row pairs
+  for (int c = 0; c < 3; ++c) {
+    if (!p.st_strips[c]) continue;
+    const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2;
+    int py = std::max(64, bsh);
+    while (py > std::max(16, bsh) && (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures * 3 < 6144) py /= 2;
+    static const int force_py = [] { const char *e = getenv("VC2HIP_STREAM_PY"); return e ? atoi(e) : 0; }();
+    if (force_py > 0) py = force_py;
+    py = ((py + bsh - 1) / bsh) * bsh;
+    p.st_py[c] = py;
+    p.st_segs[c] = (np + py - 1) / py;
+    waves += (long long)p.st_strips[c] * p.st_segs[c];
+  }
+  (void)waves;
+  return lds;
+}
+int vc2_launch_forward_stream(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s) {
+  return store16 ? dispatch_stream<false, int16_t>(L, kernel, first, p, n, lds, s) : dispatch_stream<false, int32_t>(L, kernel, first, p, n, lds, s);
+}
+int vc2_launch_inverse_stream(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s) {
+  return store16 ? dispatch_stream<true, int16_t>(L, kernel, final_level, p, n, lds, s) : dispatch_stream<true, int32_t>(L, kernel, final_level, p, n, lds, s);
+}

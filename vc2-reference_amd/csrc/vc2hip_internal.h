@@ -108,6 +108,11 @@ struct LevelParams {
   int big_lut;                // set by the launcher: LDS holds subband tables for components of up to 2048 coefficients
   int debug_skip;             // -DVC2HIP_ABLATE builds only (tools/ablate_*.py): 1 no loads, 2 no lifting, 4 no stores
   int qmatrix[VC2_MAX_BANDS];
+  // streaming kernels (vc2hip_dwt_stream.hip), set by vc2_stream_level_applicable
+  int st_strips[3], st_segs[3]; // wavefronts across / down a plane
+  int st_out[3];                // chunks (8 samples) a strip owns
+  int st_llps[3];               // log2 chunks per slice
+  int st_py[3];                 // row pairs per segment
 };
 
 // Work-skipping switches for the timing experiments of tools/ablate_*.py exist only in a library built with
