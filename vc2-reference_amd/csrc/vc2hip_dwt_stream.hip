@@ -37,7 +37,11 @@ void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s) {
 
 namespace {
 
-constexpr int PF = 2; // row pairs prefetched ahead (divides the ring length RL)
+constexpr int PF = 2;  // row pairs prefetched ahead, forward kernel (divides the ring length RL)
+#ifndef VC2_STREAM_PFI
+#define VC2_STREAM_PFI 2
+#endif
+constexpr int PFI = VC2_STREAM_PFI; // the same for the inverse kernel (four loads per pair and lane)
 
 // one row of a lane's chunk: elements 0..3 even columns, 4..7 odd columns
 struct Row {
@@ -51,6 +55,7 @@ __device__ __forceinline__ Row operator-(const Row &a) { Row r; _Pragma("unroll"
 __device__ __forceinline__ Row operator+(const Row &a, int b) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] + b; return r; }
 __device__ __forceinline__ Row operator*(int b, const Row &a) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = b * a.v[i]; return r; }
 __device__ __forceinline__ Row operator>>(const Row &a, int b) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] >> b; return r; }
+__device__ __forceinline__ Row vc2_times9(const Row &a) { Row r; _Pragma("unroll") for (int i = 0; i < 8; ++i) r.v[i] = ::vc2_times9(a.v[i]); return r; }
 
 template <int CTRL> __device__ __forceinline__ int dppm(int old, int v) {
   return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
@@ -249,6 +254,9 @@ template <int K> __device__ __forceinline__ bool strip_of_block(const LevelParam
 }
 
 __device__ __forceinline__ int ilog2d(int v) { return 31 - __clz(v); }
+// address arithmetic: row / slice numbers and row / record lengths are far below 2^24 and their products (element offsets
+// inside one picture) below 2^32, so the full-rate 24-bit multiply serves instead of 64-bit multiplies
+__device__ __forceinline__ size_t mul24z(int a, int b) { return (size_t)__umul24((unsigned)a, (unsigned)b); }
 
 // ------------------------------------------------------------------------------------------
 // forward level
@@ -285,9 +293,9 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int y = min(2 * m + h, pic_h - 1); // waveletPad: rows below the picture replicate its last row
-      if constexpr (FIRST) pf[slot][h][0] = *(const uint4 *)(raw + (size_t)y * in_w * 2);
+      if constexpr (FIRST) pf[slot][h][0] = *(const uint4 *)(raw + mul24z(y, in_w) * 2);
       else {
-        const ST *q = lvl + (size_t)y * in_w;
+        const ST *q = lvl + mul24z(y, in_w);
         pf[slot][h][0] = *(const uint4 *)q;
         if constexpr (NQ == 2) pf[slot][h][1] = *(const uint4 *)(q + 4);
       }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
       }
     } else {
       int s[8];
-      if constexpr (S_::narrow) S_::unpack8(pf[slot][h][0], lvl_w + (size_t)(2 * m + h) * in_w, s);
+      if constexpr (S_::narrow) S_::unpack8(pf[slot][h][0], lvl_w + mul24z(2 * m + h, in_w), s);
       else {
         s[0] = (int)pf[slot][h][0].x; s[1] = (int)pf[slot][h][0].y; s[2] = (int)pf[slot][h][0].z; s[3] = (int)pf[slot][h][0].w;
         s[4] = (int)pf[slot][h][NQ - 1].x; s[5] = (int)pf[slot][h][NQ - 1].y; s[6] = (int)pf[slot][h][NQ - 1].z; s[7] = (int)pf[slot][h][NQ - 1].w;
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
       for (int q = lane; q < (sp.nsl << lpb); q += 64) {
         const int s2 = q >> lpb, e = (q & ((1 << lpb) - 1)) * EP; // slice, first element inside the band block
         const int r = e >> lbsw, c = e & (bsw - 1);
-        const size_t at = (size_t)(sv * p.xs + sp.sx0 + s2) * p.slice_coefs + run0 + b * bn + e;
+        const size_t at = mul24z(sv * p.xs + sp.sx0 + s2, p.slice_coefs) + run0 + b * bn + e;
         const ST *src = stg + ((size_t)(b * bsh + r) * rs + s2 * bsw + c);
         if (bsw >= EP) *(uint4 *)(store + at) = *(const uint4 *)src;
         else { // a piece spans two block rows (bsw == EP / 2)
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
       convert(min(m, mload), U % PF, 0, re);                                                                 \
       convert(min(m, mload), U % PF, 1, ro);                                                                 \
     }                                                                                                        \
-    if (ll_k >= 0 && own) S_::store4(llp + (size_t)ll_k * ow, llp_w + (size_t)ll_k * ow, llv[0], llv[1], llv[2], llv[3]); \
+    if (ll_k >= 0 && own) S_::store4(llp + mul24z(ll_k, ow), llp_w + mul24z(ll_k, ow), llv[0], llv[1], llv[2], llv[3]); \
     if (flush_sv >= 0) { flush(flush_sv); flush_sv = -1; }                                                   \
     if constexpr (MODE != 2) {                                                                               \
       fetch(min(m + PF, mload), U % PF);                                                                     \
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   }
 #undef VC2_FWD_BLOCK
 #undef VC2_FWD_ITER
-  if (ll_k >= 0 && own) S_::store4(llp + (size_t)ll_k * ow, llp_w + (size_t)ll_k * ow, llv[0], llv[1], llv[2], llv[3]);
+  if (ll_k >= 0 && own) S_::store4(llp + mul24z(ll_k, ow), llp_w + mul24z(ll_k, ow), llv[0], llv[1], llv[2], llv[3]);
   if (flush_sv >= 0) flush(flush_sv);
 }
 
@@ -458,7 +466,9 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   for (int i = lane; i < 120; i += 64) {
     const int qf = c_qst.qf[i], off = c_qst.off[i];
     qtab[i] = qf; qtab[120 + i] = off;
-    qtab[240 + i] = qf > 0 ? (int)((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf) : -1;
+    // largest magnitude for which |v| * factor + offset + 2 stays below 2^31 with both factors inside 24 bits (the
+    // full-rate multiply-add); beyond it the literal arithmetic
+    qtab[240 + i] = (qf > 0 && qf < (1 << 24)) ? (int)min((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf, 0xFFFFFFu) : -1;
   }
   wave_sync();
   constexpr int ACC = WT<K>::accuracy;
@@ -482,17 +492,20 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   }
 
   // ---- input: per band row the lane's four coefficients of every band, straight from the slice records (a slice's
-  // band block row is bsw coefficients: neighbouring lanes read neighbouring 8 / 16 bytes), prefetched PF rows ahead
+  // band block row is bsw coefficients: neighbouring lanes read neighbouring 8 / 16 bytes), prefetched PFI rows ahead.
+  // (A version that brought the bands in through LDS-DMA in whole 128-byte lines, double buffered, was correct but
+  // slower -- 0.75 against 0.55 ms per 16 UHD pictures: its 17 KiB image per wavefront halves the occupancy, and this
+  // kernel lives on occupancy.)
   typedef typename std::conditional<S_::narrow, uint2, uint4>::type Q4; // four store elements
-  Q4 bq[PF][4];
+  Q4 bq[PFI][4];
   auto rec_at = [&](int m, int b) __attribute__((always_inline)) -> size_t { // element index of the lane's four coefficients of band b in band row m
     const int sv = m >> lbsh, r = m & (bsh - 1);
-    return (size_t)(sv * p.xs + sx) * p.slice_coefs + run0 + (b - b0) * bn + r * bsw + cc;
+    return mul24z(sv * p.xs + sx, p.slice_coefs) + run0 + (b - b0) * bn + r * bsw + cc;
   };
   auto in_fetch = [&](int m, int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (b == 0 && !p.ll_from_store) bq[slot][0] = *(const Q4 *)(llp + (size_t)m * ow);
+      if (b == 0 && !p.ll_from_store) bq[slot][0] = *(const Q4 *)(llp + mul24z(m, ow));
       else bq[slot][b] = *(const Q4 *)(store + rec_at(m, b));
     }
   };
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
       const uint2 w = bq[slot][b];
       v[0] = vc2_lo16(w.x); v[1] = vc2_hi16(w.x); v[2] = vc2_lo16(w.y); v[3] = vc2_hi16(w.y);
       if (min(min(v[0], v[1]), min(v[2], v[3])) == VC2_ST_SENTINEL) {
-        const int32_t *wq = from_plane ? llp_w + (size_t)m * ow : wide + rec_at(m, b);
+        const int32_t *wq = from_plane ? llp_w + mul24z(m, ow) : wide + rec_at(m, b);
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (v[k] == VC2_ST_SENTINEL) v[k] = wq[k];
       }
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
       if ((int)any >= 0 && (int)any <= ql[b]) { // inside the domain: (|v| * factor + offset + 2) >> 2
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned t = mg[k] ? (mg[k] * (unsigned)qf[b] + (unsigned)(qo[b] + 2)) >> 2 : 0u;
+          const unsigned t = mg[k] ? (__umul24(mg[k], (unsigned)qf[b]) + (unsigned)(qo[b] + 2)) >> 2 : 0u;
           v[k] = v[k] < 0 ? (int)(0u - t) : (int)t;
         }
       } else {
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
       const int mn = min(min(min(s[0], s[1]), min(s[2], s[3])), min(min(s[4], s[5]), min(s[6], s[7])));
       if ((mx > 32767 || mn < -32767) && own && y < lim_h) { // beyond 16 bits: the wide plane, at once
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (!S_::fits(s[k])) { lvl_w[(size_t)y * out_w + k] = s[k]; s[k] = VC2_ST_SENTINEL; }
+        for (int k = 0; k < 8; ++k) if (!S_::fits(s[k])) { lvl_w[mul24z(y, out_w) + k] = s[k]; s[k] = VC2_ST_SENTINEL; }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) o.w[k] = vc2_pack16(s[2 * k], s[2 * k + 1]);
@@ -589,11 +602,11 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   };
   auto put_out = [&](int y, const Pend &o) __attribute__((always_inline)) {
     if (!own || y >= lim_h) return;
-    if constexpr (FINAL) *(uint4 *)(rawo + (size_t)y * out_w * 2) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
-    else if constexpr (S_::narrow) *(uint4 *)(lvl + (size_t)y * out_w) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    if constexpr (FINAL) *(uint4 *)(rawo + mul24z(y, out_w) * 2) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    else if constexpr (S_::narrow) *(uint4 *)(lvl + mul24z(y, out_w)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
     else {
-      *(uint4 *)(lvl + (size_t)y * out_w) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
-      *(uint4 *)(lvl + (size_t)y * out_w + 4) = make_uint4(o.w[OW - 4], o.w[OW - 3], o.w[OW - 2], o.w[OW - 1]);
+      *(uint4 *)(lvl + mul24z(y, out_w)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+      *(uint4 *)(lvl + mul24z(y, out_w) + 4) = make_uint4(o.w[OW - 4], o.w[OW - 3], o.w[OW - 2], o.w[OW - 1]);
     }
   };
 
@@ -606,8 +619,8 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   const int mload = np - 1;
   int sv_have = -1;
 #pragma unroll
-  for (int u = 0; u < PF; ++u) in_fetch(min(m0 + u, mload), u);
-  static_assert(RL % PF == 0, "the prefetch ring shares the unrolled walk of the row rings");
+  for (int u = 0; u < PFI; ++u) in_fetch(min(m0 + u, mload), u);
+  static_assert(RL % PFI == 0, "the prefetch ring shares the unrolled walk of the row rings");
   int pend_k = -1;
   Pend pe, po;
 #pragma unroll
@@ -619,12 +632,12 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     if constexpr (MODE != 2) {                                                                               \
       const int ml = min(m, mload), sv = ml >> lbsh;                                                         \
       if (sv != sv_have) { load_q(sv); sv_have = sv; }                                                       \
-      const int4 t0 = band4(ml, U % PF, 0), t1 = band4(ml, U % PF, 1), t2 = band4(ml, U % PF, 2), t3 = band4(ml, U % PF, 3); \
+      const int4 t0 = band4(ml, U % PFI, 0), t1 = band4(ml, U % PFI, 1), t2 = band4(ml, U % PFI, 2), t3 = band4(ml, U % PFI, 3); \
       re = Row{{t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}};                                            \
       ro = Row{{t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w}};                                            \
     }                                                                                                        \
     if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }                               \
-    if constexpr (MODE != 2) in_fetch(min(m + PF, mload), U % PF);                                           \
+    if constexpr (MODE != 2) in_fetch(min(m + PFI, mload), U % PFI);                                         \
     eng.template step<U, MODE>(m, np, re, ro);                                                               \
     const int k = m - T::OFFL;                                                                               \
     if (k >= sp.kA && k < sp.kB) {                                                                           \
@@ -732,8 +745,9 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     p.st_strips[c] = (nch + out - 1) / out;
     // image: forward out * 4 elements per row; inverse every slice the 64 chunks touch
     const size_t rs = (size_t)out * 4;
-    const int nb = p.ll_to_store ? 4 : 3;
-    const size_t img = inverse ? 16 : nb * (size_t)bsh * rs * elem; // the inverse kernel reads the records directly
+    size_t img;
+    if (!inverse) img = (p.ll_to_store ? 4 : 3) * (size_t)bsh * rs * elem;
+    else img = 16; // the inverse kernel reads the records directly
     lds = std::max(lds, img);
   }
   if (lds > 40 * 1024) return 0;

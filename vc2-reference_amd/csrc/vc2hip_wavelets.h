@@ -23,11 +23,15 @@ template <int K, int S> __device__ __forceinline__ constexpr bool step_targets_o
   else return (S % 2) == 0;                                  // predict (odd) first
 }
 
+// 9 * x as shift-and-add (one v_lshl_add_u32; the integer multiply is a quarter-rate instruction)
+__device__ __forceinline__ int vc2_times9(int x) { return (int)(((unsigned)x << 3) + (unsigned)x); }
+template <class T> __device__ __forceinline__ T vc2_times9(const T &x) { const T d = x + x, q = d + d; return q + q + x; }
+
 template <int K, int S, class F> __device__ __forceinline__ auto lift_delta(F at) {
   if constexpr (K == VC2HIP_DD97 || K == VC2HIP_DD137) {
-    if constexpr (S == 0) return -((-at(-1) + 9 * at(0) + 9 * at(1) - at(2) + 8) >> 4);
+    if constexpr (S == 0) return -((vc2_times9(at(0) + at(1)) - (at(-1) + at(2)) + 8) >> 4);
     else if constexpr (K == VC2HIP_DD97) return (at(-1) + at(0) + 2) >> 2;
-    else return (-at(-2) + 9 * at(-1) + 9 * at(0) - at(1) + 16) >> 5;
+    else return (vc2_times9(at(-1) + at(0)) - (at(-2) + at(1)) + 16) >> 5;
   } else if constexpr (K == VC2HIP_LEGALL) {
     if constexpr (S == 0) return -((at(0) + at(1) + 1) >> 1);
     else return (at(-1) + at(0) + 2) >> 2;
