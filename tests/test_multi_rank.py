@@ -40,6 +40,14 @@ def test_bench_two_ranks_gloo_dry_run():
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["pictures"] == 6
     assert d["ms_per_step"] >= 19.0             # MAX over ranks: rank 1 sleeps 20 ms
+    # the ranks coded real pictures (through the oracle): the same six pictures coded by ONE rank give the same streams
+    # and the same decoded pictures (an order-free sum of per-picture digests)
+    env1 = dict(os.environ, VC2_BENCH_DRYRUN="1")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "6"], env=env1, capture_output=True,
+                         text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["pictures"] == 6 and d1["check"] == d["check"]
 
 
 def test_oracle_frames_are_independent(oracle):

@@ -756,7 +756,7 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     if (!p.st_strips[c]) continue;
     const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2;
     int py = std::max(64, bsh);
-    while (py > std::max(16, bsh) && (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures * 3 < 6144) py /= 2;
+    while (py > std::max(16, bsh) && (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures * 3 < 16384) py /= 2;
     static const int force_py = [] { const char *e = getenv("VC2HIP_STREAM_PY"); return e ? atoi(e) : 0; }();
     if (force_py > 0) py = force_py;
     py = ((py + bsh - 1) / bsh) * bsh;
