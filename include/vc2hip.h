@@ -178,6 +178,26 @@ int vc2hip_decode_picture_ld(vc2hip_ctx *ctx, const uint8_t *payload, size_t len
                              const vc2hip_picture_format *fmt, const vc2hip_coding_params *cp,
                              void *raw_out);
 
+/* Pipelined picture calls -- the per-GPU host path of SURVEY.md 8(e): one host thread, pinned staging buffers, two
+ * pictures in flight per context, so that the H2D copy of one picture, the kernels of another and the D2H copy of a
+ * third overlap (each in-flight picture has its own HIP stream and workspace inside the context).  This is what the
+ * tools' per-GPU workers drive in place of the reference's one-picture-at-a-time loop (EncodeStream.cpp:452-770,
+ * DecodeStream.cpp:289-613); results are those of the synchronous calls.
+ *   vc2hip_host_alloc / _free   page-locked host memory for raw pictures and payloads (hipHostMalloc)
+ *   *_begin                     enqueue copy-in + kernels (+ copy-out of the raw picture when decoding); returns a ticket
+ *   *_end                       wait for that ticket; encode: *len and the payload bytes are in `payload` afterwards
+ * The buffers handed to _begin must come from vc2hip_host_alloc and stay untouched until _end returned.  At most
+ * VC2HIP_MAX_INFLIGHT tickets may be open per context (VC2HIP_EINVAL beyond); tickets end in the order they began. */
+#define VC2HIP_MAX_INFLIGHT 2
+void *vc2hip_host_alloc(size_t bytes);
+void vc2hip_host_free(void *p);
+int vc2hip_encode_picture_begin(vc2hip_ctx *ctx, const void *raw, const vc2hip_picture_format *fmt,
+                                const vc2hip_coding_params *cp, uint8_t *payload, size_t cap, int32_t *qidx_out, int *ticket);
+int vc2hip_encode_picture_end(vc2hip_ctx *ctx, int ticket, size_t *len);
+int vc2hip_decode_picture_begin(vc2hip_ctx *ctx, const uint8_t *payload, size_t len, const vc2hip_picture_format *fmt,
+                                const vc2hip_coding_params *cp, void *raw_out, int *ticket);
+int vc2hip_decode_picture_end(vc2hip_ctx *ctx, int ticket);
+
 /* device-resident batches: n independent pictures per call, asynchronous on the ctx stream.
  *   d_raw       n * vc2hip_raw_picture_bytes() bytes of raw planar pictures (device memory)
  *   d_payload   n slots of payload_stride bytes each (device memory)

@@ -236,3 +236,44 @@ def test_decodestream_resynchronises_and_skips_other_units(tools, oracle, tmp_pa
     (tmp_path / "s.vc2").write_bytes(spliced)
     run("DecodeStream", tmp_path / "s.vc2", tmp_path / "d.raw")
     assert (tmp_path / "d.raw").read_bytes() == want
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_several_workers_keep_the_stream_order(tools, oracle, tmp_path, devices):
+    """N > 1 per-GPU workers (here: several workers on the one GPU of the box, --devices 0,0,..): picture k goes to
+    worker k mod N, two pictures in flight per worker; parse offsets and picture numbers chain through the ordered
+    writer, so the stream and the decoded file must be byte for byte those of one worker and of the oracle."""
+    w, h, frames = 256, 128, 11
+    raw = synth(w, h, "422", 10, 61, frames=frames)
+    p = make_params(w, h, "422", 10, "DD97", 3, 1, 2, q=7, scalar=2)
+    want_stream = oracle.encode_stream(p, raw, frames)
+    want_dec, n = oracle.decode_stream(p, want_stream, frames)
+    (tmp_path / "in.raw").write_bytes(raw)
+    args = enc_args(w, h, "422", 10, "DD97", 3, 1, 2, q=7, scalar=2)
+    run("EncodeStream", *args, tmp_path / "in.raw", tmp_path / "one.vc2")
+    run("EncodeStream", *args, "--devices", devices, tmp_path / "in.raw", tmp_path / "many.vc2")
+    assert (tmp_path / "one.vc2").read_bytes() == want_stream
+    assert (tmp_path / "many.vc2").read_bytes() == want_stream
+    run("DecodeStream", "--devices", devices, tmp_path / "many.vc2", tmp_path / "dec.raw")
+    assert (tmp_path / "dec.raw").read_bytes() == want_dec
+
+
+def test_several_workers_interlaced_cbr(tools, oracle, tmp_path):
+    w, h, frames = 256, 128, 5
+    raw = synth(w, h, "422", 10, 62, frames=frames)
+    p = make_params(w, h, "422", 10, "LeGall", 2, 2, 4, mode="HQ_CBR", s=20000, scalar=1, interlaced=True)
+    want_stream = oracle.encode_stream(p, raw, frames)
+    want_dec, n = oracle.decode_stream(p, want_stream, frames)
+    (tmp_path / "in.raw").write_bytes(raw)
+    run("EncodeStream", *enc_args(w, h, "422", 10, "LeGall", 2, 2, 4, mode="HQ_CBR", s=20000, scalar=1), "-i", "--devices", "0,0",
+        tmp_path / "in.raw", tmp_path / "out.vc2")
+    assert (tmp_path / "out.vc2").read_bytes() == want_stream
+    run("DecodeStream", "--devices", "0,0,0", tmp_path / "out.vc2", tmp_path / "dec.raw")
+    assert (tmp_path / "dec.raw").read_bytes() == want_dec
+
+
+def test_slice_surface_encode_body(tools):
+    """the encoder / decoder picture body written with the reference's Slices / sliceio / split_into_blocks vocabulary
+    (vc2-reference_amd/host/slicetest.cpp after EncodeStream.cpp:482-647, DecodeStream.cpp:451-613)"""
+    out = run("slicetest")
+    assert "slicetest ok" in out.stdout

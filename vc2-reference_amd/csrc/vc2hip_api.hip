@@ -134,6 +134,16 @@ struct vc2hip_ctx {
   struct LaneUse { Range r[2], w[2]; bool valid = false; };
   std::vector<LaneUse> lane_use;      // what lane i's latest sub-batch read and wrote (caller buffers)
   std::vector<ProfEntry> merged; // profile of this context and its lanes, rebuilt by vc2hip_profile_count
+  // pipelined picture calls: VC2HIP_MAX_INFLIGHT slots, each a child context (own stream and workspace)
+  struct Flight {
+    vc2hip_ctx *lane = nullptr;
+    bool open = false, encode = false;
+    uint8_t *payload = nullptr;      // caller's pinned buffer (encode)
+    size_t cap = 0;
+    unsigned long long *h_len = nullptr; // pinned
+  };
+  Flight flight[VC2HIP_MAX_INFLIGHT];
+  int flight_next = 0;               // slot of the next _begin
 };
 
 static const char *code_text(int code) {
@@ -305,6 +315,7 @@ extern "C" void vc2hip_destroy(vc2hip_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (vc2hip_ctx *l : c->lanes) if (l != c) vc2hip_destroy(l);
+  for (auto &f : c->flight) { if (f.lane) vc2hip_destroy(f.lane); if (f.h_len) (void)hipHostFree(f.h_len); }
   for (hipEvent_t e : c->join_ev) (void)hipEventDestroy(e);
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   c->L.collect();
@@ -316,8 +327,14 @@ extern "C" void vc2hip_destroy(vc2hip_ctx *c) {
   delete c;
 }
 
+void vc2_ld_disable_rows();
 static int err_from_flags(vc2hip_ctx *c, unsigned f) {
   if (!f) return VC2HIP_OK;
+  if (f & VC2_DEVERR_HANDOFF) { // not a property of the input: the batch has to be submitted again
+    vc2_ld_disable_rows();
+    return set_err(c, VC2HIP_EHIP, "LD index search: a hand-over between workgroups timed out; nothing was written for the batch. "
+                                   "The library now searches with one launch per slice diagonal: submit the batch again.");
+  }
   if (f & VC2_DEVERR_QINDEX) return set_err(c, VC2HIP_EQINDEX);
   if (f & VC2_DEVERR_SCALAR) return set_err(c, VC2HIP_ESCALAR);
   if (f & VC2_DEVERR_CBR_TOOBIG) return set_err(c, VC2HIP_ECBR_TOOBIG);
@@ -1490,4 +1507,99 @@ extern "C" int vc2hip_decode_picture_hq(vc2hip_ctx *c, const uint8_t *payload, s
 extern "C" int vc2hip_decode_picture_ld(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,
                                         const vc2hip_coding_params *cp, void *raw_out) {
   return decode_picture_host(c, payload, len, f, cp, raw_out, true);
+}
+
+// ------------------------------------------------------------------------------------------
+// pipelined picture calls (include/vc2hip.h): two pictures in flight per context
+// ------------------------------------------------------------------------------------------
+extern "C" void *vc2hip_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  return hipHostMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : nullptr;
+}
+extern "C" void vc2hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+static int flight_begin(vc2hip_ctx *c, bool encode, vc2hip_ctx::Flight **out, int *ticket) {
+  if (!ticket) return set_err(c, VC2HIP_EINVAL);
+  HIPCHK(c, hipSetDevice(c->device));
+  vc2hip_ctx::Flight &f = c->flight[c->flight_next];
+  if (f.open) return set_err(c, VC2HIP_EINVAL, "too many pictures in flight (VC2HIP_MAX_INFLIGHT): end the oldest ticket first");
+  if (!f.lane) {
+    const int rc = vc2hip_create(c->device, &f.lane);
+    if (rc) return set_err(c, rc, "cannot create a stream for a picture in flight");
+    HIPCHK(c, hipHostMalloc((void **)&f.h_len, 64));
+  }
+  f.open = true;
+  f.encode = encode;
+  *ticket = c->flight_next;
+  c->flight_next = (c->flight_next + 1) % VC2HIP_MAX_INFLIGHT;
+  *out = &f;
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_encode_picture_begin(vc2hip_ctx *c, const void *raw, const vc2hip_picture_format *f,
+                                           const vc2hip_coding_params *cp, uint8_t *payload, size_t cap, int32_t *qidx_out,
+                                           int *ticket) {
+  if (!c || !raw || !f || !cp || !payload) return set_err(c, VC2HIP_EINVAL);
+  vc2hip_ctx::Flight *fl;
+  int rc = flight_begin(c, true, &fl, ticket);
+  if (rc) return rc;
+  vc2hip_ctx *l = fl->lane;
+  fl->payload = payload; fl->cap = cap;
+  const size_t rb = vc2hip_raw_picture_bytes(f), pcap = (vc2hip_max_payload_bytes(f, cp) + 15) & ~(size_t)15;
+  uint8_t *d_raw, *d_pay; unsigned long long *d_len;
+  auto fail = [&](int code) { fl->open = false; return set_err(c, code, l->err.c_str()); };
+  if ((rc = need(l, B_RAW, rb + 64, (void **)&d_raw)) || (rc = need(l, B_PAYLOAD, pcap + 64, (void **)&d_pay)) ||
+      (rc = need(l, B_LENS, 64, (void **)&d_len))) return fail(rc);
+  if (hipMemcpyAsync(d_raw, raw, rb, hipMemcpyHostToDevice, l->stream) != hipSuccess) return fail(VC2HIP_EHIP);
+  if ((rc = vc2hip_encode_batch_dev(l, d_raw, 1, f, cp, d_pay, pcap, (uint64_t *)d_len))) return fail(rc);
+  (void)hipMemcpyAsync(fl->h_len, d_len, 8, hipMemcpyDeviceToHost, l->stream);
+  if (qidx_out)
+    (void)hipMemcpyAsync(qidx_out, l->buf[B_QIDX].p, (size_t)cp->y_slices * cp->x_slices * 4, hipMemcpyDeviceToHost, l->stream);
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_encode_picture_end(vc2hip_ctx *c, int ticket, size_t *len) {
+  if (!c || ticket < 0 || ticket >= VC2HIP_MAX_INFLIGHT || !len || !c->flight[ticket].open || !c->flight[ticket].encode)
+    return set_err(c, VC2HIP_EINVAL);
+  vc2hip_ctx::Flight &fl = c->flight[ticket];
+  vc2hip_ctx *l = fl.lane;
+  fl.open = false;
+  int rc = vc2hip_sync(l); // the picture's stream: lengths are on the host, error flags read
+  if (rc) return set_err(c, rc, l->err.c_str());
+  const unsigned long long n = *fl.h_len;
+  if (n > fl.cap) return set_err(c, VC2HIP_ECAP);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(fl.payload, l->buf[B_PAYLOAD].p, n, hipMemcpyDeviceToHost, l->stream)); // exactly the coded bytes
+  HIPCHK(c, hipStreamSynchronize(l->stream));
+  *len = (size_t)n;
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_decode_picture_begin(vc2hip_ctx *c, const uint8_t *payload, size_t len, const vc2hip_picture_format *f,
+                                           const vc2hip_coding_params *cp, void *raw_out, int *ticket) {
+  if (!c || !payload || !f || !cp || !raw_out) return set_err(c, VC2HIP_EINVAL);
+  vc2hip_ctx::Flight *fl;
+  int rc = flight_begin(c, false, &fl, ticket);
+  if (rc) return rc;
+  vc2hip_ctx *l = fl->lane;
+  const size_t rb = vc2hip_raw_picture_bytes(f), stride = (len + 63) & ~(size_t)63;
+  uint8_t *d_raw, *d_pay; unsigned long long *d_len;
+  auto fail = [&](int code) { fl->open = false; return set_err(c, code, l->err.c_str()); };
+  if ((rc = need(l, B_RAW, rb + 64, (void **)&d_raw)) || (rc = need(l, B_PAYLOAD, stride + 64, (void **)&d_pay)) ||
+      (rc = need(l, B_LENS, 64, (void **)&d_len))) return fail(rc);
+  *fl->h_len = len;
+  if (hipMemcpyAsync(d_pay, payload, len, hipMemcpyHostToDevice, l->stream) != hipSuccess ||
+      hipMemcpyAsync(d_len, fl->h_len, 8, hipMemcpyHostToDevice, l->stream) != hipSuccess) return fail(VC2HIP_EHIP);
+  if ((rc = decode_batch_common(l, d_pay, stride, (const uint64_t *)d_len, 1, f, cp, d_raw, cp->mode == VC2HIP_LD))) return fail(rc);
+  if (hipMemcpyAsync(raw_out, d_raw, rb, hipMemcpyDeviceToHost, l->stream) != hipSuccess) return fail(VC2HIP_EHIP);
+  return VC2HIP_OK;
+}
+
+extern "C" int vc2hip_decode_picture_end(vc2hip_ctx *c, int ticket) {
+  if (!c || ticket < 0 || ticket >= VC2HIP_MAX_INFLIGHT || !c->flight[ticket].open || c->flight[ticket].encode)
+    return set_err(c, VC2HIP_EINVAL);
+  vc2hip_ctx::Flight &fl = c->flight[ticket];
+  fl.open = false;
+  const int rc = vc2hip_sync(fl.lane);
+  return rc ? set_err(c, rc, fl.lane->err.c_str()) : VC2HIP_OK;
 }

@@ -28,6 +28,7 @@ enum : unsigned {
   VC2_DEVERR_CODE32 = 1u << 4,     // |coef| > 65534
   VC2_DEVERR_STREAM = 1u << 5,     // slice data runs past the payload
   VC2_DEVERR_LD_TOOBIG = 1u << 6,
+  VC2_DEVERR_HANDOFF = 1u << 7,    // LD index search: a row waited in vain for the row above (single-launch form)
 };
 
 struct CompGeom {

@@ -1986,6 +1986,7 @@ __global__ __launch_bounds__(256) void k_ld_tables(const LdEncParams p) {
 // candidate each; the walk over the results is the reference's loop.  Ten measurements instead of seven, a
 // dependent chain of four instead of seven.  All global loads of a step are issued together, nothing is written
 // until the index is final.
+constexpr int LD_ABORT_AT = -1; // LDS word in front of llv (the last word of the tables' padding): the row was given up
 constexpr int LD_SLOTS = 16; // candidates of round r: 4 r + (0: trial, 1: trial - step, 2: trial + step); 15: an index that was no trial
 
 // ROWS: one workgroup per row of slices of a picture walks the row (d = pictures in the batch, see k_ld_search_rows)
@@ -2018,6 +2019,7 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
   const int llA = ch ? 2 * n0c : n0y, llB = 2 * n0c; // stream indices below these are LL
   for (int i = threadIdx.x * 4; i < LD_TAB_INTS; i += blockDim.x * 4) *(int4 *)(lds_i + i) = *(const int4 *)(p.tab + i);
   __syncthreads();
+  if (threadIdx.x == 0) llv[LD_ABORT_AT] = 0;
   int qmA[CPL], qmB[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
@@ -2053,11 +2055,27 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
   if (p.search) bytes = p.slice_bytes[slice]; else qfix = p.qidx[(size_t)pic * p.n_slices + slice];
   if (wave == 0) { // reconstructed LL samples around the slice's blocks (row above: bw + 1 samples, then the column to the left), into every candidate's copy
     if (ROWS && sv > 0) { // the slice above (and with it the one above-left) is final once its index is published
+      // Hand-over between workgroups of one launch, in the form of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
+      // "Valid forms" that needs no cache maintenance: EVERY store of the handed-over samples and of the flag is a
+      // device-coherent write-through store (sc1: relaxed agent-scope atomics), the storing wavefront drains them
+      // (s_waitcnt vmcnt(0)) before it stores the flag, and EVERY load of them here is an sc1 load issued by the
+      // wavefront that polled, after its poll matched.  Nothing depends on dispatch order or placement for
+      // correctness: a workgroup that waits for one that never comes gives up (bounded wait), poisons its own row so
+      // the rows below give up at once, and reports VC2_DEVERR_HANDOFF; the library then repeats nothing silently --
+      // it reports the error and uses the per-diagonal launches from then on (vc2_launch_ld_quantise).
       const int32_t *flag = p.qidx + (size_t)pic * p.n_slices + (size_t)(sv - 1) * p.xs + sh;
-      int spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+      int spins = 0, f;
+      while ((f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 18)) { atomicOr(p.err, VC2_DEVERR_QINDEX); break; } // never on a live GPU; no hang if the row above died
+        if (++spins > (1 << 18)) { f = -2; break; }
+      }
+      if (f == -2) { // the row above is dead (or never came): stop this row too
+        if (lane == 0) {
+          atomicOr(p.err, VC2_DEVERR_HANDOFF);
+          for (int s2 = sh; s2 < p.xs; ++s2)
+            __hip_atomic_store(p.qidx + (size_t)pic * p.n_slices + (size_t)sv * p.xs + s2, -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        llv[LD_ABORT_AT] = 1;
       }
     }
     const int h0 = p.bh[0] + p.bw[0] + 1, h1 = p.bh[1] + p.bw[1] + 1, h2 = p.bh[2] + p.bw[2] + 1;
@@ -2086,6 +2104,7 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
     }
   }
   __syncthreads();
+  if (ROWS && llv[LD_ABORT_AT]) return; // every wavefront of the workgroup: the row was given up (see above)
 
   // component c's LL chain of candidate slot sl at index tq: raster scan, prediction from the reconstructed samples
   auto chain = [&](int sl, int c, int tq) {
@@ -2304,7 +2323,9 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
     }
   }
   if (ROWS && wave == 0) { // publish: the reconstructed samples first, then the index as the row's progress flag
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the coherent stores above are acknowledged (no cache write-back: they went through)
+    // this wavefront made every one of the write-through stores above: drain them, then the flag (inline asm: the
+    // compiler may not drop or move this wait -- MI355X_MICROARCH.md "Compiler hazard")
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(p.qidx + (size_t)pic * p.n_slices + slice, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   } // next slice of the row
@@ -2397,6 +2418,12 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
   for (int k = lane; k < size; k += 64) out[k] = (uint8_t)(img[k >> 2] >> (24 - 8 * (k & 3)));
 }
 
+// set once a hand-over of the single-launch search timed out (vc2hip_sync saw VC2_DEVERR_HANDOFF): from then on the
+// search runs as one launch per anti-diagonal of slices, which needs no hand-over inside a launch
+static bool g_ld_rows_disabled = false;
+bool vc2_ld_rows_disabled() { return g_ld_rows_disabled; }
+void vc2_ld_disable_rows() { g_ld_rows_disabled = true; }
+
 void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, p.search ? "ld_search" : "ld_quantise", s);
   const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.comp_n[1] > 0 && 3 * p.depth + 1 <= 32 &&
@@ -2410,7 +2437,7 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     const bool dual = p.comp_n[0] <= reach && 2 * p.comp_n[1] <= reach; // half a wavefront covers a stream
     VC2_LAUNCH(L, k_ld_tables, dim3(1), dim3(256), 0, s, p);
     static const int rows = [] { const char *e = getenv("VC2HIP_LD_ROWS"); return e ? atoi(e) : 1; }();
-    if (rows && p.search) {
+    if (rows && p.search && !vc2_ld_rows_disabled()) {
       // 3 wavefronts (LL chains + 2 x subbands) measured fastest: 3.2 ms per 16 HD pictures, 4 wavefronts 3.6, one launch per anti-diagonal 3.7-3.9
       static const int nwr = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : v > 4 ? 4 : v; }();
       (void)hipMemsetAsync(p.qidx, 0xFF, (size_t)n_pictures * p.n_slices * sizeof(int32_t), s); // progress flags: -1 = not final

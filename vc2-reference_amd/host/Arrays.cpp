@@ -1,4 +1,5 @@
 #include "Arrays.h"
+#include "WaveletTransform.h"
 
 #include <algorithm>
 #include <cstring>
@@ -39,4 +40,39 @@ const Array2D merge_blocks(const BlockArray &blocks) {
       for (Index y = 0; y < bh; ++y)
         std::memcpy(out[v * bh + y] + h * bw, blocks.at(v, h)[y], (std::size_t)bw * sizeof(int));
   return out;
+}
+
+// WaveletTransform.cpp:428-450: subband b of an in-place transform as a dense array.  LL: stride 2^depth, phase 0;
+// level L (1 .. depth): stride s = 2^(depth + 1 - L), phase s / 2 -- HL (columns), LH (rows), HH (both)
+const BlockVector split_into_subbands(const Array2D &picture, char waveletDepth) {
+  const Index H = picture.shape()[0], W = picture.shape()[1];
+  BlockVector bands;
+  Index stride = (Index)1 << waveletDepth;
+  bands.push_back(View2D(picture, Range(0, H, stride), Range(0, W, stride)));
+  for (char level = 1; level <= waveletDepth; ++level) {
+    stride = (Index)1 << (waveletDepth + 1 - level);
+    const Index offset = stride / 2;
+    bands.push_back(View2D(picture, Range(0, H, stride), Range(offset, W, stride)));
+    bands.push_back(View2D(picture, Range(offset, H, stride), Range(0, W, stride)));
+    bands.push_back(View2D(picture, Range(offset, H, stride), Range(offset, W, stride)));
+  }
+  return bands;
+}
+
+// WaveletTransform.cpp:454-476
+const Array2D merge_subbands(const BlockVector &subbands) {
+  const char waveletDepth = (char)((subbands.size() - 1) / 3);
+  const Index H = subbands[0].shape()[0] << waveletDepth, W = subbands[0].shape()[1] << waveletDepth;
+  Array2D picture(H, W);
+  Index stride = (Index)1 << waveletDepth;
+  View2D(picture, Range(0, H, stride), Range(0, W, stride)) = subbands[0];
+  std::size_t band = 1;
+  for (char level = 1; level <= waveletDepth; ++level) {
+    stride = (Index)1 << (waveletDepth + 1 - level);
+    const Index offset = stride / 2;
+    View2D(picture, Range(0, H, stride), Range(offset, W, stride)) = subbands[band++];
+    View2D(picture, Range(offset, H, stride), Range(0, W, stride)) = subbands[band++];
+    View2D(picture, Range(offset, H, stride), Range(offset, W, stride)) = subbands[band++];
+  }
+  return picture;
 }

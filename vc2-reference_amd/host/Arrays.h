@@ -47,6 +47,44 @@ class Array2D {
   std::vector<int> v_;
 };
 
+// Range(start, finish, stride) / Range(): the index ranges the reference writes as indices[Range(..)][Range(..)]
+// (Arrays.h:17-50); a default Range is the whole extent
+struct Range {
+  Index start, finish, stride;
+  bool all;
+  Range() : start(0), finish(0), stride(1), all(true) {}
+  Range(Index s, Index f, Index st = 1) : start(s), finish(f), stride(st), all(false) {}
+  Index first(Index) const { return all ? 0 : start; }
+  Index count(Index extent) const { return all ? extent : (finish > start ? (finish - start + stride - 1) / stride : 0); }
+};
+
+// a strided window onto an Array2D (the reference's View2D / ConstView2D): reads, writes, element-wise copies
+class View2D {
+ public:
+  View2D(Array2D &a, const Range &rows, const Range &cols)
+      : base_(a.data() + rows.first(a.shape()[0]) * a.shape()[1] + cols.first(a.shape()[1])),
+        rs_(rows.stride * a.shape()[1]), cs_(cols.stride), h_(rows.count(a.shape()[0])), w_(cols.count(a.shape()[1])) {}
+  View2D(const Array2D &a, const Range &rows, const Range &cols) : View2D(const_cast<Array2D &>(a), rows, cols) {}
+  Shape2D shape() const { Shape2D s = {{h_, w_}}; return s; }
+  int &at(Index y, Index x) { return base_[y * rs_ + x * cs_]; }
+  int at(Index y, Index x) const { return base_[y * rs_ + x * cs_]; }
+  View2D &operator=(const Array2D &src) { // element copy; shapes must agree
+    for (Index y = 0; y < h_; ++y) for (Index x = 0; x < w_; ++x) at(y, x) = src[y][x];
+    return *this;
+  }
+  operator Array2D() const { // a dense copy (what assigning a view to an Array2D does in the reference)
+    Array2D out(h_, w_);
+    for (Index y = 0; y < h_; ++y) for (Index x = 0; x < w_; ++x) out[y][x] = at(y, x);
+    return out;
+  }
+
+ private:
+  int *base_;
+  Index rs_, cs_, h_, w_;
+};
+
+typedef std::vector<Array2D> BlockVector; // the subbands of a transform, LL first (Arrays.h)
+
 // ySlices x xSlices blocks of planes
 struct BlockArray {
   int ys, xs;

@@ -3,6 +3,9 @@
 // the per-picture body on MI355X through libvc2hip.  Extension: --gpus N decodes picture k on GPU k mod N.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <algorithm>
 #include <fstream>
 #include <iostream>
 #include <iterator>
@@ -13,6 +16,7 @@
 #include "DataUnit.h"
 #include "Frame.h"
 #include "Hip.h"
+#include "Pipeline.h"
 #include "Picture.h"
 #include "Quantisation.h"
 #include "Slices.h"
@@ -40,18 +44,9 @@ static void writeSigned4(std::ostream &os, const Array2D &a) {
 }
 static void writePicture4(std::ostream &os, const Picture &p) { writeSigned4(os, p.y()); writeSigned4(os, p.c1()); writeSigned4(os, p.c2()); }
 
-static const std::vector<ArgSpec> SPECS = {{'v', "verbose", false, ""}, {'o', "output", true, ""}, {'G', "gpus", true, ""}, {'h', "help", false, ""}};
-static const char *USAGE = "DecodeStream (MI355X / libvc2hip)\nUsage: DecodeStream [-v] [-o Transform|Quantised|Indices|Decoded] [--gpus N] inFile outFile\n";
+static const std::vector<ArgSpec> SPECS = {{'v', "verbose", false, ""}, {'o', "output", true, ""}, {'G', "gpus", true, ""}, {'D', "devices", true, ""}, {'h', "help", false, ""}};
+static const char *USAGE = "DecodeStream (MI355X / libvc2hip)\nUsage: DecodeStream [-v] [-o Transform|Quantised|Indices|Decoded] [--gpus N | --devices a,b,..] inFile outFile\n";
 
-struct Job { // one picture waiting for its GPU
-  bool ld;
-  PicturePreamble pre;
-  const unsigned char *data; // slice bytes inside the input, or owned.data() for a reassembled picture
-  std::size_t len;
-  int compressedBytes;       // LD byte budget of the picture
-  std::vector<unsigned char> owned, raw;
-  string error;
-};
 
 struct Reassembly { // slices of a fragmented picture collected so far (DecodeStream.cpp:62-101)
   bool ld;
@@ -66,6 +61,7 @@ int main(int argc, char *argv[]) {
   try {
     if (argc < 2) { clog << USAGE; return EXIT_SUCCESS; }
     string inFileName, outFileName; bool verbose; Output output; int gpus;
+    std::vector<int> devices;
     try {
       Args a(SPECS, argc, argv);
       if (a.isSet("help")) { cout << USAGE; return EXIT_SUCCESS; }
@@ -75,6 +71,15 @@ int main(int argc, char *argv[]) {
       output = a.isSet("output") ? parseOutput(a.get("output")) : DECODED;
       gpus = a.getInt("gpus", 1);
       if (gpus < 1) throw std::invalid_argument("gpus must be >= 1");
+      if (a.isSet("devices")) { // explicit HIP devices of the workers (a device may repeat): overrides --gpus
+        const string list = a.get("devices");
+        for (std::size_t p0 = 0; p0 <= list.size();) {
+          const std::size_t p1 = list.find(',', p0) == string::npos ? list.size() : list.find(',', p0);
+          try { devices.push_back(std::stoi(list.substr(p0, p1 - p0))); }
+          catch (...) { throw std::invalid_argument("Couldn't read argument value from string '" + list + "' for arg --devices"); }
+          p0 = p1 + 1;
+        }
+      } else for (int g = 0; g < gpus; ++g) devices.push_back(g);
     } catch (const std::exception &e) { cerr << "Command line error: " << e.what() << endl; return EXIT_FAILURE; }
 
     std::ifstream inFile; std::ofstream outFile;
@@ -92,47 +97,44 @@ int main(int argc, char *argv[]) {
     bool interlaced = false, topFieldFirst = true;
     ColourFormat chromaFormat = CF_UNSET;
     int frame = 0, pic = 0;
-    std::vector<Job> jobs;
     std::vector<unsigned char> outFrame; // interlaced: the frame being filled field by field
     std::map<unsigned long, Reassembly> reassembling;
 
-    auto flush = [&]() { // decode the queued pictures, picture k on GPU k, and write them in order
-      if (jobs.empty()) return;
-      const int pictureHeight = interlaced ? height / 2 : height;
-      const PictureFormat frameFormat(height, width, chromaFormat);
-      vc2hip_picture_format pf = {width, pictureHeight, (int)chromaFormat, depthBits, bytes};
-      std::vector<std::thread> th;
-      for (std::size_t g = 0; g < jobs.size(); ++g)
-        th.emplace_back([&, g]() {
-          Job &j = jobs[g];
-          try {
-            vc2hip_ctx *c = hipContext((int)g);
-            vc2hip_coding_params cp = {(int)j.pre.wavelet_kernel, j.pre.depth, j.pre.slices_y, j.pre.slices_x,
-                                       j.ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0, j.compressedBytes, j.pre.slice_prefix,
-                                       j.pre.slice_size_scalar};
-            const unsigned char *data = j.owned.empty() ? j.data : j.owned.data();
-            j.raw.resize(vc2hip_raw_picture_bytes(&pf));
-            hipCheck(c, (j.ld ? vc2hip_decode_picture_ld : vc2hip_decode_picture_hq)(c, data, j.len, &pf, &cp, j.raw.data()));
-          } catch (const std::exception &e) { j.error = e.what(); }
-        });
-      for (auto &t : th) t.join();
-      for (Job &j : jobs) {
-        if (!j.error.empty()) throw std::logic_error(j.error);
-        if (verbose) clog << "Copy picture to output frame" << endl;
-        if (interlaced) { // DecodeStream.cpp:417-428: first field, then second field, then the frame is written
-          if (pic == 0) outFrame.assign((std::size_t)frameFormat.samples() * bytes, 0);
-          insertFieldRaw(outFrame.data(), frameFormat, bytes, (pic == 0) == topFieldFirst, j.raw.data());
-          if (pic == 0) { pic = 1; continue; }
-          pic = 0;
-          if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
-          out->write((const char *)outFrame.data(), (std::streamsize)outFrame.size());
-        } else {
-          if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
-          out->write((const char *)j.raw.data(), (std::streamsize)j.raw.size());
-        }
-        ++frame;
+    // Decoded output: pictures go to the per-GPU workers (picture k to worker k mod N, two in flight per worker:
+    // Pipeline.h) and come back in order.  The largest data unit of the input bounds a picture's payload.
+    std::size_t maxUnit = 0;
+    for (std::size_t p0 = pos; p0 + 13 <= s.size();) {
+      const std::size_t nxt = ((std::size_t)s[p0 + 5] << 24) | ((std::size_t)s[p0 + 6] << 16) | ((std::size_t)s[p0 + 7] << 8) | s[p0 + 8];
+      if (nxt == 0) { maxUnit = std::max(maxUnit, s.size() - p0); break; }
+      maxUnit = std::max(maxUnit, nxt);
+      p0 += nxt;
+    }
+    std::unique_ptr<GpuWorkers> workers;
+    unsigned long long seq = 0;
+    auto writeDecoded = [&](const PictureResult &r) {
+      if (!r.error.empty()) throw std::logic_error(r.error);
+      if (verbose) clog << "Copy picture to output frame" << endl;
+      if (interlaced) { // DecodeStream.cpp:417-428: first field, then second field, then the frame is written
+        const PictureFormat frameFormat(height, width, chromaFormat);
+        if (pic == 0) outFrame.assign((std::size_t)frameFormat.samples() * bytes, 0);
+        insertFieldRaw(outFrame.data(), frameFormat, bytes, (pic == 0) == topFieldFirst, r.bytes.data());
+        if (pic == 0) { pic = 1; return; }
+        pic = 0;
+        if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
+        out->write((const char *)outFrame.data(), (std::streamsize)outFrame.size());
+      } else {
+        if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
+        out->write((const char *)r.bytes.data(), (std::streamsize)r.bytes.size());
       }
-      jobs.clear();
+      ++frame;
+    };
+    auto flush = [&]() { // everything submitted so far is decoded and written (a new sequence header may change the format)
+      if (!workers) return;
+      PictureResult r;
+      workers->close();
+      while (workers->wait(r)) writeDecoded(r);
+      workers.reset();
+      seq = 0;
     };
 
     // one complete picture's slice bytes: queue it for a GPU, or run the diagnostic outputs
@@ -140,10 +142,15 @@ int main(int argc, char *argv[]) {
                              std::vector<unsigned char> *owned) {
       const int pictureHeight = interlaced ? height / 2 : height;
       if (output == DECODED) {
-        Job j; j.ld = ld; j.pre = pre; j.data = data; j.len = dlen; j.compressedBytes = compressedBytes;
-        if (owned) j.owned.swap(*owned);
-        jobs.push_back(j);
-        if ((int)jobs.size() == gpus) flush();
+        (void)owned;
+        vc2hip_picture_format pf = {width, pictureHeight, (int)chromaFormat, depthBits, bytes};
+        vc2hip_coding_params cp = {(int)pre.wavelet_kernel, pre.depth, pre.slices_y, pre.slices_x, ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0,
+                                   compressedBytes, pre.slice_prefix, pre.slice_size_scalar};
+        if (!workers) workers.reset(new GpuWorkers(devices, std::max(maxUnit, dlen), vc2hip_raw_picture_bytes(&pf)));
+        std::memcpy(workers->inputBuffer(seq), data, dlen);
+        workers->submitDecode(seq++, dlen, pf, cp, ld);
+        PictureResult r;
+        while (workers->poll(r)) writeDecoded(r);
         return;
       }
       // diagnostic outputs through the fine-grained functions
@@ -201,7 +208,8 @@ int main(int argc, char *argv[]) {
           break;
         }
         case END_OF_SEQUENCE:
-          if (verbose) clog << "End of Sequence after " << frame + (int)jobs.size() << " frames" << endl;
+          flush();
+          if (verbose) clog << "End of Sequence after " << frame << " frames" << endl;
           break;
         case AUXILIARY_DATA:
           if (du.length() < 0) throw std::logic_error("Auxilliary data length is less than zero.");

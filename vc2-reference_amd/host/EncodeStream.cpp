@@ -14,6 +14,7 @@
 #include "DataUnit.h"
 #include "Frame.h"
 #include "Hip.h"
+#include "Pipeline.h"
 #include "Picture.h"
 #include "Quantisation.h"
 #include "Slices.h"
@@ -66,16 +67,14 @@ static const std::vector<ArgSpec> SPECS = {
     {'z', "bitDepth", true, ""}, {'n', "bytes", true, ""}, {'f', "format", true, ""}, {'x', "width", true, ""},
     {'y', "height", true, ""}, {'r', "framerate", true, ""}, {'S', "scalar", true, ""}, {'P', "prefix", true, ""},
     {'F', "fragmentLength", true, ""}, {'s', "compressedBytes", true, ""}, {'q', "quantIndex", true, ""},
-    {'G', "gpus", true, ""}, {'h', "help", false, ""}};
+    {'G', "gpus", true, ""}, {'D', "devices", true, ""}, {'h', "help", false, ""}};
 
 static const char *USAGE =
     "EncodeStream (MI355X / libvc2hip)\n"
     "Usage: EncodeStream -m <HQ_ConstQ|HQ_CBR|LD> -k <kernel> -d <depth> -u <vSlice> -a <hSlice> -f <4:4:4|4:2:2|4:2:0>\n"
     "       -x <width> -y <height> [-l lumaDepth] [-c chromaDepth] [-z bitDepth] [-n bytes] [-r framerate]\n"
     "       [-i [-t|-b]] [-F fragmentLength] [-q quantIndex] [-s compressedBytes] [-S scalar] [-P prefix] [-o Transform|Quantised|Indices|Packaged|\n"
-    "       Stream|Decoded|PSNR] [-v] [--gpus N] inFile outFile      (\"-\" = standard input / output)\n";
-
-struct Encoded { std::vector<unsigned char> payload; Array2D qidx; string error; };
+    "       Stream|Decoded|PSNR] [-v] [--gpus N | --devices a,b,..] inFile outFile      (\"-\" = standard input / output)\n";
 
 int main(int argc, char *argv[]) {
   try {
@@ -84,6 +83,7 @@ int main(int argc, char *argv[]) {
     string inFileName, outFileName; bool verbose; int height, width, bytes, lumaDepth, chromaDepth; ColourFormat chromaFormat;
     WaveletKernel kernel; int waveletDepth, ySize, xSize; Output output; Mode mode; int frameRate, sliceScalar, slicePrefix;
     int fragmentLength, compressedBytes, qIndex, gpus; bool interlaced, topFieldFirst;
+    std::vector<int> devices;
     try {
       Args a(SPECS, argc, argv);
       if (a.isSet("help")) { cout << USAGE; return EXIT_SUCCESS; }
@@ -139,6 +139,15 @@ int main(int argc, char *argv[]) {
       if (mode != HQ_ConstQ && compressedBytes < 1) throw std::invalid_argument("number of compressed bytes must be >0");
       if (mode == HQ_ConstQ && (qIndex < 0 || qIndex > 119)) throw std::invalid_argument("quantisation index must be in the range 0 to 119");
       if (gpus < 1) throw std::invalid_argument("gpus must be >= 1");
+      if (a.isSet("devices")) { // explicit HIP devices of the workers (a device may repeat): overrides --gpus
+        const string list = a.get("devices");
+        for (std::size_t p0 = 0; p0 <= list.size();) {
+          const std::size_t p1 = list.find(',', p0) == string::npos ? list.size() : list.find(',', p0);
+          try { devices.push_back(std::stoi(list.substr(p0, p1 - p0))); }
+          catch (...) { throw std::invalid_argument("Couldn't read argument value from string '" + list + "' for arg --devices"); }
+          p0 = p1 + 1;
+        }
+      } else for (int g = 0; g < gpus; ++g) devices.push_back(g);
     } catch (const std::exception &e) {
       cerr << "Command line error: " << e.what() << endl;
       return EXIT_FAILURE;
@@ -212,11 +221,74 @@ int main(int argc, char *argv[]) {
 
     unsigned long long frame = 0;
     bool done = false;
-    std::vector<std::vector<unsigned char> > raws((std::size_t)gpus);
+
+    if (output == STREAM) {
+      // The fused picture path (EncodeStream.cpp:482-647 on the device), pipelined: this thread reads frames into the
+      // workers' pinned buffers and writes finished pictures in order; picture k is coded by worker k mod N, which keeps
+      // two pictures in flight on its GPU (Pipeline.h).  An interlaced frame is two pictures, first field first
+      // (Frame.cpp:90-104).
+      GpuWorkers workers(devices, picBytes, vc2hip_max_payload_bytes(&pf, &cp) + 64);
+      const utils::Rational ldRatio = utils::rationalise(pictureBytes, ySlices * xSlices);
+      auto writePicture = [&](const PictureResult &e) { // the ordered writer: parse offsets and picture numbers chain
+        if (!e.error.empty()) throw std::logic_error(e.error);
+        if (verbose) clog << "Forward transform" << endl << "Quantise transform coefficients" << endl << "Writing compressed output to file" << endl;
+        const unsigned long picnum = utils::getPictureNumber((int)(e.seq % framePics), e.seq / framePics, framePics);
+        du.clear();
+        if (fragmented) {
+          // DataUnit.cpp:156-232 / :267-342: parameters fragment + fragments of whole slices
+          const std::vector<unsigned char> params =
+              mode == LD ? writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)ldRatio.numerator, (unsigned)ldRatio.denominator)
+                         : writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)slicePrefix, (unsigned)sliceScalar);
+          std::vector<std::size_t> sizes;
+          if (mode == LD) for (std::size_t i = 0; i < ldSliceBytes.num_elements(); ++i) sizes.push_back((std::size_t)ldSliceBytes.data()[i]);
+          else sizes = sliceSizesHQ(e.bytes.data(), e.bytes.size(), ySlices * xSlices, slicePrefix, sliceScalar);
+          writeFragmentedPicture(du, mode == LD, picnum, params, e.bytes.data(), sizes, xSlices, fragmentLength, &prev_parse_offset);
+          out->write((const char *)du.data(), (std::streamsize)du.size());
+        } else {
+          const std::vector<unsigned char> hdr =
+              mode == LD ? writePictureHeaderLD(picnum, kernel, waveletDepth, xSlices, ySlices, ldRatio, major_version)
+                         : writePictureHeaderHQ(picnum, kernel, waveletDepth, xSlices, ySlices, slicePrefix, sliceScalar, major_version);
+          const unsigned long next = (unsigned long)(hdr.size() + e.bytes.size() + 13);
+          writeParseInfo(du, mode == LD ? LD_PICTURE : HQ_PICTURE, next, prev_parse_offset);
+          prev_parse_offset = next;
+          du.insert(du.end(), hdr.begin(), hdr.end());
+          out->write((const char *)du.data(), (std::streamsize)du.size());
+          out->write((const char *)e.bytes.data(), (std::streamsize)e.bytes.size());
+        }
+        if (!*out) throw std::runtime_error(string("Failed to write output file \"") + outFileName + "\"");
+      };
+      std::vector<unsigned char> frameBuf; // interlaced: the frame is read here and its fields go to the workers
+      unsigned long long seq = 0;
+      PictureResult res;
+      for (;; ++frame) {
+        if (verbose) clog << "Reading input frame number " << frame;
+        unsigned char *dst;
+        if (interlaced) { frameBuf.resize(frameBytes); dst = frameBuf.data(); }
+        else dst = workers.inputBuffer(seq);
+        in->read((char *)dst, (std::streamsize)frameBytes);
+        if ((std::size_t)in->gcount() < frameBytes) {
+          if (frame == 0) { cerr << "\rFailed to read input frame number 0" << endl; return EXIT_FAILURE; }
+          if (verbose) clog << "\rEnd of input reached after " << frame << " frames" << endl;
+          break; // (the buffer taken for the missing frame is simply never submitted)
+        } else if (verbose) clog << endl;
+        if (interlaced) {
+          for (int pic = 0; pic < framePics; ++pic) {
+            extractFieldRaw(frameBuf.data(), format, bytes, (pic == 0) == topFieldFirst, workers.inputBuffer(seq));
+            workers.submitEncode(seq++, pf, cp, mode == LD);
+          }
+        } else workers.submitEncode(seq++, pf, cp, mode == LD);
+        while (workers.poll(res)) writePicture(res);
+      }
+      workers.close();
+      while (workers.wait(res)) writePicture(res);
+      done = true;
+    }
+
+    std::vector<std::vector<unsigned char> > raws(1);
     while (!done) {
-      // read up to `gpus` frames
+      // diagnostic outputs work on one frame at a time
       int got = 0;
-      for (; got < gpus; ++got) {
+      for (; got < 1; ++got) {
         raws[got].resize(frameBytes);
         if (verbose) clog << "Reading input frame number " << frame + got;
         in->read((char *)raws[got].data(), (std::streamsize)frameBytes);
@@ -228,68 +300,6 @@ int main(int argc, char *argv[]) {
         } else if (verbose) clog << endl;
       }
       if (got == 0) break;
-
-      if (output == STREAM) {
-        // fused picture path: frame k of this group on GPU k (EncodeStream.cpp:482-647 on the device);
-        // an interlaced frame is two pictures, first field first (Frame.cpp:90-104)
-        std::vector<Encoded> enc((std::size_t)(got * framePics));
-        std::vector<std::thread> th;
-        for (int g = 0; g < got; ++g)
-          th.emplace_back([&, g]() {
-            std::vector<unsigned char> field;
-            for (int pic = 0; pic < framePics; ++pic) {
-              Encoded &e = enc[(std::size_t)(g * framePics + pic)];
-              try {
-                vc2hip_ctx *c = hipContext(g);
-                const unsigned char *src = raws[g].data();
-                if (interlaced) {
-                  field.resize(picBytes);
-                  extractFieldRaw(raws[g].data(), format, bytes, (pic == 0) == topFieldFirst, field.data());
-                  src = field.data();
-                }
-                e.payload.resize(vc2hip_max_payload_bytes(&pf, &cp) + 64);
-                e.qidx = Array2D(ySlices, xSlices);
-                std::size_t len = 0;
-                hipCheck(c, (mode == LD ? vc2hip_encode_picture_ld : vc2hip_encode_picture_hq)(
-                                c, src, &pf, &cp, e.payload.data(), e.payload.size(), &len, e.qidx.data()));
-                e.payload.resize(len);
-              } catch (const std::exception &ex) { e.error = ex.what(); }
-            }
-          });
-        for (auto &t : th) t.join();
-        for (int k = 0; k < got * framePics; ++k) { // ordered writer: parse offsets and picture numbers chain in order
-          const Encoded &e = enc[(std::size_t)k];
-          if (!e.error.empty()) throw std::logic_error(e.error);
-          if (verbose) clog << "Forward transform" << endl << "Quantise transform coefficients" << endl << "Writing compressed output to file" << endl;
-          const unsigned long picnum = utils::getPictureNumber(k % framePics, frame + (unsigned long long)(k / framePics), framePics);
-          const utils::Rational ldRatio = utils::rationalise(pictureBytes, ySlices * xSlices);
-          du.clear();
-          if (fragmented) {
-            // DataUnit.cpp:156-232 / :267-342: parameters fragment + fragments of whole slices
-            const std::vector<unsigned char> params =
-                mode == LD ? writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)ldRatio.numerator, (unsigned)ldRatio.denominator)
-                           : writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)slicePrefix, (unsigned)sliceScalar);
-            std::vector<std::size_t> sizes;
-            if (mode == LD) for (std::size_t i = 0; i < ldSliceBytes.num_elements(); ++i) sizes.push_back((std::size_t)ldSliceBytes.data()[i]);
-            else sizes = sliceSizesHQ(e.payload.data(), e.payload.size(), ySlices * xSlices, slicePrefix, sliceScalar);
-            writeFragmentedPicture(du, mode == LD, picnum, params, e.payload.data(), sizes, xSlices, fragmentLength, &prev_parse_offset);
-            out->write((const char *)du.data(), (std::streamsize)du.size());
-          } else {
-            const std::vector<unsigned char> hdr =
-                mode == LD ? writePictureHeaderLD(picnum, kernel, waveletDepth, xSlices, ySlices, ldRatio, major_version)
-                           : writePictureHeaderHQ(picnum, kernel, waveletDepth, xSlices, ySlices, slicePrefix, sliceScalar, major_version);
-            const unsigned long next = (unsigned long)(hdr.size() + e.payload.size() + 13);
-            writeParseInfo(du, mode == LD ? LD_PICTURE : HQ_PICTURE, next, prev_parse_offset);
-            prev_parse_offset = next;
-            du.insert(du.end(), hdr.begin(), hdr.end());
-            out->write((const char *)du.data(), (std::streamsize)du.size());
-            out->write((const char *)e.payload.data(), (std::streamsize)e.payload.size());
-          }
-          if (!*out) { cerr << "Failed to write output file \"" << outFileName << "\"" << endl; return EXIT_FAILURE; }
-        }
-        frame += got;
-        continue;
-      }
 
       // diagnostic outputs: the fine-grained Library functions, one frame at a time
       for (int g = 0; g < got; ++g, ++frame) {

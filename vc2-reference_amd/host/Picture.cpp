@@ -65,3 +65,34 @@ void packSamples(const Array2D &plane, int wordBytes, int bitDepth, bool leftJus
     for (int b = 0; b < wordBytes; ++b) raw[i * wordBytes + b] = (unsigned char)(v >> (8 * (wordBytes - 1 - b)));
   }
 }
+
+// Picture.cpp:231-247: slice (v, h) of every component
+const PictureArray split_into_blocks(const Picture &picture, int ySlices, int xSlices) {
+  const BlockArray y = split_into_blocks(picture.y(), ySlices, xSlices);
+  const BlockArray u = split_into_blocks(picture.c1(), ySlices, xSlices);
+  const BlockArray v = split_into_blocks(picture.c2(), ySlices, xSlices);
+  const PictureFormat f((int)y.at(0, 0).shape()[0], (int)y.at(0, 0).shape()[1], (int)u.at(0, 0).shape()[0],
+                        (int)u.at(0, 0).shape()[1], picture.format().chromaFormat());
+  PictureArray out(ySlices, xSlices);
+  for (int i = 0; i < ySlices; ++i)
+    for (int j = 0; j < xSlices; ++j) {
+      Picture p(f);
+      p.y(y.at(i, j)); p.c1(u.at(i, j)); p.c2(v.at(i, j));
+      out.at(i, j) = p;
+    }
+  return out;
+}
+
+// Picture.cpp:249-271
+const Picture merge_blocks(const PictureArray &blocks) {
+  const int ys = (int)blocks.shape()[0], xs = (int)blocks.shape()[1];
+  BlockArray y(ys, xs), u(ys, xs), v(ys, xs);
+  for (int i = 0; i < ys; ++i)
+    for (int j = 0; j < xs; ++j) { y.at(i, j) = blocks.at(i, j).y(); u.at(i, j) = blocks.at(i, j).c1(); v.at(i, j) = blocks.at(i, j).c2(); }
+  const Array2D my = merge_blocks(y), mu = merge_blocks(u), mv = merge_blocks(v);
+  const PictureFormat f((int)my.shape()[0], (int)my.shape()[1], (int)mu.shape()[0], (int)mu.shape()[1],
+                        blocks.at(0, 0).format().chromaFormat());
+  Picture out(f);
+  out.y(my); out.c1(mu); out.c2(mv);
+  return out;
+}

@@ -5,6 +5,7 @@
 
 #include <iosfwd>
 #include <string>
+#include <vector>
 
 #include "Arrays.h"
 
@@ -50,6 +51,26 @@ class Picture {
   PictureFormat fmt;
   Array2D luma, c1_, c2_;
 };
+
+// ySlices x xSlices pictures (the reference's PictureArray, a 2-D multi_array of Picture)
+class PictureArray {
+ public:
+  PictureArray(int y = 0, int x = 0) : ys_(y), xs_(x), p_((std::size_t)(y * x)) { d_[0] = y; d_[1] = x; }
+  const Index *shape() const { return dims(); }
+  Picture &at(int v, int h) { return p_[(std::size_t)(v * xs_ + h)]; }
+  const Picture &at(int v, int h) const { return p_[(std::size_t)(v * xs_ + h)]; }
+  Picture *operator[](int v) { return p_.data() + (std::size_t)v * xs_; }
+  const Picture *operator[](int v) const { return p_.data() + (std::size_t)v * xs_; }
+
+ private:
+  const Index *dims() const { d_[0] = ys_; d_[1] = xs_; return d_; }
+  int ys_, xs_;
+  mutable Index d_[2];
+  std::vector<Picture> p_;
+};
+
+const PictureArray split_into_blocks(const Picture &picture, int ySlices, int xSlices); // Picture.cpp:231-247
+const Picture merge_blocks(const PictureArray &blocks);                                // Picture.cpp:249-271
 
 const Picture clip(const Picture &p, int yMin, int yMax, int uvMin, int uvMax); // Picture.cpp:284-292
 

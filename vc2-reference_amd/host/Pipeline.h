@@ -1,0 +1,75 @@
+// Pipeline.h -- the per-GPU pipelined host path of the tools: a reader, one worker thread per GPU
+// with its own libvc2hip context and pinned staging buffers, and an ordered writer.
+//
+// The reference's loop handles one picture at a time (EncodeStream.cpp:452-770, DecodeStream.cpp:289-613); pictures are
+// independent, and only the ORDER of what is written chains (parse offsets, DataUnit.cpp:112-123; picture numbers,
+// Utils.cpp:52-63).  So: picture k goes to worker k mod N; a worker keeps VC2HIP_MAX_INFLIGHT pictures in flight
+// through the asynchronous picture calls of include/vc2hip.h (copy-in of one picture, kernels of another and copy-out
+// of a third overlap); results come back to the caller in picture order.  Nothing here touches picture data on the
+// CPU except the copies in and out of the staging buffers.
+#ifndef VC2HOST_PIPELINE_H
+#define VC2HOST_PIPELINE_H
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "vc2hip.h"
+
+struct PictureResult {
+  unsigned long long seq = 0;
+  std::vector<unsigned char> bytes; // encode: the slice payload; decode: the raw picture
+  std::vector<int> qidx;            // encode: the quantiser indices (ys * xs)
+  std::string error;                // the exception text of a failed picture (thrown again by the caller, in order)
+};
+
+class GpuWorkers {
+ public:
+  // devices[g]: HIP device of worker g (a device may appear more than once: more pictures in flight on it).
+  // in_bytes / out_bytes: upper bounds of one picture's input and output
+  GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, std::size_t out_bytes);
+  ~GpuWorkers();
+  // a pinned buffer to put picture `seq`'s input in (blocks until the worker of seq has one free); then submit it
+  unsigned char *inputBuffer(unsigned long long seq);
+  void submitEncode(unsigned long long seq, const vc2hip_picture_format &pf, const vc2hip_coding_params &cp, bool ld);
+  void submitDecode(unsigned long long seq, std::size_t len, const vc2hip_picture_format &pf, const vc2hip_coding_params &cp, bool ld);
+  bool poll(PictureResult &r); // the next picture in order, if it is done
+  bool wait(PictureResult &r); // blocking; false once every submitted picture has been returned
+  void close();                // no more submissions: the workers finish what they hold
+
+ private:
+  struct Job {
+    unsigned long long seq;
+    int slot;
+    bool decode, ld;
+    std::size_t len;
+    vc2hip_picture_format pf;
+    vc2hip_coding_params cp;
+  };
+  struct Worker {
+    int device = 0;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> queue;
+    std::vector<unsigned char *> in, out; // pinned, SLOTS each
+    std::vector<bool> busy;               // input slot handed out and not yet finished
+    int next_slot = 0;
+    bool closing = false;
+    std::string init_error;
+  };
+  static const int SLOTS = VC2HIP_MAX_INFLIGHT + 1;
+  void run(Worker &w);
+  void publish(PictureResult &&r);
+  std::vector<Worker *> workers_;
+  std::size_t in_bytes_, out_bytes_;
+  std::mutex rm_;
+  std::condition_variable rcv_;
+  std::map<unsigned long long, PictureResult> done_;
+  std::map<unsigned long long, int> slot_of_; // seq -> input slot, between inputBuffer and submit
+  unsigned long long next_out_ = 0, submitted_ = 0;
+};
+#endif

@@ -17,6 +17,9 @@ int paddedSize(int size, int depth);                                            
 int sliceSizeIsValid(int waveletDepth, int lengthLuma, int lengthChroma, int nSize);    // :116-136
 const Array1D quantMatrix(WaveletKernel kernel, int depth);                                   // :345-423
 
+const BlockVector split_into_subbands(const Array2D &picture, char waveletDepth);             // :428-450
+const Array2D merge_subbands(const BlockVector &subbands);                                   // :454-476
+
 const Array2D waveletTransform(const Array2D &picture, WaveletKernel kernel, int depth);      // :262-281
 const Array2D inverseWaveletTransform(const Array2D &transform, WaveletKernel kernel, int depth, Shape2D shape); // :321-342
 const Picture waveletTransform(const Picture &picture, WaveletKernel kernel, int depth);      // :1267-1279

@@ -6,6 +6,9 @@
 #include <string>
 
 #include "Arrays.h"
+#include "Picture.h"
+#include "Slices.h"
+#include "WaveletTransform.h"
 #include "DataUnit.h"
 #include "Utils.h"
 #include "VLC.h"
@@ -16,6 +19,42 @@ static int failures = 0;
 static std::string thrown(void (*f)()) { try { f(); } catch (const std::logic_error &e) { return e.what(); } return "<no exception>"; }
 
 int main() {
+  { // views, subbands, blocks (Arrays.h:17-50, WaveletTransform.cpp:428-476, Picture.cpp:231-271)
+    Array2D a(8, 16);
+    for (Index y = 0; y < 8; ++y) for (Index x = 0; x < 16; ++x) a[y][x] = (int)(100 * y + x);
+    const View2D v(a, Range(1, 8, 2), Range(4, 16, 4));
+    EXPECT(v.shape()[0] == 4 && v.shape()[1] == 3 && v.at(0, 0) == 104 && v.at(3, 2) == 712);
+    const BlockVector bands = split_into_subbands(a, 2);
+    EXPECT(bands.size() == 7 && bands[0].shape()[0] == 2 && bands[0].shape()[1] == 4);
+    EXPECT(bands[0][1][1] == 404);                      // LL: rows / columns 0 mod 4
+    EXPECT(bands[1][0][0] == 2 && bands[2][0][0] == 200 && bands[3][0][0] == 202);   // level 1: HL, LH, HH at stride 4, phase 2
+    EXPECT(bands[4][0][0] == 1 && bands[5][0][0] == 100 && bands[6][3][7] == 715);   // level 2: stride 2, phase 1
+    const Array2D back = merge_subbands(bands);
+    bool same = back.shape()[0] == 8 && back.shape()[1] == 16;
+    for (Index y = 0; same && y < 8; ++y) for (Index x = 0; x < 16; ++x) same = same && back[y][x] == a[y][x];
+    EXPECT(same);
+    Picture pic(PictureFormat(8, 16, CF422));
+    pic.y(a);
+    const PictureArray blocks = split_into_blocks(pic, 2, 4);
+    EXPECT(blocks.shape()[0] == 2 && blocks.shape()[1] == 4 && blocks[1][3].y().shape()[1] == 4 && blocks[1][3].c1().shape()[1] == 2);
+    EXPECT(blocks[1][3].y()[0][0] == 412);
+    const Picture merged = merge_blocks(blocks);
+    EXPECT(merged.y()[7][15] == 715 && merged.format().chromaWidth() == 8);
+    // component_slice_bytes, Slices.cpp:97-119: bits through the last non-zero coefficient in subband order
+    Array2D sl(4, 4);
+    EXPECT(component_slice_bytes(sl, 1, 1) == 0);
+    sl[0][0] = 1;                                        // LL first: one 4-bit code
+    EXPECT(component_slice_bytes(sl, 1, 1) == 1 && component_slice_bytes(sl, 1, 3) == 3);
+    sl[3][3] = -2;                                       // HH last: 4 LL + 4 HL + 4 LH + 3 HH zeros ... then 4 bits
+    EXPECT(luma_slice_bits(sl, 1) == 4 + 3 + 4 + 4 + 3 + 4);
+    EXPECT(component_slice_bytes(sl, 1, 2) == 4);
+    EXPECT(thrown([] { Array2D big(16, 32); for (std::size_t i = 0; i < big.num_elements(); ++i) big.data()[i] = 30000; component_slice_bytes(big, 2, 1); }) ==
+           "Slice scalar is too small, consider using a larger slice scalar.");
+    // slice_bytes(v, h, ...), Slices.cpp:18-26: 1000 bytes over 3 x 2 slices
+    int sum = 0;
+    for (int vv = 0; vv < 3; ++vv) for (int h = 0; h < 2; ++h) sum += slice_bytes(vv, h, 3, 2, 1000, 6);
+    EXPECT(sum == 1000 && slice_bytes(0, 0, 3, 2, 1000, 6) == 166 && slice_bytes(2, 1, 3, 2, 1000, 6) == 167);
+  }
   { // tests/Arrays.cpp:6-16
     Array2D a(3, 7);
     EXPECT(a.shape()[0] == 3 && a.shape()[1] == 7 && a.num_elements() == 21);
