@@ -101,3 +101,62 @@ def test_store16_escapes_both_directions(variants, oracle):
             _check(variants, oracle, raw, w, h, "422", 16, "LeGall", depth, u, a, q=q, scalar=8)
             break
     assert hit is not None, "no quantiser index puts quantised values between 32768 and 65534"
+
+
+def test_pipelined_picture_calls(variants, oracle):
+    """vc2hip_encode_picture_begin / _end and the decode pair (two pictures in flight, pinned staging): the bytes of the
+    synchronous calls, in order; a third _begin before an _end is refused"""
+    hip = variants["default"]
+    w, h, depth, n = 1024, 64, 3, 5
+    raw = synth(w, h, "422", 10, 75, frames=n)
+    rb = len(raw) // n
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", depth, 1, 2, q=5, scalar=2)
+    raws = [raw[k * rb:(k + 1) * rb] for k in range(n)]
+    pays = hip.encode_pictures_pipelined(raws, fmt, cp)
+    assert pays == [hip.encode_picture_hq(r, fmt, cp)[0] for r in raws]
+    assert hip.decode_pictures_pipelined(pays, fmt, cp) == [hip.decode_picture(p, fmt, cp) for p in pays]
+
+
+@pytest.mark.parametrize("scalar", [60, 120, 200])
+def test_long_slices_large_scalar(variants, oracle, scalar):
+    """slice size scalars beyond what four LDS slice images hold (> 40): two, one wavefront per workgroup, then the
+    images in global memory; VBR and CBR.  The reference takes any scalar (Slices.cpp:97-119)."""
+    hip = variants["default"]
+    w, h, depth = 256, 64, 2
+    raw = noise_frame(w, h, "422", 10, seed=81)
+    p = make_params(w, h, "422", 10, "LeGall", depth, 2, 4, q=0, scalar=scalar)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "LeGall", depth, 2, 4, q=0, scalar=scalar)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec == raw
+    raw = synth(w, h, "422", 10, 83)
+    s = cp.y_slices * cp.x_slices * (4 + 3 * scalar * 2)   # CBR: two units per component and slice
+    p = make_params(w, h, "422", 10, "LeGall", depth, 2, 4, mode="HQ_CBR", s=s, scalar=scalar)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "LeGall", depth, 2, 4, mode="HQ_CBR", s=s, scalar=scalar)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+@pytest.mark.parametrize("kernel,mode", [("DD97", "HQ_ConstQ"), ("Fidelity", "HQ_ConstQ"), ("LeGall", "HQ_CBR")])
+def test_one_slice_per_picture(variants, oracle, kernel, mode):
+    """the largest slice the reference admits: the whole picture (WaveletTransform.cpp:116-136).  No LDS tile holds it:
+    the transform runs on whole planes in HBM, the CBR search reads the slice from the store in every trial, the slice
+    coder keeps its image in global memory (components of ~50 KB need a scalar beyond 200)."""
+    hip = variants["default"]
+    w, h, depth = 512, 256, 2
+    raw = synth(w, h, "444", 10, 82)
+    u, a = h >> depth, w >> depth          # one slice (4:4:4: with subsampled chroma the reference wants two across)
+    kw = dict(q=20, scalar=1000) if mode == "HQ_ConstQ" else dict(mode="HQ_CBR", s=300000, scalar=1000)
+    p = make_params(w, h, "444", 10, kernel, depth, u, a, **kw)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "444", 10, kernel, depth, u, a, **kw)
+    assert cp.y_slices == 1 and cp.x_slices == 1
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec

@@ -20,6 +20,7 @@ int vc2_halo_y(int kernel);
 void vc2_upload_vlc_lut(hipStream_t s);
 bool vc2_slice_index_supported(int prefix, int scalar);
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
+int vc2_pack_image_mode(int prefix, int scalar);
 void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s);
 bool vc2_fast_level_applicable(LevelParams &p);
 int vc2_launch_forward_fast(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, hipStream_t s);
@@ -28,6 +29,12 @@ void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s);
 size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool inverse, bool store16, int n_pictures);
 int vc2_launch_forward_stream(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s);
 int vc2_launch_inverse_stream(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s);
+int vc2_launch_plane_transform(Launcher &L, int kernel, int32_t *plane, long long plane_stride, int ph, int pw, int depth, bool inverse,
+                               int n, hipStream_t s);
+void vc2_launch_plane_ingest(Launcher &L, const void *raw, long long raw_stride, int pic_h, int pic_w, int word_bytes, int bit_depth,
+                             int32_t *plane, long long plane_stride, int ph, int pw, int n, hipStream_t s);
+void vc2_launch_plane_emit(Launcher &L, const int32_t *plane, long long plane_stride, int pw, void *raw, long long raw_stride, int pic_h,
+                           int pic_w, int word_bytes, int bit_depth, int n, hipStream_t s);
 void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s);
 void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 
@@ -745,6 +752,73 @@ static bool use_store16(const vc2hip_ctx *c, const Geom &g, int kernel) {
   return true;
 }
 
+// A slice that does not fit the LDS tile of any level kernel (the reference admits slices up to the whole picture):
+// the transform then runs on whole planes in HBM (vc2hip_dwt_plane.hip), the store is filled / read by the layout
+// conversion kernels.
+static bool needs_plane_path(const vc2hip_ctx *c, const Geom &g, int kernel) {
+  for (int level = 0; level < g.depth; ++level) {
+    LevelParams p;
+    memset(&p, 0, sizeof p);
+    fill_level(p, g, level, kernel, nullptr);
+    LevelParams pf = p;
+    if (!c->force_generic && vc2_fast_level_applicable(pf)) continue;
+    if (vc2_level_lds_bytes(kernel, p) > 160 * 1024) return true;
+  }
+  return false;
+}
+static size_t plane_elems(const Geom &g) {
+  size_t e = 0;
+  for (int k = 0; k < 3; ++k) e += (size_t)g.c[k].ph * g.c[k].pw;
+  return e;
+}
+// raw pictures -> store (forward), general geometry
+static int plane_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const void *const src[3], const long long ss[3],
+                         const vc2hip_picture_format *f, int32_t *d_store) {
+  int32_t *d_plane;
+  NEED(c, B_PLANE, plane_elems(g) * n * 4, d_plane);
+  size_t off = 0;
+  for (int k = 0; k < 3; ++k) {
+    const CompGeom &cg = g.c[k];
+    if (!cg.ph) continue;
+    const long long ps = (long long)cg.ph * cg.pw;
+    int32_t *pl = d_plane + off;
+    off += (size_t)ps * n;
+    vc2_launch_plane_ingest(c->L, src[k], ss[k], cg.h, cg.w, f->word_bytes, f->bit_depth, pl, ps, cg.ph, cg.pw, n, c->stream);
+    const int rc = vc2_launch_plane_transform(c->L, kernel, pl, ps, cg.ph, cg.pw, g.depth, false, n, c->stream);
+    if (rc) return set_err(c, rc, "invalid wavelet kernel");
+    for (int p = 0; p < n; ++p)
+      vc2_launch_plane_to_store(c->L, pl + (size_t)p * ps, cg.ph, cg.pw, g.depth, g.ys, g.xs,
+                                d_store + (size_t)p * g.ys * g.xs * g.slice_coefs, g.slice_coefs, cg.coef_off, c->stream);
+  }
+  return VC2HIP_OK;
+}
+// store (quantised) -> raw pictures (inverse), general geometry
+static int plane_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, const int32_t *d_store, const int32_t *d_q, const int32_t *qm,
+                         void *const dst[3], const long long ds[3], const vc2hip_picture_format *f) {
+  int32_t *d_plane;
+  int *d_qm;
+  NEED(c, B_PLANE, plane_elems(g) * n * 4, d_plane);
+  NEED(c, B_QM, 256, d_qm);
+  HIPCHK(c, hipMemcpyAsync(d_qm, qm, (size_t)(3 * g.depth + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // qm lives on the caller's stack
+  const int ns = g.ys * g.xs;
+  size_t off = 0;
+  for (int k = 0; k < 3; ++k) {
+    const CompGeom &cg = g.c[k];
+    if (!cg.ph) continue;
+    const long long ps = (long long)cg.ph * cg.pw;
+    int32_t *pl = d_plane + off;
+    off += (size_t)ps * n;
+    for (int p = 0; p < n; ++p)
+      vc2_launch_store_to_plane(c->L, d_store + (size_t)p * ns * g.slice_coefs, g.slice_coefs, cg.coef_off, pl + (size_t)p * ps, cg.ph,
+                                cg.pw, g.depth, g.ys, g.xs, d_q + (size_t)p * ns, d_qm, 1, c->d_err, c->stream);
+    const int rc = vc2_launch_plane_transform(c->L, kernel, pl, ps, cg.ph, cg.pw, g.depth, true, n, c->stream);
+    if (rc) return set_err(c, rc, "invalid wavelet kernel");
+    vc2_launch_plane_emit(c->L, pl, ps, cg.pw, dst[k], ds[k], cg.h, cg.w, f->word_bytes, f->bit_depth, n, c->stream);
+  }
+  return VC2HIP_OK;
+}
+
 static void fill_comp_arrays(const Geom &g, int n[3], int off[3], int n0[3]) {
   for (int c = 0; c < 3; ++c) { n[c] = g.c[c].sh * g.c[c].sw; off[c] = g.c[c].coef_off; n0[c] = g.c[c].n0 ? g.c[c].n0 : 1; }
 }
@@ -765,15 +839,14 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const void *store, cons
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm ? qm[b] : 0;
   p.err = c->d_err; p.quantise = quantise;
   p.payload = d_payload; p.payload_stride = stride;
-  if (vc2_pack_lds_bytes(prefix, scalar) > 144 * 1024)
-    return set_err(c, VC2HIP_EINVAL, "slice prefix / size scalar too large for the slice coder (four slice images of prefix + 4 + 765 * scalar bytes must fit in LDS)");
-  if (d_cbr_bytes) {
+  const bool gimg = vc2_pack_image_mode(prefix, scalar) < 0; // slice images in the slots (global memory): CBR goes through slots too
+  if (d_cbr_bytes && !gimg) {
     p.cbr_bytes = d_cbr_bytes; p.cbr_offsets = d_cbr_offs;
     vc2_launch_pack(c->L, p, n, c->stream);
     vc2_launch_fill_u64(c->L, d_lens, cbr_total, (size_t)n, c->stream);
     return VC2HIP_OK;
   }
-  if (!c->two_pass_vbr) { // single pass: slice offsets by decoupled look-back inside the pack kernel
+  if (!c->two_pass_vbr && !gimg && !d_cbr_bytes) { // single pass: slice offsets by decoupled look-back inside the pack kernel
     const long long lb_stride = (long long)((ns + 3) / 4) + 8;
     unsigned long long *lb;
     NEED(c, B_SIZES, (size_t)n * lb_stride * 8, lb);
@@ -783,14 +856,16 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const void *store, cons
     vc2_launch_pack(c->L, p, n, c->stream);
     return VC2HIP_OK;
   }
-  const int slot = (int)((max_slice_bytes(prefix, scalar) + 15) & ~(size_t)15);
+  // (images kept in the slots themselves: room for the two guard words of an image)
+  const int slot = (int)((max_slice_bytes(prefix, scalar) + (gimg ? 8 : 0) + 15) & ~(size_t)15);
   uint8_t *slots; uint32_t *sizes, *offs;
   NEED(c, B_SLOTS, (size_t)n * ns * slot, slots);
   NEED(c, B_SIZES, (size_t)n * ns * 4, sizes);
   NEED(c, B_OFFS, (size_t)n * ns * 4, offs);
   p.slots = slots; p.slot_bytes = slot; p.sizes = sizes;
+  if (d_cbr_bytes) { p.cbr_bytes = d_cbr_bytes; p.cbr_offsets = d_cbr_offs; }
   vc2_launch_pack(c->L, p, n, c->stream);
-  vc2_launch_scan_sizes(c->L, sizes, offs, d_lens, ns, n, c->stream);
+  vc2_launch_scan_sizes(c->L, sizes, offs, d_lens, ns, n, c->stream); // (CBR: the same offsets as d_cbr_offs; sizes = budgets)
   vc2_launch_compact(c->L, slots, slot, sizes, offs, d_payload, stride, ns, n, c->stream);
   return VC2HIP_OK;
 }
@@ -1067,7 +1142,6 @@ extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_
   Geom g;
   int rc = geom_from_abi(g, ga);
   if (rc) return set_err(c, rc);
-  if ((size_t)g.slice_coefs * 4 + 2048 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
   const int ns = g.ys * g.xs;
   int32_t *d_store, *d_q, *d_sb;
   NEED(c, B_STORE, (size_t)ns * g.slice_coefs * 4, d_store);
@@ -1303,7 +1377,9 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
   ll_layout(g, n, d_ll, s16 ? 2 : 4, d_llw, ll);
   const void *src[3]; long long ss[3];
   raw_planes(f, d_raw, src, ss);
-  if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll, s16, d_storew))) return rc;
+  if (cp->mode != VC2HIP_LD && needs_plane_path(c, g, cp->kernel)) {
+    if ((rc = plane_forward(c, g, cp->kernel, n, src, ss, f, d_store))) return rc;
+  } else if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll, s16, d_storew))) return rc;
   int32_t *d_cb = nullptr; uint32_t *d_co = nullptr; uint64_t total = 0;
   if (cp->mode == VC2HIP_LD) {
     // EncodeStream.cpp:509-512 (slice_bytes with scalar 1), :141-245, :195-244
@@ -1327,8 +1403,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     return VC2HIP_OK;
   }
   if (cp->mode == VC2HIP_HQ_CBR) {
-    if ((size_t)g.slice_coefs * 4 + 2048 > 160 * 1024) return set_err(c, VC2HIP_EINVAL, "slice too large for the CBR search kernel");
-    const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
+      const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
     if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
       std::vector<int32_t> sb(ns);
       vc2hip_slice_bytes(g.ys, g.xs, cp->compressed_bytes, cp->scalar, sb.data());
@@ -1429,6 +1504,7 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
   const void *dstc[3]; long long ds[3];
   raw_planes(f, d_raw_out, dstc, ds);
   void *dst[3] = {(void *)dstc[0], (void *)dstc[1], (void *)dstc[2]};
+  if (!ld && needs_plane_path(c, g, cp->kernel)) return plane_inverse(c, g, cp->kernel, n, d_store, d_q, qm, dst, ds, f);
   return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew);
 }
 

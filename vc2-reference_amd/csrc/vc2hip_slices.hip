@@ -431,9 +431,13 @@ __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, in
 
 // W lanes work on one slice: 64 (a wavefront per slice, any geometry) or, for small slices, 32 / 16 with two / four
 // slices per wavefront, so that a slice of e.g. 128 + 2 x 64 coefficients (1080p, -u 2 -a 4) still fills its lanes.
-template <int W, bool MID, class ST>
+// GIMG: the slice images live in the slots in global memory instead of LDS (slices too long for LDS: slice size scalars
+// beyond ~160; VBR and CBR then both go through slots + compaction) -- the same code on flat atomics, an order slower, for
+// command lines the reference accepts and nobody uses.
+template <int W, bool MID, class ST, bool GIMG = false>
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   constexpr int S = 64 / W;
+  const int nwv = (int)blockDim.x >> 6; // wavefronts per workgroup: 4, fewer when four slice images do not fit in LDS
   extern __shared__ unsigned lds_u[];
   __shared__ unsigned long long s_base; // byte offset of this tile inside the picture payload
   __shared__ int s_tile, s_tot[4];
@@ -446,17 +450,19 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     __syncthreads();
     tile = s_tile;
   }
-  const int slice = (tile * 4 + wave) * S + seg;
+  const int slice = (tile * nwv + wave) * S + seg;
   const int img_words = (p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2;
-  unsigned *img = lds_u + (wave * S + seg) * img_words;
-  unsigned *lut = lds_u + 4 * S * img_words;
+  const bool active = slice < p.n_slices;
+  unsigned *img = GIMG ? (unsigned *)(p.slots + ((size_t)pic * p.n_slices + (active ? slice : 0)) * p.slot_bytes)
+                       : lds_u + (wave * S + seg) * img_words;
+  unsigned *lut = lds_u + (GIMG ? 0 : nwv * S * img_words);
   unsigned char *band_y = (unsigned char *)(lut + VLC_LUT_N), *band_c = band_y + 512;
   uint4 *qtab = (uint4 *)(band_c + 256) + (wave * S + seg) * 32;
   // slices of up to 2048 coefficients per component (more than one round of 512): the same tables, longer (launcher: big_lut)
-  unsigned char *big_y = (unsigned char *)((uint4 *)(band_c + 256) + 4 * S * 32), *big_c = big_y + 2048;
-  const bool active = slice < p.n_slices;
+  unsigned char *big_y = (unsigned char *)((uint4 *)(band_c + 256) + nwv * S * 32), *big_c = big_y + 2048;
   const bool fast = p.comp_n[0] <= 8 * W && p.comp_n[1] <= 4 * W && p.comp_n[1] == p.comp_n[2];
-  for (int i = sl; i < img_words; i += W) img[i] = 0;
+  if (!GIMG || active) for (int i = sl; i < img_words; i += W) img[i] = 0;
+  if (GIMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zeros are in place before the first atomic OR
   build_vlc_lut(lut);
   if (fast && p.quantise) {
     const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
@@ -632,7 +638,15 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     }
     return;
   }
-  if (p.cbr_bytes) {
+  if (GIMG) { // the image is the slot: big-endian words to stream order in place, then the size
+    if (bad_cbr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = sl; i < (total + 3) / 4; i += W) {
+      const unsigned w = __hip_atomic_load(&img[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&img[i], __builtin_bswap32(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (sl == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
+  } else if (p.cbr_bytes) {
     if (bad_cbr) return;
     uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
     for (int i = sl; i < total; i += W) dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3)));
@@ -644,9 +658,16 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
 }
 
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
-static size_t pack_lds(int prefix, int scalar, int slices_per_wave, bool big_lut = false) {
-  const size_t img_words = ((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2;
-  return 4 * slices_per_wave * img_words * 4 + VLC_LUT_N * 4 + 768 + 4 * (size_t)slices_per_wave * 32 * 16 + (big_lut ? 4096 : 0);
+static size_t pack_lds(int prefix, int scalar, int slices_per_wave, bool big_lut = false, int waves = 4, bool gimg = false) {
+  const size_t img_words = gimg ? 0 : ((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2;
+  return waves * slices_per_wave * img_words * 4 + VLC_LUT_N * 4 + 768 + waves * (size_t)slices_per_wave * 32 * 16 + (big_lut ? 4096 : 0);
+}
+// 0: four slice images fit in LDS; else the wavefronts per workgroup to use (2, 1), or -1: images in global memory
+int vc2_pack_image_mode(int prefix, int scalar) {
+  if (pack_lds(prefix, scalar, 1) <= 144 * 1024) return 0;
+  if (pack_lds(prefix, scalar, 1, false, 2) <= 144 * 1024) return 2;
+  if (pack_lds(prefix, scalar, 1, false, 1) <= 144 * 1024) return 1;
+  return -1;
 }
 size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
@@ -667,6 +688,23 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
   const bool one_round = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && same_c;
   p.big_lut = W == 64 && !one_round && same_c && p.comp_n[0] <= 2048 && p.comp_n[1] <= 2048 && 3 * p.depth + 1 <= 32 &&
               pack_lds(p.prefix, p.scalar, 1, true) <= 144 * 1024;
+  const int mode = vc2_pack_image_mode(p.prefix, p.scalar);
+  if (mode != 0) { // long slices: fewer wavefronts per workgroup, or the images in the slots in global memory
+    const int waves = mode < 0 ? 4 : mode;
+    const size_t lds = pack_lds(p.prefix, p.scalar, 1, false, waves, mode < 0);
+    const int tiles = (p.n_slices + waves - 1) / waves;
+    vc2_prof_begin(L, "hq_pack", s);
+#define VC2_PACK_LONG(TT, GG)                                                                         \
+  do {                                                                                                \
+    vc2_allow_lds((const void *)k_hq_pack<64, false, TT, GG>, 144 * 1024);                            \
+    VC2_LAUNCH(L, (k_hq_pack<64, false, TT, GG>), dim3(tiles, n_pictures), dim3(64 * waves), lds, s, p); \
+  } while (0)
+    if (mode < 0) { if (p.store16) VC2_PACK_LONG(int16_t, true); else VC2_PACK_LONG(int32_t, true); }
+    else { if (p.store16) VC2_PACK_LONG(int16_t, false); else VC2_PACK_LONG(int32_t, false); }
+#undef VC2_PACK_LONG
+    vc2_prof_end(L, s);
+    return;
+  }
   const size_t lds = pack_lds(p.prefix, p.scalar, S, p.big_lut);
   const int tiles = (p.n_slices + 4 * S - 1) / (4 * S);
   vc2_prof_begin(L, "hq_pack", s);
@@ -812,7 +850,8 @@ __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, in
 // ------------------------------------------------------------------------------------------
 // HQ_CBR quantiser search: one wavefront per slice, slice coefficients staged in LDS
 // ------------------------------------------------------------------------------------------
-template <class ST>
+// GLOBAL: the slice is too large to be staged in LDS (more than ~40 K coefficients): every trial reads it from the store
+template <class ST, bool GLOBAL = false>
 __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6; // 1..4 wavefronts per workgroup
@@ -821,8 +860,8 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   // table, the quantiser constants of every subband at the trial index from a per-wavefront table, both in LDS --
   // indexing the kernel-argument matrix and the constant-memory factor tables per lane costs several dependent
   // memory operations per coefficient.
-  const bool fast = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32;
-  unsigned char *band_y = (unsigned char *)(lds_i + wpw * p.slice_coefs), *band_c = band_y + 512;
+  const bool fast = !GLOBAL && p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32;
+  unsigned char *band_y = (unsigned char *)(lds_i + (GLOBAL ? 0 : wpw * p.slice_coefs)), *band_c = band_y + 512;
   uint4 *qtab = (uint4 *)(band_c + 256) + wave * 32;
   if (fast) {
     const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
@@ -832,11 +871,15 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   }
   __syncthreads();
   if (slice >= p.n_slices) return; // no workgroup barriers below
-  int *co = lds_i + wave * p.slice_coefs;
-  {
-    const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-    const ST *rec = (const ST *)p.store + rec_at;
-    const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
+  int *co = lds_i + (GLOBAL ? 0 : wave * p.slice_coefs);
+  const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  const ST *rec = (const ST *)p.store + rec_at;
+  const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
+  auto coef = [&](int i) -> int { // coefficient i of the slice record
+    if constexpr (GLOBAL) return St<ST>::load1(rec + i, recw + i);
+    else return co[i];
+  };
+  if constexpr (!GLOBAL) {
     if ((p.slice_coefs & 7) == 0 && (rec_at & 7) == 0) {
       for (int i = lane * 8; i < p.slice_coefs; i += 512) {
         int e[8];
@@ -886,8 +929,12 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
       need += comp_bytes(__shfl(cnt, 0), bad) + comp_bytes(__shfl(cnt, 32), bad);
       return need;
     }
-    for (int c = 0; c < 3; ++c)
-      need += comp_bytes(component_bits_lds(co + p.comp_off[c], p.comp_n[c], p.comp_n0[c], tq, p.qmatrix, lane, p.err), bad);
+    for (int c = 0; c < 3; ++c) {
+      if constexpr (GLOBAL)
+        need += comp_bytes(component_bits<true, false>([&](int j) { return coef(p.comp_off[c] + j); }, p.comp_n[c], p.comp_n0[c], tq,
+                                                       p.qmatrix, lane, nullptr, 0, p.err), bad);
+      else need += comp_bytes(component_bits_lds(co + p.comp_off[c], p.comp_n[c], p.comp_n0[c], tq, p.qmatrix, lane, p.err), bad);
+    }
     return need;
   };
   // luma-only sum of squared reconstruction error (int product, 64-bit sum)
@@ -915,7 +962,7 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
     for (int j = lane; j < p.comp_n[0]; j += 64) {
       const int aq = max(tq - p.qmatrix[band_of_index(j, p.comp_n0[0])], 0);
       if (aq > 119) { bad = true; continue; }
-      const int v = src[j];
+      const int v = GLOBAL ? coef(p.comp_off[0] + j) : src[j];
       const int d = (int)((unsigned)v - (unsigned)scale_dev(quant_dev(v, aq), aq));
       acc += (int)((unsigned)d * (unsigned)d);
     }
@@ -958,8 +1005,16 @@ int vc2_waves_for_lds(size_t per_wave) {
 }
 void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
   const size_t per_wave = (size_t)p.slice_coefs * 4 + 32 * 16, tables = 768; // + the wavefront's quantiser table; + band tables
-  const int wpw = std::max(1, std::min(4, (int)((160 * 1024 - tables) / per_wave)));
   vc2_prof_begin(L, "cbr_search", s);
+  if (per_wave + tables > 160 * 1024) { // the slice does not fit in LDS: the search reads it from the store in every trial
+    const int wpw = 4;
+    const size_t lds = tables + wpw * 32 * 16;
+    if (p.store16) VC2_LAUNCH(L, (k_cbr_search<int16_t, true>), dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), lds, s, p);
+    else VC2_LAUNCH(L, (k_cbr_search<int32_t, true>), dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), lds, s, p);
+    vc2_prof_end(L, s);
+    return;
+  }
+  const int wpw = std::max(1, std::min(4, (int)((160 * 1024 - tables) / per_wave)));
   if (p.store16) {
     vc2_allow_lds((const void *)k_cbr_search<int16_t>, 160 * 1024);
     VC2_LAUNCH(L, k_cbr_search<int16_t>, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);

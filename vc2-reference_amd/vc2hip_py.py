@@ -51,6 +51,8 @@ EXPORTS = [
     "vc2hip_max_payload_bytes", "vc2hip_encode_picture_hq", "vc2hip_decode_picture_hq",
     "vc2hip_decode_picture_ld", "vc2hip_encode_batch_dev", "vc2hip_decode_batch_dev",
     "vc2hip_profile_enable", "vc2hip_profile_count", "vc2hip_profile_get", "vc2hip_profile_reset",
+    "vc2hip_host_alloc", "vc2hip_host_free", "vc2hip_encode_picture_begin", "vc2hip_encode_picture_end",
+    "vc2hip_decode_picture_begin", "vc2hip_decode_picture_end",
 ]
 
 
@@ -111,6 +113,16 @@ def load_library():
     lib.vc2hip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_double)]
     lib.vc2hip_profile_reset.argtypes = [vp]
+    lib.vc2hip_host_alloc.argtypes = [C.c_size_t]
+    lib.vc2hip_host_alloc.restype = vp
+    lib.vc2hip_host_free.argtypes = [vp]
+    lib.vc2hip_host_free.restype = None
+    lib.vc2hip_encode_picture_begin.argtypes = [vp, vp, C.POINTER(PictureFormat), C.POINTER(CodingParams), vp, C.c_size_t, vp,
+                                                C.POINTER(C.c_int)]
+    lib.vc2hip_encode_picture_end.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+    lib.vc2hip_decode_picture_begin.argtypes = [vp, vp, C.c_size_t, C.POINTER(PictureFormat), C.POINTER(CodingParams), vp,
+                                                C.POINTER(C.c_int)]
+    lib.vc2hip_decode_picture_end.argtypes = [vp, C.c_int]
     return lib
 
 
@@ -318,6 +330,64 @@ class Vc2Hip:
     def decode_batch_dev(self, d_payload, stride, d_lens, n, fmt, cp, d_raw_out):
         self._chk(self.lib.vc2hip_decode_batch_dev(self.h, d_payload, stride, d_lens, n, C.byref(fmt),
                                                    C.byref(cp), d_raw_out))
+
+    def encode_pictures_pipelined(self, raws, fmt, cp):
+        """pictures in host memory through the pipelined calls (pinned staging, two in flight); returns the payloads"""
+        rb = self.raw_picture_bytes(fmt)
+        cap = self.max_payload_bytes(fmt, cp) + 64
+        n_slots = 2
+        ins = [self.lib.vc2hip_host_alloc(rb + 64) for _ in range(n_slots)]
+        outs = [self.lib.vc2hip_host_alloc(cap) for _ in range(n_slots)]
+        res, open_ = [], []
+        try:
+            def finish():
+                slot, ticket = open_.pop(0)
+                n = C.c_size_t()
+                self._chk(self.lib.vc2hip_encode_picture_end(self.h, ticket, C.byref(n)))
+                res.append(C.string_at(outs[slot], n.value))
+            for k, raw in enumerate(raws):
+                if len(open_) == n_slots:
+                    finish()
+                slot = k % n_slots
+                C.memmove(ins[slot], raw, rb)
+                t = C.c_int()
+                self._chk(self.lib.vc2hip_encode_picture_begin(self.h, ins[slot], C.byref(fmt), C.byref(cp), outs[slot], cap, None,
+                                                               C.byref(t)))
+                open_.append((slot, t.value))
+            while open_:
+                finish()
+        finally:
+            for p in ins + outs:
+                self.lib.vc2hip_host_free(p)
+        return res
+
+    def decode_pictures_pipelined(self, payloads, fmt, cp):
+        rb = self.raw_picture_bytes(fmt)
+        cap = max(len(p) for p in payloads) + 64
+        n_slots = 2
+        ins = [self.lib.vc2hip_host_alloc(cap) for _ in range(n_slots)]
+        outs = [self.lib.vc2hip_host_alloc(rb + 64) for _ in range(n_slots)]
+        res, open_ = [], []
+        try:
+            def finish():
+                slot, ticket = open_.pop(0)
+                self._chk(self.lib.vc2hip_decode_picture_end(self.h, ticket))
+                res.append(C.string_at(outs[slot], rb))
+            for k, pay in enumerate(payloads):
+                if len(open_) == n_slots:
+                    finish()
+                slot = k % n_slots
+                C.memmove(ins[slot], pay, len(pay))
+                t = C.c_int()
+                self._chk(self.lib.vc2hip_decode_picture_begin(self.h, ins[slot], len(pay), C.byref(fmt), C.byref(cp), outs[slot],
+                                                               C.byref(t)))
+                open_.append((slot, t.value))
+            while open_:
+                finish()
+        finally:
+            for p in ins + outs:
+                self.lib.vc2hip_host_free(p)
+        return res
 
     def set_streams(self, k):
         self._chk(self.lib.vc2hip_set_streams(self.h, k))
