@@ -466,9 +466,10 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   for (int i = lane; i < 120; i += 64) {
     const int qf = c_qst.qf[i], off = c_qst.off[i];
     qtab[i] = qf; qtab[120 + i] = off;
-    // largest magnitude for which |v| * factor + offset + 2 stays below 2^31 with both factors inside 24 bits (the
-    // full-rate multiply-add); beyond it the literal arithmetic
-    qtab[240 + i] = (qf > 0 && qf < (1 << 24)) ? (int)min((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf, 0xFFFFFFu) : -1;
+    // largest magnitude for which the five-instruction form below is exact: |v| and the factor inside 23 / 24 bits (the
+    // full-rate 24-bit multiplies) and the result (|v| * factor + offset + 2) >> 2 inside 23 bits; beyond it the literal
+    // arithmetic
+    qtab[240 + i] = (qf > 0 && qf < (1 << 24)) ? (int)min(((1u << 25) - (unsigned)off - 8u) / (unsigned)qf, 0x7FFFFFu) : -1;
   }
   wave_sync();
   constexpr int ACC = WT<K>::accuracy;
@@ -538,14 +539,15 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
       v[0] = (int)w.x; v[1] = (int)w.y; v[2] = (int)w.z; v[3] = (int)w.w;
     }
     if (p.dequant && !from_plane) {
-      unsigned mg[4], any = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { mg[k] = v[k] < 0 ? 0u - (unsigned)v[k] : (unsigned)v[k]; any |= mg[k]; }
-      if ((int)any >= 0 && (int)any <= ql[b]) { // inside the domain: (|v| * factor + offset + 2) >> 2
+      const int mx = max(max(v[0], v[1]), max(v[2], v[3])), mn = min(min(v[0], v[1]), min(v[2], v[3]));
+      if (mx <= ql[b] && mn >= -ql[b]) {
+        // scale(), Quantisation.cpp:86-95, inside its domain: sign(v) * ((|v| * factor + offset + 2) >> 2), 0 for 0.
+        // sg = sign(v) in {-1, 0, 1}; |v| = v * sg; the final product with sg restores the sign and zeroes the v = 0 case
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned t = mg[k] ? (__umul24(mg[k], (unsigned)qf[b]) + (unsigned)(qo[b] + 2)) >> 2 : 0u;
-          v[k] = v[k] < 0 ? (int)(0u - t) : (int)t;
+          const int sg = min(max(v[k], -1), 1);
+          const unsigned t = (__umul24((unsigned)__mul24(v[k], sg), (unsigned)qf[b]) + (unsigned)(qo[b] + 2)) >> 2;
+          v[k] = __mul24((int)t, sg);
         }
       } else {
 #pragma unroll
