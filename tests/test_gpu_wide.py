@@ -160,3 +160,40 @@ def test_one_slice_per_picture(variants, oracle, kernel, mode):
     payload, _ = hip.encode_picture_hq(raw, fmt, cp)
     assert payload == stream[-13 - len(payload):-13]
     assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+@pytest.mark.parametrize("amp,budget,scalar", [(40, 30000, 1), (600, 9000, 1), (600, 60000, 3), (30000, 3000, 1), (30000, 200000, 2),
+                                               (200000, 40000, 1), (5, 1400, 1)])
+def test_cbr_search_register_kernel_and_hand_back(variants, oracle, amp, budget, scalar):
+    """HQ_CBR quantiser indices over coefficient planes of every magnitude and budgets from starved to generous: the
+    register search inside its domain, and the slices it hands to the general kernel (coefficients beyond 16 bits, trial
+    indices above 79, length-byte overflow) -- all against the oracle's search (EncodeStream.cpp:73-125)."""
+    depth, ys, xs = 3, 8, 16
+    rng = np.random.default_rng(amp + budget)
+    ph, pw = 64, 512
+    def plane(h, w):
+        p = (rng.laplace(0, amp / 3.0, size=(h, w))).astype(np.int64)
+        p[rng.random((h, w)) < 0.5] = 0
+        return np.clip(p, -amp * 4, amp * 4).astype(np.int32)
+    ty, tu, tv = plane(ph, pw), plane(ph, pw // 2), plane(ph, pw // 2)
+    qm = oracle.quant_matrix(KERNELS["DD97"], depth)
+    sb = oracle.slice_bytes(ys, xs, budget, scalar)
+    try:
+        want = oracle.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
+    except Exception:               # the search leaves the quantiser table: an error on both sides
+        for name, hip in variants.items():
+            with pytest.raises(Exception):
+                hip.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
+        return
+    for name, hip in variants.items():
+        try:
+            got = hip.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
+        except Exception as e:      # a device error flag (index / length byte out of range): the general kernel raises the same
+            os.environ["VC2HIP_CBR_GENERAL"] = "1"
+            try:
+                with pytest.raises(type(e)):
+                    hip.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
+            finally:
+                del os.environ["VC2HIP_CBR_GENERAL"]
+            continue
+        assert np.array_equal(got, want), name

@@ -278,6 +278,10 @@ static void make_tables(QuantTables &t) {
       t.magic[q] = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
       t.shift[q] = l - 1;
     }
+    const double r = 4.0 / (double)(uint32_t)t.qf[q];
+    float up = (float)r;
+    if ((double)up < r) up = nextafterf(up, INFINITY);
+    t.inv4[q] = up;
   }
 }
 

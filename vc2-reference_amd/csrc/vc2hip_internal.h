@@ -73,6 +73,7 @@ struct QuantTables {
   // t = mulhi(magic, n); valid for every 32-bit n when qf > 0 (indices 0..115)
   uint32_t magic[120];
   int32_t shift[120];
+  float inv4[120]; // the smallest float >= 4 / qf (k_cbr_search_reg)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -183,7 +184,10 @@ struct CbrParams {
   int n_bands;
   int qmatrix[VC2_MAX_BANDS];
   unsigned *err;
+  int only_marked;            // set by the launcher: search only the slices whose index is VC2_CBR_MARK
+  float inv_scalar;           // set by the launcher
 };
+#define VC2_CBR_MARK 0x7FFFFFFF
 
 // ------------------------------------------------------------------------------------------
 // launchers (implemented in the kernel TUs)

@@ -855,7 +855,7 @@ template <class ST, bool GLOBAL = false>
 __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6; // 1..4 wavefronts per workgroup
-  const int slice = blockIdx.x * wpw + wave, pic = blockIdx.y;
+  int slice = blockIdx.x * wpw + wave; const int pic = blockIdx.y;
   // Common geometry (component <= 512 / 256 coefficients): the subband of every coefficient index comes from a byte
   // table, the quantiser constants of every subband at the trial index from a per-wavefront table, both in LDS --
   // indexing the kernel-argument matrix and the constant-memory factor tables per lane costs several dependent
@@ -870,7 +870,11 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
     for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
   }
   __syncthreads();
-  if (slice >= p.n_slices) return; // no workgroup barriers below
+  // no workgroup barriers below.  only_marked: the second pass behind k_cbr_search_reg -- a small grid walks the slices and
+  // searches those the register kernel handed back
+  const int slice_step = p.only_marked ? (int)gridDim.x * wpw : p.n_slices;
+  for (; slice < p.n_slices; slice += slice_step) {
+  if (p.only_marked && p.qidx[(size_t)pic * p.n_slices + slice] != VC2_CBR_MARK) continue;
   int *co = lds_i + (GLOBAL ? 0 : wave * p.slice_coefs);
   const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   const ST *rec = (const ST *)p.store + rec_at;
@@ -994,6 +998,156 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   }
   if (__any(bad) && lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX);
   if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
+  wave_lds_sync();
+  } // slices of this wavefront
+}
+
+// The same search with the slice in registers: a lane keeps its eight luma and eight chroma magnitudes as floats for all
+// trials, the quantiser is one multiply by a rounded-up 4 / factor, and the code length comes from the exponent of
+// 4|c| / factor + 1 -- no LDS staging, no integer multiplies, no count-leading-zeros.
+//   quant (Quantisation.cpp:69-76): q = floor(4|c| / f).  With r = the smallest float >= 4 / f and |c| < 2^15:
+//     fl(|c| * r) lies in [4|c|/f, 4|c|/f * (1 + 2^-22)); 4|c|/f is a multiple of 1/f, so no integer lies in between as
+//     long as 4|c| < 2^22 -> truncation gives q exactly.
+//   SignedVLC bits (VLC.cpp:78-85): 1 for q = 0, else 2 floor(log2(q + 1)) + 2, and floor(log2(q + 1)) =
+//     floor(log2(x + 1)) for any real x in [q, q + 1): E = exponent of fma(|c|, r, 1), exact while
+//     1.5 * 4|c| * 2^-23 + f * 2^-23 < 1 (f < 2^22: quantiser indices up to 79); bits = 2E + 1 + min(E, 1).
+// Anything outside that domain (a coefficient beyond 16 bits, a trial index above 79, a length byte overflow) hands the
+// slice to the general kernel through VC2_CBR_MARK: same answers, found the slow way.
+// Needs the common geometry (components of at most 512 / 256 coefficients, multiples of 8).
+template <class ST>
+__global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
+  __shared__ __attribute__((aligned(8))) unsigned char band_y[512], band_c[256];
+  __shared__ float s_inv[4][32];
+  __shared__ uint2 s_qfo[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  {
+    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
+    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
+    for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
+    for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+  }
+  __syncthreads();
+  if (slice >= p.n_slices) return; // no workgroup barriers below
+  const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  const ST *rec = (const ST *)p.store + rec_at;
+  const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
+  const int half = lane >> 5, cc = 1 + half; // lanes 0-31 U, lanes 32-63 V
+  const int jy = lane * 8, jc = (lane & 31) * 8;
+  const bool has_y = jy < p.comp_n[0], has_c = jc < p.comp_n[1];
+  float fy[8], fc[8];
+  int am[8], by[8], bc[8];
+  bool out = false;
+  {
+    int raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = 0;
+    if (has_y) St<ST>::load8(rec + p.comp_off[0] + jy, recw + p.comp_off[0] + jy, raw);
+    const uint2 b = *(const uint2 *)(band_y + (has_y ? jy : 0));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      am[k] = raw[k] < 0 ? -raw[k] : raw[k];
+      out |= (unsigned)am[k] > 32767u;
+      fy[k] = (float)am[k];
+      by[k] = (int)(((k < 4 ? b.x : b.y) >> (8 * (k & 3))) & 0xFFu);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = 0;
+    if (has_c) St<ST>::load8(rec + p.comp_off[cc] + jc, recw + p.comp_off[cc] + jc, raw);
+    const uint2 d = *(const uint2 *)(band_c + (has_c ? jc : 0));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int a = raw[k] < 0 ? -raw[k] : raw[k];
+      out |= (unsigned)a > 32767u;
+      fc[k] = (float)a;
+      bc[k] = (int)(((k < 4 ? d.x : d.y) >> (8 * (k & 3))) & 0xFFu);
+    }
+  }
+  const float *inv = s_inv[wave];
+  const uint2 *qfo = s_qfo[wave];
+  const int avail = p.slice_bytes[slice] - 4;
+  // (rounded-up 4 / factor), (factor, offset + 2) of every subband at index tq; false if an index leaves the domain
+  auto set_q = [&](int tq) -> bool {
+    bool ok = true;
+    wave_lds_sync(); // the previous trial's readers are done
+    if (lane < p.n_bands) {
+      const int aq = max(tq - p.qmatrix[lane], 0);
+      ok = aq <= 79;
+      const int a = min(aq, 79);
+      s_inv[wave][lane] = c_qs.inv4[a];
+      s_qfo[wave][lane] = make_uint2((unsigned)c_qs.qf[a], (unsigned)c_qs.off[a] + 2u);
+    }
+    wave_lds_sync();
+    return !__any(!ok);
+  };
+  auto bits8 = [&](const float (&f)[8], const int (&b)[8], bool has, int &sum, int &last_end) {
+    sum = 0; last_end = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float y = __builtin_fmaf(f[k], inv[b[k]], 1.0f);
+      const int E = (int)(__float_as_uint(y) >> 23) - 127;
+      sum += 2 * E + min(E, 1) + 1;
+      last_end = E >= 1 ? sum : last_end;
+    }
+    if (!has) { sum = 0; last_end = 0; }
+  };
+  auto comp_bytes = [&](int count, bool &bad) -> int { // the same rounded-up reciprocal for the division by the size scalar
+    const int len = (int)((float)(((count + 7) >> 3) + p.scalar - 1) * p.inv_scalar);
+    bad |= len > 255;
+    return __mul24(len, p.scalar);
+  };
+  auto need_bytes = [&](int tq, bool &bad) -> int {
+    if (!set_q(tq)) bad = true;
+    int sum, last_end;
+    bits8(fy, by, has_y, sum, last_end);
+    int incl = wave_incl_scan(sum, lane);
+    int need = comp_bytes(wave_max(last_end ? incl - sum + last_end : 0), bad);
+    bits8(fc, bc, has_c, sum, last_end);
+    incl = wave_incl_scan(sum, lane);
+    const int total_u = __shfl(incl, 31);
+    const int rel = incl - sum - (half ? total_u : 0);
+    const int cnt = seg_max<32>(last_end ? rel + last_end : 0);
+    need += comp_bytes(__shfl(cnt, 0), bad) + comp_bytes(__shfl(cnt, 32), bad);
+    return need;
+  };
+  // luma-only sum of squared reconstruction error (EncodeStream.cpp:73-125 through quant / scale, Quantisation.cpp:69-95)
+  auto yss = [&](int tq, bool &bad) -> long long {
+    if (!set_q(tq)) bad = true;
+    long long acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned q = (unsigned)(fy[k] * inv[by[k]]);
+      const uint2 t = qfo[by[k]];
+      const unsigned r = q ? (__umul24(q, t.x) + t.y) >> 2 : 0u;
+      const int d = am[k] - (int)r;
+      acc += (long long)__mul24(d, d);
+    }
+    return wave_sum64(acc);
+  };
+
+  bool bad = __any(out);
+  int trial = 63, q = 127, delta = 64;
+  while (delta > 0 && !bad) {
+    delta >>= 1;
+    const int need = need_bytes(trial, bad);
+    bad = __any(bad);
+    if (need <= avail) { if (trial < q) q = trial; trial -= delta; }
+    else trial += delta;
+  }
+  if (!bad) {
+    trial = q;
+    long long prev = yss(trial, bad), d;
+    do {
+      ++trial;
+      const long long cur = yss(trial, bad);
+      bad = __any(bad);
+      if (bad) break;
+      d = cur - prev;
+      prev = cur;
+    } while (d < 0);
+    q = trial - 1;
+  }
+  if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = __any(bad) ? VC2_CBR_MARK : q;
 }
 
 // wavefronts per workgroup so that their LDS (per_wave bytes each) fits: 4 down to 1; 0 if even one does not
@@ -1003,24 +1157,39 @@ int vc2_waves_for_lds(size_t per_wave) {
   const size_t w = (size_t)(160 * 1024) / per_wave;
   return (int)std::min<size_t>(4, w);
 }
-void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s) {
+void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_t s) {
+  CbrParams p = p0;
   const size_t per_wave = (size_t)p.slice_coefs * 4 + 32 * 16, tables = 768; // + the wavefront's quantiser table; + band tables
   vc2_prof_begin(L, "cbr_search", s);
+  p.only_marked = 0;
+  p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
+  if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
+  const char *e_gen = getenv("VC2HIP_CBR_GENERAL"); const bool no_reg = e_gen && e_gen[0] == '1'; // A/B and test switch: the general kernel only
+  const bool reg = !no_reg && p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32 &&
+                   p.comp_n[0] % 8 == 0 && p.comp_n[1] % 8 == 0 && (p.store_stride % 8) == 0 && (p.slice_coefs % 8) == 0 &&
+                   p.comp_off[1] % 8 == 0 && p.comp_off[2] % 8 == 0;
+  if (reg) { // the register kernel, then the general one over the slices it handed back (usually none: a small grid)
+    if (p.store16) VC2_LAUNCH(L, k_cbr_search_reg<int16_t>, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), 0, s, p);
+    else VC2_LAUNCH(L, k_cbr_search_reg<int32_t>, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), 0, s, p);
+    p.only_marked = 1;
+  }
   if (per_wave + tables > 160 * 1024) { // the slice does not fit in LDS: the search reads it from the store in every trial
     const int wpw = 4;
     const size_t lds = tables + wpw * 32 * 16;
-    if (p.store16) VC2_LAUNCH(L, (k_cbr_search<int16_t, true>), dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), lds, s, p);
-    else VC2_LAUNCH(L, (k_cbr_search<int32_t, true>), dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), lds, s, p);
+    const int gx = p.only_marked ? std::min((p.n_slices + wpw - 1) / wpw, 64) : (p.n_slices + wpw - 1) / wpw;
+    if (p.store16) VC2_LAUNCH(L, (k_cbr_search<int16_t, true>), dim3(gx, n_pictures), dim3(64 * wpw), lds, s, p);
+    else VC2_LAUNCH(L, (k_cbr_search<int32_t, true>), dim3(gx, n_pictures), dim3(64 * wpw), lds, s, p);
     vc2_prof_end(L, s);
     return;
   }
   const int wpw = std::max(1, std::min(4, (int)((160 * 1024 - tables) / per_wave)));
+  const int gx = p.only_marked ? std::min((p.n_slices + wpw - 1) / wpw, 64) : (p.n_slices + wpw - 1) / wpw;
   if (p.store16) {
     vc2_allow_lds((const void *)k_cbr_search<int16_t>, 160 * 1024);
-    VC2_LAUNCH(L, k_cbr_search<int16_t>, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
+    VC2_LAUNCH(L, k_cbr_search<int16_t>, dim3(gx, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
   } else {
     vc2_allow_lds((const void *)k_cbr_search<int32_t>, 160 * 1024);
-    VC2_LAUNCH(L, k_cbr_search<int32_t>, dim3((p.n_slices + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
+    VC2_LAUNCH(L, k_cbr_search<int32_t>, dim3(gx, n_pictures), dim3(64 * wpw), wpw * per_wave + tables, s, p);
   }
   vc2_prof_end(L, s);
 }
