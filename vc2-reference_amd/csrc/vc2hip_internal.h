@@ -186,6 +186,7 @@ struct CbrParams {
   unsigned *err;
   int only_marked;            // set by the launcher: search only the slices whose index is VC2_CBR_MARK
   float inv_scalar;           // set by the launcher
+  int qm_min;                 // set by the launcher: the smallest matrix entry
 };
 #define VC2_CBR_MARK 0x7FFFFFFF
 

@@ -872,9 +872,7 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   __syncthreads();
   // no workgroup barriers below.  only_marked: the second pass behind k_cbr_search_reg -- a small grid walks the slices and
   // searches those the register kernel handed back
-  const int slice_step = p.only_marked ? (int)gridDim.x * wpw : p.n_slices;
-  for (; slice < p.n_slices; slice += slice_step) {
-  if (p.only_marked && p.qidx[(size_t)pic * p.n_slices + slice] != VC2_CBR_MARK) continue;
+  auto search = [&](const int slice) {
   int *co = lds_i + (GLOBAL ? 0 : wave * p.slice_coefs);
   const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
   const ST *rec = (const ST *)p.store + rec_at;
@@ -999,7 +997,16 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   if (__any(bad) && lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX);
   if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = q;
   wave_lds_sync();
-  } // slices of this wavefront
+  }; // search(slice)
+  if (!p.only_marked) {
+    if (slice < p.n_slices) search(slice);
+    return;
+  }
+  // 64 indices per look: the wavefronts of the small grid stride over the picture's slices
+  for (int base = slice * 64; base < p.n_slices; base += (int)gridDim.x * wpw * 64) {
+    const bool marked = base + lane < p.n_slices && p.qidx[(size_t)pic * p.n_slices + base + lane] == VC2_CBR_MARK;
+    for (unsigned long long m = __ballot(marked); m; m &= m - 1) search(base + __ffsll((long long)m) - 1);
+  }
 }
 
 // The same search with the slice in registers: a lane keeps its eight luma and eight chroma magnitudes as floats for all
@@ -1017,8 +1024,8 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
 template <class ST>
 __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
   __shared__ __attribute__((aligned(8))) unsigned char band_y[512], band_c[256];
-  __shared__ float s_inv[4][32];
-  __shared__ uint2 s_qfo[4][32];
+  __shared__ uint4 s_tab[80];  // by quantiser index: (rounded-up 4 / factor as a float, factor, offset + 2, -)
+  __shared__ int s_qm[32];     // 16 x the quantisation matrix entry of every subband (byte offsets into s_tab)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
   {
@@ -1026,6 +1033,9 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
     for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
     for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+    if (threadIdx.x < 80)
+      s_tab[threadIdx.x] = make_uint4(__float_as_uint(c_qs.inv4[threadIdx.x]), (unsigned)c_qs.qf[threadIdx.x], (unsigned)c_qs.off[threadIdx.x] + 2u, 0u);
+    if (threadIdx.x < 32) s_qm[threadIdx.x] = threadIdx.x < p.n_bands ? 16 * p.qmatrix[threadIdx.x] : 0;
   }
   __syncthreads();
   if (slice >= p.n_slices) return; // no workgroup barriers below
@@ -1035,8 +1045,8 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
   const int half = lane >> 5, cc = 1 + half; // lanes 0-31 U, lanes 32-63 V
   const int jy = lane * 8, jc = (lane & 31) * 8;
   const bool has_y = jy < p.comp_n[0], has_c = jc < p.comp_n[1];
-  float fy[8], fc[8];
-  int am[8], by[8], bc[8];
+  float fy[8], fc[8]; // |coefficient|
+  int my[8], mc[8];   // 16 x the matrix entry of its subband: table offset of a trial tq = clamp(16 tq - m, 0, 16 * 79)
   bool out = false;
   {
     int raw[8];
@@ -1046,10 +1056,10 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     const uint2 b = *(const uint2 *)(band_y + (has_y ? jy : 0));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      am[k] = raw[k] < 0 ? -raw[k] : raw[k];
-      out |= (unsigned)am[k] > 32767u;
-      fy[k] = (float)am[k];
-      by[k] = (int)(((k < 4 ? b.x : b.y) >> (8 * (k & 3))) & 0xFFu);
+      const int a = raw[k] < 0 ? -raw[k] : raw[k];
+      out |= (unsigned)a > 32767u;
+      fy[k] = (float)a;
+      my[k] = s_qm[((k < 4 ? b.x : b.y) >> (8 * (k & 3))) & 0x1Fu];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) raw[k] = 0;
@@ -1060,34 +1070,20 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
       const int a = raw[k] < 0 ? -raw[k] : raw[k];
       out |= (unsigned)a > 32767u;
       fc[k] = (float)a;
-      bc[k] = (int)(((k < 4 ? d.x : d.y) >> (8 * (k & 3))) & 0xFFu);
+      mc[k] = s_qm[((k < 4 ? d.x : d.y) >> (8 * (k & 3))) & 0x1Fu];
     }
   }
-  const float *inv = s_inv[wave];
-  const uint2 *qfo = s_qfo[wave];
   const int avail = p.slice_bytes[slice] - 4;
-  // (rounded-up 4 / factor), (factor, offset + 2) of every subband at index tq; false if an index leaves the domain
-  auto set_q = [&](int tq) -> bool {
-    bool ok = true;
-    wave_lds_sync(); // the previous trial's readers are done
-    if (lane < p.n_bands) {
-      const int aq = max(tq - p.qmatrix[lane], 0);
-      ok = aq <= 79;
-      const int a = min(aq, 79);
-      s_inv[wave][lane] = c_qs.inv4[a];
-      s_qfo[wave][lane] = make_uint2((unsigned)c_qs.qf[a], (unsigned)c_qs.off[a] + 2u);
-    }
-    wave_lds_sync();
-    return !__any(!ok);
-  };
-  auto bits8 = [&](const float (&f)[8], const int (&b)[8], bool has, int &sum, int &last_end) {
+  const char *tab = (const char *)s_tab;
+  auto entry = [&](int tq16, int m) -> int { return min(max(tq16 - m, 0), 16 * 79); };
+  auto bits8 = [&](int tq16, const float (&f)[8], const int (&m)[8], bool has, int &sum, int &last_end) {
     sum = 0; last_end = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float y = __builtin_fmaf(f[k], inv[b[k]], 1.0f);
-      const int E = (int)(__float_as_uint(y) >> 23) - 127;
-      sum += 2 * E + min(E, 1) + 1;
-      last_end = E >= 1 ? sum : last_end;
+      const float y = __builtin_fmaf(f[k], *(const float *)(tab + entry(tq16, m[k])), 1.0f);
+      const int eb = (int)__builtin_amdgcn_ubfe(__float_as_uint(y), 23, 8); // 127 + E
+      sum += 2 * eb + min(eb, 128) - 380;                                    // 2E + min(E, 1) + 1
+      last_end = eb >= 128 ? sum : last_end;
     }
     if (!has) { sum = 0; last_end = 0; }
   };
@@ -1097,32 +1093,40 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     return __mul24(len, p.scalar);
   };
   auto need_bytes = [&](int tq, bool &bad) -> int {
-    if (!set_q(tq)) bad = true;
-    int sum, last_end;
-    bits8(fy, by, has_y, sum, last_end);
-    int incl = wave_incl_scan(sum, lane);
+    bad |= tq - p.qm_min > 79; // a factor of 2^22 or more: outside the float domain
+    int sum, last_end, sum_c, last_c;
+    bits8(16 * tq, fy, my, has_y, sum, last_end);
+    bits8(16 * tq, fc, mc, has_c, sum_c, last_c);
+    // both scans in one: a lane's bits are below 2^9, a component's below 2^15
+    const int incl2 = wave_incl_scan(sum | (sum_c << 16), lane);
+    const int incl = incl2 & 0xFFFF, incl_c = incl2 >> 16;
     int need = comp_bytes(wave_max(last_end ? incl - sum + last_end : 0), bad);
-    bits8(fc, bc, has_c, sum, last_end);
-    incl = wave_incl_scan(sum, lane);
-    const int total_u = __shfl(incl, 31);
-    const int rel = incl - sum - (half ? total_u : 0);
-    const int cnt = seg_max<32>(last_end ? rel + last_end : 0);
-    need += comp_bytes(__shfl(cnt, 0), bad) + comp_bytes(__shfl(cnt, 32), bad);
+    const int total_u = __builtin_amdgcn_readlane(incl_c, 31);
+    const int rel = incl_c - sum_c - (half ? total_u : 0);
+    const int cnt = seg_max<32>(last_c ? rel + last_c : 0);
+    need += comp_bytes(__builtin_amdgcn_readlane(cnt, 0), bad) + comp_bytes(__builtin_amdgcn_readlane(cnt, 32), bad);
     return need;
   };
   // luma-only sum of squared reconstruction error (EncodeStream.cpp:73-125 through quant / scale, Quantisation.cpp:69-95)
   auto yss = [&](int tq, bool &bad) -> long long {
-    if (!set_q(tq)) bad = true;
-    long long acc = 0;
+    bad |= tq - p.qm_min > 79;
+    long long acc = 1ll << 35; // keeps the lane's sum of eight 32-bit products non-negative
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const unsigned q = (unsigned)(fy[k] * inv[by[k]]);
-      const uint2 t = qfo[by[k]];
-      const unsigned r = q ? (__umul24(q, t.x) + t.y) >> 2 : 0u;
-      const int d = am[k] - (int)r;
-      acc += (long long)__mul24(d, d);
+    for (int g = 0; g < 8; g += 4) { // four table reads in flight
+      uint4 t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = *(const uint4 *)(tab + entry(16 * tq, my[g + k]));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned q = (unsigned)(fy[g + k] * __uint_as_float(t[k].x));
+        const unsigned r = (__umul24(q, t[k].y) + __umul24(min(q, 1u), t[k].z)) >> 2; // scale(): nothing is added to a zero
+        const int d = (int)fy[g + k] - (int)r;
+        acc += (long long)__mul24(d, d);
+      }
     }
-    return wave_sum64(acc);
+    // the 64-lane sum as two sums of 24-bit limbs on the DPP adder
+    const int lo = seg_incl_scan<64>((int)(acc & 0xFFFFFF), lane), hi = seg_incl_scan<64>((int)(acc >> 24), lane);
+    return (long long)__builtin_amdgcn_readlane(lo, 63) + ((long long)__builtin_amdgcn_readlane(hi, 63) << 24) - (64ll << 35);
   };
 
   bool bad = __any(out);
@@ -1140,14 +1144,13 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     do {
       ++trial;
       const long long cur = yss(trial, bad);
-      bad = __any(bad);
       if (bad) break;
       d = cur - prev;
       prev = cur;
     } while (d < 0);
     q = trial - 1;
   }
-  if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = __any(bad) ? VC2_CBR_MARK : q;
+  if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = bad ? VC2_CBR_MARK : q;
 }
 
 // wavefronts per workgroup so that their LDS (per_wave bytes each) fits: 4 down to 1; 0 if even one does not
@@ -1162,6 +1165,8 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_
   const size_t per_wave = (size_t)p.slice_coefs * 4 + 32 * 16, tables = 768; // + the wavefront's quantiser table; + band tables
   vc2_prof_begin(L, "cbr_search", s);
   p.only_marked = 0;
+  p.qm_min = p.qmatrix[0];
+  for (int b = 1; b < p.n_bands; ++b) p.qm_min = std::min(p.qm_min, p.qmatrix[b]);
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
   if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
   const char *e_gen = getenv("VC2HIP_CBR_GENERAL"); const bool no_reg = e_gen && e_gen[0] == '1'; // A/B and test switch: the general kernel only
