@@ -619,8 +619,8 @@ def test_multi_stream_ld_batches(oracle):
 @pytest.mark.parametrize("scalar", [11, 30, 45])
 def test_large_slice_scalars(hip, oracle, scalar):
     """Slices that may exceed 8191 bytes use 32 KiB index chunks, beyond 32767 bytes a serial walk: any slice size
-    scalar the stream syntax allows is decoded.  The GPU slice coder keeps four slice images in LDS and stops at
-    scalar 40 with an error; beyond that the stream comes from the oracle only."""
+    scalar the stream syntax allows is decoded and coded (the slice coder keeps four slice images in LDS up to scalar 40,
+    fewer beyond, see test_gpu_wide.py for the largest)."""
     import ctypes as C
     w, h, depth, prefix = 256, 128, 3, 2
     raw = noise_frame(w, h, "422", 10, seed=59)
@@ -635,12 +635,8 @@ def test_large_slice_scalars(hip, oracle, scalar):
     assert stream[second + 13:second + 13 + m.value] == bytes(ph[:m.value])
     payload = stream[second + 13 + m.value:-13]
     assert hip.decode_picture(payload, fmt, cp) == dec
-    if scalar <= 40:
-        got, _ = hip.encode_picture_hq(raw, fmt, cp)
-        assert got == payload
-    else:
-        with pytest.raises(Exception, match="too large for the slice coder"):
-            hip.encode_picture_hq(raw, fmt, cp)
+    got, _ = hip.encode_picture_hq(raw, fmt, cp)   # beyond scalar 40: fewer slice images per workgroup (then in global memory)
+    assert got == payload
 
 
 @pytest.mark.parametrize("u,a,cf", [(1, 1, "444"), (1, 2, "422"), (2, 2, "422"), (2, 2, "420"), (2, 4, "444"), (4, 4, "422")])

@@ -350,25 +350,24 @@ __device__ __forceinline__ void load8_tab(Coef8 &c, const ST *src, const int32_t
   if (j0 + 8 <= n) {
     St<ST>::load8(src + j0, wide + j0, raw);
     const uint2 bands = *(const uint2 *)(band_lut + j0);
-    // quant(), Quantisation.cpp:69-76, eight at a time: the reciprocal multiply for all, then ONE test whether any of
-    // them left its domain (factor <= 1 or |v| << 2 overflowed: sign bit of `a | (factor - 2)`, the table's 4th word)
-    unsigned mag4[8], qf2[8], dom = 0;
+    // quant(), Quantisation.cpp:69-76, eight at a time: floor(4|v| / factor) as the truncated float product of |v| and
+    // the rounded-up 4 / factor (exact for |v| < 2^20, see k_cbr_search_reg), then ONE test whether any left that domain
     int qq[8];
+    float big = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const unsigned b = ((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu;
-      const uint4 t = qtab[b];
-      const int v = raw[k];
-      const unsigned a = (v < 0 ? 0u - (unsigned)v : (unsigned)v) << 2;
-      const unsigned m = __umulhi(t.x, a);
-      qq[k] = (int)((m + ((a - m) >> 1)) >> t.y);
-      mag4[k] = a; qf2[k] = t.w;
-      dom |= a | t.w;
+      const float f = (float)raw[k];
+      qq[k] = (int)(unsigned)(__builtin_fabsf(f) * __uint_as_float(qtab[b].w));
+      big = fmaxf(big, __builtin_fabsf(f));
     }
-    if (__any((int)dom < 0)) { // rare: the literal int division for the coefficients concerned
+    if (__any(big >= 1048576.f)) { // rare: the literal int division for the coefficients concerned
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if ((int)(mag4[k] | qf2[k]) < 0) qq[k] = (int)mag4[k] / (int)(qf2[k] + 2u);
+      for (int k = 0; k < 8; ++k) {
+        const unsigned b = ((k < 4 ? bands.x : bands.y) >> (8 * (k & 3))) & 0xFFu;
+        const unsigned a = (raw[k] < 0 ? 0u - (unsigned)raw[k] : (unsigned)raw[k]) << 2;
+        if (a >= (1u << 22)) qq[k] = (int)a / (int)qtab[b].z;
+      }
     }
     // codes straight from magnitude and sign (the table holds the code of +m; a negative value sets its last bit)
     unsigned all = 0;
@@ -482,9 +481,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   if (p.quantise) {
     if (active && sl < 3 * p.depth + 1) { // quantiser constants of every subband for this slice's index
       const int aq = max(p.qidx[(size_t)pic * p.n_slices + slice] - p.qmatrix[sl], 0);
-      // (magic, shift, factor, factor - 2): the 4th word's sign bit marks a factor outside the multiply's domain
-      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[sl] = make_uint4(0u, 0u, 0x40000000u, 0x3FFFFFFEu); }
-      else qtab[sl] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], (unsigned)c_qs.qf[aq] - 2u);
+      // (magic, shift, factor, rounded-up 4 / factor as a float)
+      if (aq > 119) { atomicOr(p.err, VC2_DEVERR_QINDEX); qtab[sl] = make_uint4(0u, 0u, 0x40000000u, 0u); }
+      else qtab[sl] = make_uint4(c_qs.magic[aq], (unsigned)c_qs.shift[aq], (unsigned)c_qs.qf[aq], __float_as_uint(c_qs.inv4[aq]));
     }
   }
   __syncthreads();
