@@ -24,9 +24,15 @@ void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s) {
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_qd), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
 }
 
+#ifndef VC2_FID_NT
+#define VC2_FID_NT 512
+#endif
 namespace {
 
-constexpr int TY = 32, TX = 128, NT = 256;
+constexpr int TY = 32, TX = 128;
+// threads per workgroup (one tile): the long Fidelity filter works step by step through LDS with a barrier per step and
+// is latency-bound -- eight wavefronts per tile halve the work between barriers and double the wavefronts per CU
+template <int K> constexpr int NTK = K == VC2HIP_FIDELITY ? VC2_FID_NT : 256;
 constexpr int TXQ = TX / 8; // 16-byte chunks (8 samples, 4 pairs) across a tile row
 
 struct I4 {
@@ -102,6 +108,7 @@ __device__ __forceinline__ void reg_pass(T (&E)[NW], T (&O)[NW], bool edge, int 
 // NIT = iterations of 256 threads; results are held in registers across the barrier.
 template <int K, bool INV, int NIT>
 __device__ __forceinline__ void h_pass(int *lds, int row_lo, int n_rows, int kx_base, int npx) {
+  constexpr int NT = NTK<K>;
   using C = Cfg<K>;
   constexpr int NW = C::NWH, P = 4 * C::PADQ;
   I4 re[NIT], ro[NIT];
@@ -144,6 +151,7 @@ __device__ __forceinline__ void h_pass(int *lds, int row_lo, int n_rows, int kx_
 // vertical pass over the core row pairs, column quads [cq_lo, cq_lo + n_cq) of both column parities
 template <int K, bool INV, int NIT>
 __device__ __forceinline__ void v_pass(int *lds, int cq_lo, int n_cq, int ky_base, int npy) {
+  constexpr int NT = NTK<K>;
   using C = Cfg<K>;
   constexpr int NW = C::NWV, P = C::PADV;
   I4 re[NIT][4], ro[NIT][4];
@@ -197,6 +205,7 @@ constexpr int floor_div4(int v) { return v >= 0 ? v / 4 : -((-v + 3) / 4); }
 // lifting step S along x on rows [row_lo, row_lo + n_rows) of the (2 * WYP)-row stack, pair quads [q_lo, q_hi)
 template <int K, int S, bool INV>
 __device__ __forceinline__ void step_h(int *lds, int row_lo, int n_rows, int q_lo, int q_hi, int kx_base, int npx) {
+  constexpr int NT = NTK<K>;
   using C = Cfg<K>;
   constexpr bool odd = step_targets_odd<K, S>();
   constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
@@ -236,6 +245,7 @@ __device__ __forceinline__ void step_h(int *lds, int row_lo, int n_rows, int q_l
 // lifting step S along y on row pairs [r_lo, r_hi), column quads [cq_lo, cq_lo + n_cq) of both column parities
 template <int K, int S, bool INV>
 __device__ __forceinline__ void step_v(int *lds, int r_lo, int r_hi, int cq_lo, int n_cq, int ky_base, int npy) {
+  constexpr int NT = NTK<K>;
   using C = Cfg<K>;
   constexpr bool odd = step_targets_odd<K, S>();
   constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
@@ -324,7 +334,8 @@ __device__ __forceinline__ bool tile_of_block(int tiles_x, int tiles_y, int &tx,
 // forward level
 // ------------------------------------------------------------------------------------------
 template <int K, bool FIRST, class ST>
-__global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
+__global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
+  constexpr int NT = NTK<K>;
   using S_ = St<ST>;
   using C = Cfg<K>;
   extern __shared__ __attribute__((aligned(16))) int lds[];
@@ -528,7 +539,8 @@ __global__ __launch_bounds__(NT) void k_fwd_fast(const LevelParams p) {
 // SMALL: the band blocks of a slice are narrower than four coefficients (deep levels); the store bands are then
 // gathered slice by slice (see below) instead of window position by window position.
 template <int K, bool FINAL, bool SMALL, class ST>
-__global__ __launch_bounds__(NT) void k_inv_fast(const LevelParams p) {
+__global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
+  constexpr int NT = NTK<K>;
   using S_ = St<ST>;
   using C = Cfg<K>;
   extern __shared__ __attribute__((aligned(16))) int lds[];
@@ -787,7 +799,7 @@ template <int K, bool EDGE, bool INV, class ST>
 void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t s) {
   int gx = 0, gy = 0;
   for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.tiles_x[c]); gy = std::max(gy, p.tiles_y[c]); }
-  dim3 grid(gx, gy, 3 * n_pictures), block(NT);
+  dim3 grid(gx, gy, 3 * n_pictures), block(NTK<K>);
   const size_t lds = INV ? Cfg<K>::LDS_INV : Cfg<K>::LDS;
   if constexpr (INV) {
     // element-wise gather when some component's band blocks are narrower than four coefficients
