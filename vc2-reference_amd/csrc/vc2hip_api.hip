@@ -18,6 +18,7 @@ void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s);
 int vc2_halo_x(int kernel);
 int vc2_halo_y(int kernel);
 void vc2_upload_vlc_lut(hipStream_t s);
+void vc2_upload_unpack_lut(hipStream_t s);
 bool vc2_slice_index_supported(int prefix, int scalar);
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
 int vc2_pack_image_mode(int prefix, int scalar);
@@ -315,6 +316,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   vc2_upload_tables_fast(t, c->stream);
   vc2_upload_tables_stream(t, c->stream);
   vc2_upload_vlc_lut(c->stream);
+  vc2_upload_unpack_lut(c->stream);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   *out = c;
   return VC2HIP_OK;

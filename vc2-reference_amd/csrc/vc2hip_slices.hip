@@ -1447,67 +1447,210 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
   }
 }
 
-// The same decoder writing the 16-bit store: 64 coefficients per lane and round staged as shorts (a row is one 128-byte
-// line of the store again), eight lanes flush one row with 16-byte streaming stores.  Needs component sizes that are
-// multiples of 8 (the host selects the 16-bit store only then).
+// ------------------------------------------------------------------------------------------
+// HQ unpack into the 16-bit store: table-driven, several coefficients per look-up.
+//
+// A lane decodes one slice component as before, but a turn of its loop is two look-ups of the next 10 stream bits in a
+// table of "what these bits decode to": bits consumed, coefficients produced (zeros included, at most 8), and up to
+// two non-zero values with their positions -- 3.6 coefficients per turn on the bench pictures for ~70 instructions,
+// where the code-by-code decoder above spends ~150 per turn.  What the table cannot hold (a code longer than 10 bits:
+// |value| > 30) takes a separate step that runs on every fourth turn only: with 64 lanes per wavefront something rare
+// per lane happens on almost every turn somewhere, and a step the wavefront executes for one lane costs all of them.
+// The bit reader keeps 33..64 unread bits in a register pair and appends one pre-fetched 32-bit word when it runs low
+// (one short conditional block per turn instead of the 64-bit window assembly and refill of WordReader).
+// Rows hold 64 coefficients plus 8 of slack: a table entry is applied whole, coefficients that spill over the end of a
+// round are carried into the next one.
+// ------------------------------------------------------------------------------------------
+// entry: bits [3:0] consumed (1..10), [7:4] coefficients (1..8), [11:8] / [15:12] positions of the two values,
+// [23:16] / [31:24] the values (int8).  No non-zero value: both slots store 0 at position 0 (a zero anyway); one: both
+// slots hold it.  0: the first token is a code longer than the index.
+constexpr int UNP_LUT_BITS = 10, UNP_LUT_N = 1 << UNP_LUT_BITS;
+__device__ unsigned g_unp_lut[UNP_LUT_N];
+void vc2_upload_unpack_lut(hipStream_t s) {
+  static unsigned host[UNP_LUT_N];
+  for (int idx = 0; idx < UNP_LUT_N; ++idx) {
+    auto bit = [&](int i) { return (idx >> (UNP_LUT_BITS - 1 - i)) & 1; };
+    int pos = 0, nc = 0, nnz = 0, at[2] = {0, 0}, val[2] = {0, 0};
+    while (nc < 8 && pos < UNP_LUT_BITS) {
+      if (bit(pos)) { ++nc; ++pos; continue; } // a lone '1': the value 0 (VLC.cpp:283-295)
+      int q = pos, mag = 1;
+      bool whole = false;
+      while (q + 1 < UNP_LUT_BITS) {           // (0 b)* 1 s
+        mag = (mag << 1) | bit(q + 1);
+        q += 2;
+        if (q >= UNP_LUT_BITS) break;
+        if (bit(q)) { whole = q + 1 < UNP_LUT_BITS; break; }
+      }
+      if (!whole || nnz == 2) break;
+      const int v = bit(q + 1) ? -(mag - 1) : mag - 1;
+      at[nnz] = nc; val[nnz] = v; ++nnz;
+      ++nc;
+      pos = q + 2;
+    }
+    if (nnz == 1) { at[1] = at[0]; val[1] = val[0]; }
+    host[idx] = nc == 0 ? 0u
+                        : (unsigned)pos | (unsigned)nc << 4 | (unsigned)at[0] << 8 | (unsigned)at[1] << 12 |
+                              (unsigned)(val[0] & 0xFF) << 16 | (unsigned)(val[1] & 0xFF) << 24;
+  }
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_unp_lut), host, sizeof host, 0, hipMemcpyHostToDevice, s);
+}
+
+// 33..64 unread bits at the top of `acc`; the next stream word is already in a register.  Words are fetched as aligned
+// dwords from the picture's payload (a wave-uniform base + a 32-bit offset per lane); bits past the bounded data read
+// as 1 (VLC.cpp:182-185) and no word without a data bit is ever loaded.
+struct Reader32 {
+  unsigned long long acc;
+  int have;      // valid bits in acc, 33..64 between turns
+  unsigned nw;   // the word after those in acc
+  unsigned off;  // byte offset (from the payload base) of the word after nw
+  int left;      // data bits from that word on (<= 0: none)
+  __device__ __forceinline__ unsigned fetch(const uint8_t *pay) {
+    unsigned v = ~0u;
+    if (left > 0) {
+      v = __builtin_bswap32(*(const unsigned *)(pay + off));
+      if (left < 32) v |= ~0u >> left;
+    }
+    off += 4;
+    left -= 32;
+    return v;
+  }
+  // nbytes of data at byte offset pos of the payload
+  __device__ __forceinline__ void init(const uint8_t *pay, unsigned pos, int nbytes) {
+    const int lead = 8 * (int)(pos & 3u);
+    off = pos & ~3u;
+    left = nbytes > 0 ? 8 * nbytes + lead : 0;
+    const unsigned w0 = fetch(pay), w1 = fetch(pay);
+    acc = (((unsigned long long)w0 << 32) | w1) << lead;
+    have = 64 - lead;
+    nw = fetch(pay);
+  }
+  __device__ __forceinline__ unsigned top() const { return (unsigned)(acc >> 32); }
+  __device__ __forceinline__ void skip(const uint8_t *pay, int n) { // n <= 32
+    acc <<= n;
+    have -= n;
+    if (have <= 32) {
+      acc |= (unsigned long long)nw << (32 - have);
+      have += 32;
+      nw = fetch(pay);
+    }
+  }
+};
+
 __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
-  constexpr int UNP_N = 64, UNP_PITCH = UNP_N + 8; // shorts per staging row, 16-byte aligned rows
+  constexpr int UNP_N = 64, UNP_PITCH = UNP_N + 8; // shorts per staging row (8 of slack), 16-byte aligned rows
   __shared__ __attribute__((aligned(16))) short stage[4][64 * UNP_PITCH];
-  __shared__ unsigned long long outp[4][64];
-  __shared__ unsigned short vlut[1024];
-  vlut_init(vlut);
-  __syncthreads();
+  __shared__ unsigned lut[UNP_LUT_N];
+  for (int i = threadIdx.x * 4; i < UNP_LUT_N; i += blockDim.x * 4) *(uint4 *)(lut + i) = *(const uint4 *)(g_unp_lut + i);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y, comp = blockIdx.z;
-  const int slice = blockIdx.x * 256 + threadIdx.x;
+  const int slice0 = blockIdx.x * 256 + wave * 64, slice = slice0 + lane;
   const bool active = slice < p.n_slices;
   const int n = p.comp_n[comp];
   short *st = stage[wave] + lane * UNP_PITCH;
-  int32_t *wide = nullptr;
-  WordReader br;
+  const uint8_t *pay0 = p.payload + (size_t)pic * p.payload_stride;
+  const unsigned mis = (unsigned)((size_t)pay0 & 3);
+  const uint8_t *pay = pay0 - mis; // dword aligned: the reader's offsets count from here
+  const size_t rec0 = (size_t)pic * p.store_stride + p.comp_off[comp]; // + slice * slice_coefs: a component record
+  int32_t *wide = p.store_wide + rec0 + (size_t)(active ? slice : 0) * p.slice_coefs;
+  Reader32 br;
   {
-    int16_t *out = nullptr;
-    const uint8_t *data = nullptr;
-    unsigned len = 0;
+    unsigned pos = 0, len = 0;
     if (active) {
-      const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
       const unsigned long long plen = min(p.lens[pic], (unsigned long long)p.payload_stride);
-      unsigned long long pos = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
-      auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay[a] : 0u; };
-      if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(pos);
-      pos += 1;
-      for (int c = 0; c < comp; ++c) pos += 1 + (unsigned long long)rd(pos) * p.scalar;
-      len = rd(pos) * p.scalar;
-      pos += 1;
-      if (pos + len > plen) {
+      unsigned long long at = (unsigned long long)p.offsets[(size_t)pic * p.n_slices + slice] + p.prefix;
+      auto rd = [&](unsigned long long a) -> unsigned { return a < plen ? pay0[a] : 0u; };
+      if (comp == 0) p.qidx[(size_t)pic * p.n_slices + slice] = (int)rd(at);
+      at += 1;
+      for (int c = 0; c < comp; ++c) at += 1 + (unsigned long long)rd(at) * p.scalar;
+      len = rd(at) * p.scalar;
+      at += 1;
+      if (at + len > plen) {
         atomicOr(p.err, VC2_DEVERR_STREAM);
-        len = pos < plen ? (unsigned)(plen - pos) : 0;
+        len = at < plen ? (unsigned)(plen - at) : 0;
       }
-      data = pay + (pos < plen ? pos : 0);
-      const size_t at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[comp];
-      out = (int16_t *)p.store + at;
-      wide = p.store_wide + at;
+      pos = at < plen ? (unsigned)at : 0u;
     }
-    outp[wave][lane] = (unsigned long long)out;
-    if (active) br.init(data, (int)len); else br.init_ones();
+    br.init(pay, pos + mis, (int)len);
   }
+#pragma unroll
+  for (int k = 0; k < UNP_PITCH; k += 8) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
+  __syncthreads(); // the table
+  int cnt = 0;     // coefficients of the current round already in the row (carried over from the previous one)
   for (int base = 0; base < n; base += UNP_N) {
     const int room = min(UNP_N, n - base);
-    decode_round<UNP_N, short>(br, room, st, vlut, wide + base);
-    wave_lds_sync(); // staging rows are private to the wavefront (see k_hq_unpack)
+    for (int turn = 0; cnt < room; ++turn) {
+      int used = 0;
+      // two look-ups.  Stores go to st[cnt + position]; with no value in the entry they rewrite a zero.
+#pragma unroll
+      for (int look = 0; look < 2; ++look) {
+        const unsigned w = look ? (unsigned)((br.acc << used) >> 32) : br.top();
+        const unsigned e = lut[w >> (32 - UNP_LUT_BITS)];
+        if (e != 0 && (look == 0 || (used != 0 && cnt < room))) {
+          st[cnt + (int)((e >> 8) & 15u)] = (short)__builtin_amdgcn_sbfe((int)e, 16, 8);
+          st[cnt + (int)((e >> 12) & 15u)] = (short)((int)e >> 24);
+          cnt += (int)((e >> 4) & 15u);
+          used += (int)(e & 15u);
+        }
+      }
+      // every fourth turn: lanes stopped at a code the table does not hold decode that one code
+      if ((turn & 3) == 3) {
+        if (used == 0 && cnt < room) {
+          const unsigned hi = br.top();                   // starts with a 0: a code
+          const unsigned follow = hi & 0xAAAAAAAAu;       // follow bits sit at even offsets from the code start
+          if (follow != 0) {
+            const int K = __clz((int)follow) >> 1;        // 1..15 (bit 31 of hi is 0)
+            const unsigned body = hi >> ((32 - 2 * K) & 31); // top 2K bits: (0 b) pairs
+            const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
+            const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
+            int v = neg ? (int)(0u - mag) : (int)mag;
+            if (!St<int16_t>::fits(v)) { wide[base + cnt] = v; v = VC2_ST_SENTINEL; }
+            st[cnt++] = (short)v;
+            used = 2 * K + 2;
+          } else { // longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
+            unsigned value = 1;
+            for (;;) {
+              const unsigned f = br.top() >> 31;
+              br.skip(pay, 1);
+              if (f) break;
+              value = (value << 1) | (br.top() >> 31);
+              br.skip(pay, 1);
+            }
+            value -= 1u;
+            int v = 0;
+            if (value) {
+              v = (br.top() >> 31) ? (int)(0u - value) : (int)value;
+              br.skip(pay, 1);
+            }
+            if (!St<int16_t>::fits(v)) { wide[base + cnt] = v; v = VC2_ST_SENTINEL; }
+            st[cnt++] = (short)v;
+          }
+        }
+      }
+      br.skip(pay, used);
+    }
+    // flush: eight lanes x 16 bytes per row (one 128-byte line of the store).  The staging rows are private to the
+    // wavefront, so only its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup
+    // barrier, the four wavefronts of the workgroup drift apart freely.
+    wave_lds_sync();
     const short *sw = stage[wave];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = j * 8 + (lane >> 3), c = (lane & 7) * 8;
-      int16_t *dst = (int16_t *)outp[wave][r];
-      if (dst && c < room) {
+      if (slice0 + r < p.n_slices && c < room) {
         const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
         typedef int v4i __attribute__((ext_vector_type(4)));
         const v4i vv = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)(dst + base + c));
+        int16_t *dst = (int16_t *)p.store + rec0 + (size_t)(slice0 + r) * p.slice_coefs + base + c;
+        __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
       }
     }
     wave_lds_sync();
+    // coefficients decoded beyond the round move to the front of the row
+    const int4 spill = *(const int4 *)(st + UNP_N);
+#pragma unroll
+    for (int k = 0; k < UNP_PITCH; k += 8) *(int4 *)(st + k) = make_int4(0, 0, 0, 0);
+    cnt = max(cnt - UNP_N, 0);
+    if (cnt) *(int4 *)st = spill;
   }
 }
 
