@@ -108,6 +108,7 @@ struct LevelParams {
   int dequant;                // inverse: apply scale() to store values
   unsigned *err;              // device error flags
   int big_lut;                // set by the launcher: LDS holds subband tables for components of up to 2048 coefficients
+  float inv_scalar;           // set by the launcher: the smallest float >= 1 / scalar
   int debug_skip;             // -DVC2HIP_ABLATE builds only (tools/ablate_*.py): 1 no loads, 2 no lifting, 4 no stores
   int qmatrix[VC2_MAX_BANDS];
   // streaming kernels (vc2hip_dwt_stream.hip), set by vc2_stream_level_applicable
@@ -147,6 +148,7 @@ struct PackParams {
   unsigned *err;
   int quantise;               // 0: store already holds quantised values (fine-grained API)
   int big_lut;                // set by the launcher: LDS holds subband tables for components of up to 2048 coefficients
+  float inv_scalar;           // set by the launcher: the smallest float >= 1 / scalar
   int debug_skip;             // timing experiments only (VC2HIP_DEBUG_PACK): 1 no code writes, 2 no copy-out
   // single-pass VBR: slice offsets by decoupled look-back over workgroup tiles (4 slices each).
   // lookback: per picture [0] = tile ticket, [1 + t] = status of tile t: flag (2 bits) << 62 | bytes

@@ -497,8 +497,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     const ST *rec = (const ST *)p.store + rec_at;
     const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
     const int cbr_total = p.cbr_bytes ? p.cbr_bytes[slice] : 0;
-    auto comp_len = [&](int count) -> int {
-      int len = ((count + 7) / 8 + p.scalar - 1) / p.scalar;
+    auto comp_len = [&](int count) -> int { // ceil(bytes / scalar) by the rounded-up reciprocal (exact far beyond 255 * scalar)
+      int len = (int)((float)(((count + 7) >> 3) + p.scalar - 1) * p.inv_scalar);
       if (len > 255) { if (sl == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
       return len * p.scalar;
     };
@@ -671,6 +671,8 @@ int vc2_pack_image_mode(int prefix, int scalar) {
 size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
+  p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
+  if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
 #ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
 #endif
@@ -1450,10 +1452,10 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 // ------------------------------------------------------------------------------------------
 // HQ unpack into the 16-bit store: table-driven, several coefficients per look-up.
 //
-// A lane decodes one slice component as before, but a turn of its loop is two look-ups of the next 10 stream bits in a
+// A lane decodes one slice component as before, but a turn of its loop is three look-ups of the next 10 stream bits in a
 // table of "what these bits decode to": bits consumed, coefficients produced (zeros included, at most 8), and up to
-// two non-zero values with their positions -- 3.6 coefficients per turn on the bench pictures for ~70 instructions,
-// where the code-by-code decoder above spends ~150 per turn.  What the table cannot hold (a code longer than 10 bits:
+// two non-zero values with their positions -- a few coefficients per look-up for ~20 instructions, where the
+// code-by-code decoder above spends ~150 per turn of two codes.  What the table cannot hold (a code longer than 10 bits:
 // |value| > 30) takes a separate step that runs on every fourth turn only: with 64 lanes per wavefront something rare
 // per lane happens on almost every turn somewhere, and a step the wavefront executes for one lane costs all of them.
 // The bit reader keeps 33..64 unread bits in a register pair and appends one pre-fetched 32-bit word when it runs low
@@ -1464,6 +1466,12 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 // entry: bits [3:0] consumed (1..10), [7:4] coefficients (1..8), [11:8] / [15:12] positions of the two values,
 // [23:16] / [31:24] the values (int8).  No non-zero value: both slots store 0 at position 0 (a zero anyway); one: both
 // slots hold it.  0: the first token is a code longer than the index.
+#ifndef UNP_LOOKS
+#define UNP_LOOKS 3
+#endif
+#ifndef UNP_LONG_EVERY
+#define UNP_LONG_EVERY 3
+#endif
 constexpr int UNP_LUT_BITS = 10, UNP_LUT_N = 1 << UNP_LUT_BITS;
 __device__ unsigned g_unp_lut[UNP_LUT_N];
 void vc2_upload_unpack_lut(hipStream_t s) {
@@ -1580,9 +1588,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
     const int room = min(UNP_N, n - base);
     for (int turn = 0; cnt < room; ++turn) {
       int used = 0;
-      // two look-ups.  Stores go to st[cnt + position]; with no value in the entry they rewrite a zero.
+      // the look-ups (after two, 13 or more unread bits are left: still a whole index).  Stores go to st[cnt + position]; with no value in the entry they rewrite a zero.
 #pragma unroll
-      for (int look = 0; look < 2; ++look) {
+      for (int look = 0; look < UNP_LOOKS; ++look) {
         const unsigned w = look ? (unsigned)((br.acc << used) >> 32) : br.top();
         const unsigned e = lut[w >> (32 - UNP_LUT_BITS)];
         if (e != 0 && (look == 0 || (used != 0 && cnt < room))) {
@@ -1593,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
         }
       }
       // every fourth turn: lanes stopped at a code the table does not hold decode that one code
-      if ((turn & 3) == 3) {
+      if ((turn & UNP_LONG_EVERY) == UNP_LONG_EVERY) {
         if (used == 0 && cnt < room) {
           const unsigned hi = br.top();                   // starts with a 0: a code
           const unsigned follow = hi & 0xAAAAAAAAu;       // follow bits sit at even offsets from the code start
