@@ -30,7 +30,8 @@ def _ctx(env):
 
 @pytest.fixture(scope="module")
 def variants():
-    return {"default": _ctx({}), "store32": _ctx({"VC2HIP_STORE32": "1"}), "tiles": _ctx({"VC2HIP_NO_STREAM": "1"})}
+    return {"default": _ctx({}), "store32": _ctx({"VC2HIP_STORE32": "1"}), "tiles": _ctx({"VC2HIP_NO_STREAM": "1"}),
+            "records": _ctx({"VC2HIP_NO_BANDPLANES": "1"})}
 
 
 def _fmt_cp(hip, w, h, cf, bits, kernel, depth, u, a, **kw):

@@ -129,6 +129,7 @@ struct vc2hip_ctx {
   bool two_pass_vbr = true;
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
+  bool allow_planes = true; // decode: band planes for the streaming levels (A/B and test switch VC2HIP_NO_BANDPLANES)
   bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
   // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
@@ -297,6 +298,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
   { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_STREAM"); c->allow_stream = !(e && e[0] == '1'); }
+  { const char *e = getenv("VC2HIP_NO_BANDPLANES"); c->allow_planes = !(e && e[0] == '1'); }
 #ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
 #endif
@@ -691,15 +693,21 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
 }
 
 // inverse transform of n pictures: store (optionally dequantised on load) -> int32 planes or raw words
+// bp: the decoder's band planes (levels < bp->levels read their bands from them; the store stride then includes them).
+// stream_mask != nullptr: a dry run -- nothing is launched, bit l of *stream_mask says whether level l would go through
+// the streaming kernel (the planning step of the band planes asks this before the slices are decoded).
 static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *store, const int32_t *qidx,
                        const int32_t *qm, bool dequant, bool ll_ready, const LLPlanes &ll, void *const dst[3],
                        const long long dst_stride[3], bool dst_raw, const vc2hip_picture_format *f,
-                       bool s16 = false, int32_t *store_wide = nullptr) {
+                       bool s16 = false, int32_t *store_wide = nullptr, const BandPlanes *bp = nullptr,
+                       long long store_stride = 0, unsigned *stream_mask = nullptr) {
+  if (stream_mask) *stream_mask = 0;
   for (int level = g.depth - 1; level >= 0; --level) {
     LevelParams p;
     memset(&p, 0, sizeof p);
     fill_level(p, g, level, kernel, qm);
-    p.store = store; p.store_stride = (long long)g.ys * g.xs * g.slice_coefs;
+    p.store = store; p.store_stride = store_stride ? store_stride : (long long)g.ys * g.xs * g.slice_coefs;
+    for (int k = 0; k < 3; ++k) p.bp_base[k] = (bp && level < bp->levels && g.c[k].ph) ? bp->base[k][level] : -1;
     p.store_wide = store_wide;
     p.qidx = qidx; p.err = c->d_err; p.dequant = dequant;
     p.ll_from_store = (level == g.depth - 1) && !ll_ready;
@@ -722,11 +730,14 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
       LevelParams ps = p;
       const size_t lds = vc2_stream_level_applicable(ps, kernel, fin, true, s16, n);
       if (lds) {
+        if (stream_mask) { *stream_mask |= 1u << level; continue; }
         int rc = vc2_launch_inverse_stream(c->L, kernel, fin, ps, n, s16, lds, c->stream);
         if (rc) return set_err(c, rc, "invalid wavelet kernel");
         continue;
       }
     }
+    if (stream_mask) continue;
+    if (bp && level < bp->levels) return set_err(c, VC2HIP_EINVAL, "internal: band planes without the streaming kernel");
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
       int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, s16, c->stream);
       if (rc) return set_err(c, rc, "invalid wavelet kernel");
@@ -1452,11 +1463,51 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
   int32_t qm[VC2_MAX_BANDS];
   if ((rc = vc2hip_quant_matrix(cp->kernel, cp->depth, qm))) return set_err(c, rc);
   const bool s16 = !ld && use_store16(c, g, cp->kernel);
+  const void *dstc[3]; long long ds[3];
+  raw_planes(f, d_raw_out, dstc, ds);
+  void *dst[3] = {(void *)dstc[0], (void *)dstc[1], (void *)dstc[2]};
+  const bool plane_path = !ld && needs_plane_path(c, g, cp->kernel);
+  // Band planes (vc2hip_internal.h): the finest levels, as long as they go through the streaming inverse kernel, a
+  // slice's block row in them is at least 4 coefficients (8: rows that keep 16-byte pieces aligned) and they are not
+  // the level whose LL comes from the store.  16-bit store only (the int32 store is the fallback decoder's).
+  BandPlanes bp;
+  memset(&bp, 0, sizeof bp);
+  long long sstride = (long long)ns * g.slice_coefs; // elements per picture: slice records, then band planes
+  if (s16 && !plane_path && c->allow_planes) {
+    unsigned mask = 0;
+    LLPlanes none;
+    memset(&none, 0, sizeof none);
+    (void)run_inverse(c, g, cp->kernel, n, nullptr, nullptr, qm, true, ld, none, dst, ds, true, f, s16, nullptr, nullptr, 0, &mask);
+    for (int k = 0; k < 3; ++k) bp.from[k] = g.c[k].ph ? g.c[k].sh * g.c[k].sw : 0;
+    for (int l = 0; l < VC2_BP_MAX && l < g.depth - 1 && (mask >> l & 1); ++l) {
+      bool ok = true;
+      for (int k = 0; k < 3 && ok; ++k) {
+        const CompGeom &cg = g.c[k];
+        if (!cg.ph) continue;
+        const int bsh = (cg.sh >> l) / 2, bsw = (cg.sw >> l) / 2, ow = (cg.pw >> l) / 2;
+        ok = bsh >= 1 && bsw >= 4 && (bsh & (bsh - 1)) == 0 && (bsw & (bsw - 1)) == 0 && ow % (bsw >= 8 ? 8 : 4) == 0 &&
+             (bsh * bsw) % 8 == 0;
+      }
+      if (!ok) break;
+      for (int k = 0; k < 3; ++k) {
+        const CompGeom &cg = g.c[k];
+        if (!cg.ph) continue;
+        const int bsh = (cg.sh >> l) / 2, bsw = (cg.sw >> l) / 2;
+        bp.np[k][l] = (cg.ph >> l) / 2; bp.ow[k][l] = (cg.pw >> l) / 2;
+        bp.lbsh[k][l] = 31 - __builtin_clz(bsh); bp.lbsw[k][l] = 31 - __builtin_clz(bsw);
+        bp.base[k][l] = sstride;
+        sstride += ((long long)3 * bp.np[k][l] * bp.ow[k][l] + 7) & ~7ll;
+        bp.from[k] -= 3 * bsh * bsw;
+      }
+      bp.levels = l + 1;
+    }
+    if (sstride >= (1ll << 31)) { memset(&bp, 0, sizeof bp); sstride = (long long)ns * g.slice_coefs; } // 32-bit element offsets
+  }
   int32_t *d_store, *d_ll, *d_q, *d_storew = nullptr, *d_llw = nullptr;
-  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store);
+  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store); // 16-bit elements: records and band planes fit in it
   NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
   if (s16) {
-    NEED(c, B_STOREW, (size_t)n * ns * g.slice_coefs * 4, d_storew);
+    NEED(c, B_STOREW, (size_t)n * sstride * 4, d_storew);
     NEED(c, B_LLW, ll_bytes(g, n) + 16, d_llw);
   }
   NEED(c, B_QIDX, (size_t)n * ns * 4, d_q);
@@ -1471,12 +1522,13 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     memset(&p, 0, sizeof p);
     p.payload = (const uint8_t *)d_payload; p.payload_stride = (long long)payload_stride;
     p.lens = (const unsigned long long *)d_lens; p.offsets = d_offs;
-    p.store = d_store; p.store_stride = (long long)ns * g.slice_coefs; p.qidx = d_q;
+    p.store = d_store; p.store_stride = sstride; p.qidx = d_q;
     p.store16 = s16; p.store_wide = d_storew;
     p.n_slices = ns; p.slice_coefs = g.slice_coefs;
     int n0[3];
     fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
     p.prefix = cp->prefix; p.scalar = cp->scalar; p.err = c->d_err;
+    p.bp = bp; p.xs = g.xs;
     vc2_launch_unpack(c->L, p, n, c->stream);
   } else {
     // DecodeStream.cpp:312, :331-333: per-slice sizes from the picture byte budget
@@ -1507,11 +1559,8 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
                        g.c[k].ph >> g.depth, g.c[k].pw >> g.depth, g.ys, g.xs, d_q, qm[0], (int32_t *)ll.p[g.depth][k],
                        ll.stride[g.depth][k], n, c->d_err, c->stream);
   }
-  const void *dstc[3]; long long ds[3];
-  raw_planes(f, d_raw_out, dstc, ds);
-  void *dst[3] = {(void *)dstc[0], (void *)dstc[1], (void *)dstc[2]};
-  if (!ld && needs_plane_path(c, g, cp->kernel)) return plane_inverse(c, g, cp->kernel, n, d_store, d_q, qm, dst, ds, f);
-  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew);
+  if (plane_path) return plane_inverse(c, g, cp->kernel, n, d_store, d_q, qm, dst, ds, f);
+  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew, &bp, sstride);
 }
 
 extern "C" int vc2hip_decode_batch_dev(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens,

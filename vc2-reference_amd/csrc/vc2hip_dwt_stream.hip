@@ -492,14 +492,18 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     if constexpr (S_::narrow) llp_w = p.ll_wide[comp] + (size_t)pic * p.ll_stride[comp] + (size_t)chunk * 4;
   }
 
-  // ---- input: per band row the lane's four coefficients of every band, straight from the slice records (a slice's
-  // band block row is bsw coefficients: neighbouring lanes read neighbouring 8 / 16 bytes), prefetched PFI rows ahead.
+  // ---- input: per band row the lane's four coefficients of every band, straight from the store, prefetched PFI rows ahead.
   // (A version that brought the bands in through LDS-DMA in whole 128-byte lines, double buffered, was correct but
   // slower -- 0.75 against 0.55 ms per 16 UHD pictures: its 17 KiB image per wavefront halves the occupancy, and this
   // kernel lives on occupancy.)
   typedef typename std::conditional<S_::narrow, uint2, uint4>::type Q4; // four store elements
   Q4 bq[PFI][4];
-  auto rec_at = [&](int m, int b) __attribute__((always_inline)) -> size_t { // element index of the lane's four coefficients of band b in band row m
+  // element index of the lane's four coefficients of band b in band row m: in the slice records (a slice's band block
+  // row is bsw coefficients: neighbouring lanes read neighbouring 8 / 16 bytes of it, then the next slice's record), or,
+  // when the decoder laid this level's bands out as planes (BandPlanes), simply row m, column 4 * chunk of plane b
+  const long long bp = p.bp_base[comp];
+  auto rec_at = [&](int m, int b) __attribute__((always_inline)) -> size_t {
+    if (bp >= 0 && b > 0) return (size_t)bp + (size_t)mul24z((b - 1) * np + m, ow) + (size_t)chunk * 4;
     const int sv = m >> lbsh, r = m & (bsh - 1);
     return mul24z(sv * p.xs + sx, p.slice_coefs) + run0 + (b - b0) * bn + r * bsw + cc;
   };

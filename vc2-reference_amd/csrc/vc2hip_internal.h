@@ -107,8 +107,6 @@ struct LevelParams {
   int ll_to_store;            // forward, last level: LL goes to store band 0
   int dequant;                // inverse: apply scale() to store values
   unsigned *err;              // device error flags
-  int big_lut;                // set by the launcher: LDS holds subband tables for components of up to 2048 coefficients
-  float inv_scalar;           // set by the launcher: the smallest float >= 1 / scalar
   int debug_skip;             // -DVC2HIP_ABLATE builds only (tools/ablate_*.py): 1 no loads, 2 no lifting, 4 no stores
   int qmatrix[VC2_MAX_BANDS];
   // streaming kernels (vc2hip_dwt_stream.hip), set by vc2_stream_level_applicable
@@ -116,6 +114,9 @@ struct LevelParams {
   int st_out[3];                // chunks (8 samples) a strip owns
   int st_llps[3];               // log2 chunks per slice
   int st_py[3];                 // row pairs per segment
+  // inverse, streaming kernels: element offset (from the picture's store) of this level's HL band plane, LH and HH behind
+  // it, when the decoder keeps the level's bands as planes (BandPlanes below); -1: in the slice records
+  long long bp_base[3];
 };
 
 // Work-skipping switches for the timing experiments of tools/ablate_*.py exist only in a library built with
@@ -157,6 +158,20 @@ struct PackParams {
   unsigned long long *lens;   // per picture payload length (written by the last tile)
 };
 
+// Decode side only: the bands of the finest levels -- those the streaming inverse kernels read -- are kept as whole
+// planes behind the slice records instead of inside them.  The inverse transform then reads every band row with fully
+// coalesced loads (lanes = neighbouring columns) where the slice records give it 8 or 16 bytes per slice at slice-record
+// distance; the slice decoder, whose lanes are neighbouring slices, writes a band row piece per lane, also contiguous.
+// (The encoder keeps slice records throughout: its transform is not bound by the store writes.)
+constexpr int VC2_BP_MAX = 3;
+struct BandPlanes {
+  int levels;                       // finest levels kept as planes (0: none)
+  int from[3];                      // first coefficient of a component record that lives in a plane
+  long long base[3][VC2_BP_MAX];    // element offset, from the picture's store, of band 1 (HL) of level l; LH, HH follow
+  int ow[3][VC2_BP_MAX], np[3][VC2_BP_MAX];     // width / height of a band plane
+  int lbsh[3][VC2_BP_MAX], lbsw[3][VC2_BP_MAX]; // log2 of a slice's block in it
+};
+
 struct UnpackParams {
   const uint8_t *payload;
   long long payload_stride;
@@ -171,6 +186,8 @@ struct UnpackParams {
   int comp_n[3], comp_off[3];
   int prefix, scalar;
   unsigned *err;
+  BandPlanes bp;
+  int xs;                     // slices across
 };
 
 struct CbrParams {

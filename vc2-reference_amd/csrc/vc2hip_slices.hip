@@ -1544,6 +1544,20 @@ struct Reader32 {
   }
 };
 
+// Where coefficient j of a component record lives when the finest levels are kept as band planes (BandPlanes):
+// level l (0 = finest) holds the last 3 * 4^-l ... of the record; inside it band, block row, column.  Returns the element
+// offset from the picture's store of (slice sy, sx)'s coefficient, or -1 for the slice record.
+__device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int n, int j, int sy, int sx, int &lw, int &ow) {
+  lw = ow = 0;
+  if (j < bp.from[comp]) return -1;
+  int l = 0, start = n - (3 << (bp.lbsh[comp][0] + bp.lbsw[comp][0]));
+  while (j < start) { ++l; start -= 3 << (bp.lbsh[comp][l] + bp.lbsw[comp][l]); }
+  const int lh = bp.lbsh[comp][l], e = j - start;
+  lw = bp.lbsw[comp][l]; ow = bp.ow[comp][l];
+  const int b = e >> (lh + lw), rem = e & ((1 << (lh + lw)) - 1), r = rem >> lw, c = rem & ((1 << lw) - 1);
+  return (int)bp.base[comp][l] + (b * bp.np[comp][l] + (sy << lh) + r) * ow + (sx << lw) + c; // (a picture's store is < 2^31 elements)
+}
+
 __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
   constexpr int UNP_N = 64, UNP_PITCH = UNP_N + 8; // shorts per staging row (8 of slack), 16-byte aligned rows
   __shared__ __attribute__((aligned(16))) short stage[4][64 * UNP_PITCH];
@@ -1560,6 +1574,14 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
   const uint8_t *pay = pay0 - mis; // dword aligned: the reader's offsets count from here
   const size_t rec0 = (size_t)pic * p.store_stride + p.comp_off[comp]; // + slice * slice_coefs: a component record
   int32_t *wide = p.store_wide + rec0 + (size_t)(active ? slice : 0) * p.slice_coefs;
+  const int sy = (active ? slice : 0) / p.xs, sx = (active ? slice : 0) - sy * p.xs;
+  // an escape of coefficient j: the wide element with the index of the store element (record or band plane)
+  auto escape = [&](int j, int v) {
+    int lw, ow;
+    const int at = p.bp.levels ? band_plane_at(p.bp, comp, n, j, sy, sx, lw, ow) : -1;
+    if (at >= 0) p.store_wide[(size_t)pic * p.store_stride + (size_t)at] = v;
+    else wide[j] = v;
+  };
   Reader32 br;
   {
     unsigned pos = 0, len = 0;
@@ -1611,7 +1633,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
             const unsigned mag = ((1u << K) | compact_even32(body)) - 1u;
             const int neg = (int)((hi >> ((30 - 2 * K) & 31)) & 1u);
             int v = neg ? (int)(0u - mag) : (int)mag;
-            if (!St<int16_t>::fits(v)) { wide[base + cnt] = v; v = VC2_ST_SENTINEL; }
+            if (!St<int16_t>::fits(v)) { escape(base + cnt, v); v = VC2_ST_SENTINEL; }
             st[cnt++] = (short)v;
             used = 2 * K + 2;
           } else { // longer than 32 bits (outside the reference's domain): bit-serial, wraps like the oracle
@@ -1629,7 +1651,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
               v = (br.top() >> 31) ? (int)(0u - value) : (int)value;
               br.skip(pay, 1);
             }
-            if (!St<int16_t>::fits(v)) { wide[base + cnt] = v; v = VC2_ST_SENTINEL; }
+            if (!St<int16_t>::fits(v)) { escape(base + cnt, v); v = VC2_ST_SENTINEL; }
             st[cnt++] = (short)v;
           }
         }
@@ -1641,15 +1663,63 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
     // barrier, the four wavefronts of the workgroup drift apart freely.
     wave_lds_sync();
     const short *sw = stage[wave];
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const int rec_end = min(room, p.bp.from[comp] - base); // coefficients of this round that belong in the slice record
+    if (rec_end > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 8;
-      if (slice0 + r < p.n_slices && c < room) {
-        const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        const v4i vv = {v.x, v.y, v.z, v.w};
-        int16_t *dst = (int16_t *)p.store + rec0 + (size_t)(slice0 + r) * p.slice_coefs + base + c;
-        __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
+      for (int j = 0; j < 8; ++j) {
+        const int r = j * 8 + (lane >> 3), c = (lane & 7) * 8;
+        if (slice0 + r < p.n_slices && c < rec_end) {
+          const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
+          const v4i vv = {v.x, v.y, v.z, v.w};
+          int16_t *dst = (int16_t *)p.store + rec0 + (size_t)(slice0 + r) * p.slice_coefs + base + c;
+          __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
+        }
+      }
+    }
+    // band planes: neighbouring lanes are neighbouring slices, and their pieces of a band row are neighbours in the
+    // plane.  A block row of 8 coefficients is one 16-byte piece per lane; of 4, two 8-byte halves (two rows); of 16 or
+    // more, 2^(lw-3) pieces per slice: the lanes then take the pieces of the row in plane order (piece t of the run of
+    // 64 slices = slice t / P, piece t % P -- read from that slice's staging row), so that every store instruction
+    // still writes one contiguous kilobyte.  (The piece index is wave-uniform: level / band / row on the SALU.)
+    if (rec_end < room) {
+      for (int q = 0; q < 8;) {
+        const int j0 = base + 8 * q;
+        if (8 * q >= room) break;
+        if (j0 < p.bp.from[comp]) { ++q; continue; }
+        int lw, ow;
+        int at = band_plane_at(p.bp, comp, n, j0, sy, sx, lw, ow); // (lw, ow: the same in every lane)
+        if (!active) at = -1;
+        lw = __builtin_amdgcn_readfirstlane(lw);
+        if (lw >= 4) {
+          const int lp = lw - 3, P = 1 << lp; // pieces per block row
+          for (int k = 0; k < P; ++k) {
+            const int t = lane + 64 * k, sl = t >> lp, pp = t & (P - 1);
+            const int at_t = __shfl(at, sl);
+            if (at_t >= 0) {
+              const int4 v = *(const int4 *)(sw + sl * UNP_PITCH + 8 * (q + pp));
+              const v4i vv = {v.x, v.y, v.z, v.w};
+              int16_t *dst = (int16_t *)p.store + (size_t)pic * p.store_stride + (size_t)(at_t + 8 * pp);
+              __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
+            }
+          }
+          q += P;
+          continue;
+        }
+        if (at >= 0) {
+          int16_t *dst = (int16_t *)p.store + (size_t)pic * p.store_stride + (size_t)at;
+          const int4 v = *(const int4 *)(st + 8 * q);
+          if (lw == 3) {
+            const v4i vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
+          } else { // two rows of 4 (the host admits no narrower blocks)
+            const v2i lo = {v.x, v.y}, hi = {v.z, v.w};
+            __builtin_nontemporal_store(lo, (__attribute__((address_space(1))) v2i *)(size_t)dst);
+            __builtin_nontemporal_store(hi, (__attribute__((address_space(1))) v2i *)(size_t)(dst + ow));
+          }
+        }
+        ++q;
       }
     }
     wave_lds_sync();
@@ -1662,7 +1732,10 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
   }
 }
 
-void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s) {
+void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipStream_t s) {
+  UnpackParams p = p0;
+  if (!p.bp.levels) for (int c = 0; c < 3; ++c) p.bp.from[c] = 1 << 30; // everything in the slice records
+  if (p.xs < 1) p.xs = 1;
   vc2_prof_begin(L, "hq_unpack", s);
   if (p.store16) {
     VC2_LAUNCH(L, k_hq_unpack16, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
