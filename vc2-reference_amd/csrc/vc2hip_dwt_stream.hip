@@ -37,9 +37,12 @@ void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s) {
 
 namespace {
 
-constexpr int PF = 2;  // row pairs prefetched ahead, forward kernel (divides the ring length RL)
+#ifndef VC2_STREAM_PF
+#define VC2_STREAM_PF 2
+#endif
+constexpr int PF = VC2_STREAM_PF; // row pairs prefetched ahead, forward kernel (divides the ring length RL)
 #ifndef VC2_STREAM_PFI
-#define VC2_STREAM_PFI 2
+#define VC2_STREAM_PFI 1 // (with the band planes: 1 and 2 the same on the last level, 1 a little ahead below it; 4 slower)
 #endif
 constexpr int PFI = VC2_STREAM_PFI; // the same for the inverse kernel (four loads per pair and lane)
 
