@@ -1469,6 +1469,9 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 #ifndef UNP_LOOKS
 #define UNP_LOOKS 3
 #endif
+#ifndef VC2_UNP16_N
+#define VC2_UNP16_N 64
+#endif
 #ifndef UNP_LONG_EVERY
 #define UNP_LONG_EVERY 3
 #endif
@@ -1559,7 +1562,7 @@ __device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int
 }
 
 __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
-  constexpr int UNP_N = 64, UNP_PITCH = UNP_N + 8; // shorts per staging row (8 of slack), 16-byte aligned rows
+  constexpr int UNP_N = VC2_UNP16_N, UNP_PITCH = UNP_N + 8, PR = UNP_N / 8; // shorts per staging row (8 of slack), 16-byte aligned rows; pieces per row
   __shared__ __attribute__((aligned(16))) short stage[4][64 * UNP_PITCH];
   __shared__ unsigned lut[UNP_LUT_N];
   for (int i = threadIdx.x * 4; i < UNP_LUT_N; i += blockDim.x * 4) *(uint4 *)(lut + i) = *(const uint4 *)(g_unp_lut + i);
@@ -1668,8 +1671,8 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
     const int rec_end = min(room, p.bp.from[comp] - base); // coefficients of this round that belong in the slice record
     if (rec_end > 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = j * 8 + (lane >> 3), c = (lane & 7) * 8;
+      for (int j = 0; j < PR; ++j) {
+        const int r = j * (64 / PR) + lane / PR, c = (lane % PR) * 8;
         if (slice0 + r < p.n_slices && c < rec_end) {
           const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
           const v4i vv = {v.x, v.y, v.z, v.w};
@@ -1684,7 +1687,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
     // 64 slices = slice t / P, piece t % P -- read from that slice's staging row), so that every store instruction
     // still writes one contiguous kilobyte.  (The piece index is wave-uniform: level / band / row on the SALU.)
     if (rec_end < room) {
-      for (int q = 0; q < 8;) {
+      for (int q = 0; q < PR;) {
         const int j0 = base + 8 * q;
         if (8 * q >= room) break;
         if (j0 < p.bp.from[comp]) { ++q; continue; }
@@ -1692,8 +1695,8 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
         int at = band_plane_at(p.bp, comp, n, j0, sy, sx, lw, ow); // (lw, ow: the same in every lane)
         if (!active) at = -1;
         lw = __builtin_amdgcn_readfirstlane(lw);
-        if (lw >= 4) {
-          const int lp = lw - 3, P = 1 << lp; // pieces per block row
+        const int lp = lw - 3, P = lw >= 4 ? 1 << lp : 1; // pieces per block row
+        if (lw >= 4 && q + P <= PR && ((j0 >> 3) & (P - 1)) == 0) { // (a whole row inside the round; else piece by piece)
           for (int k = 0; k < P; ++k) {
             const int t = lane + 64 * k, sl = t >> lp, pp = t & (P - 1);
             const int at_t = __shfl(at, sl);
@@ -1710,7 +1713,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
         if (at >= 0) {
           int16_t *dst = (int16_t *)p.store + (size_t)pic * p.store_stride + (size_t)at;
           const int4 v = *(const int4 *)(st + 8 * q);
-          if (lw == 3) {
+          if (lw >= 3) {
             const v4i vv = {v.x, v.y, v.z, v.w};
             __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
           } else { // two rows of 4 (the host admits no narrower blocks)
