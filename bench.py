@@ -29,7 +29,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vc2-reference_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-OVERLAP_STREAMS = 4
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 W, H, CFMT, BITS = 3840, 2160, "422", 10
 KERNEL, DEPTH, U, A, Q, SCALAR = "DD97", 4, 1, 2, 16, 2
@@ -231,20 +230,10 @@ def main():
     dt_enc = timed(enc, args.steps)
     dt_dec = timed(dec, args.steps)
     hip.sync()
-    # ... and the library cutting the batch over four HIP streams (vc2hip_set_streams): kernels of different sub-batches
-    # overlap, the per-kernel durations then say little, so this is a number beside the line, not `value`
-    dt_ov = 0.0
-    if args.streams == 1 and B >= OVERLAP_STREAMS:
-        hip.set_streams(OVERLAP_STREAMS)
-        step()
-        dt_ov = timed(step, args.steps)
-        hip.sync()
-        hip.set_streams(1)
-
-    tmax = torch.tensor([dt, dt_noev, dt_enc, dt_dec, dt_ov], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, dt_noev, dt_enc, dt_dec], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, dt_noev, dt_enc, dt_dec, dt_ov = tmax.tolist()
+    dt, dt_noev, dt_enc, dt_dec = tmax.tolist()
 
     # ---- parity of what was timed: EVERY slot of the batch
     lens = d_len.cpu().numpy().astype(np.int64)
@@ -336,12 +325,6 @@ def main():
                          "path_frac": round(path_achieved / HBM_PEAK_GBS, 4),
                          "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kern.items())}},
             "value_without_kernel_events": round(total_px / dt_noev / 1e6, 1),
-            "overlapped": None if not dt_ov else {
-                "value": round(total_px / dt_ov / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(dt_ov / args.steps * 1e3, 4),
-                "streams": OVERLAP_STREAMS,
-                "method": f"the same {args.steps} steps with vc2hip_set_streams({OVERLAP_STREAMS}): the library codes the batch as "
-                          f"{OVERLAP_STREAMS} sub-batches on their own HIP streams, no kernel events; the outputs of this run are the "
-                          "ones the parity check below compares"},
             "parity_checked": parity,
             "e2e": e2e,
         }
