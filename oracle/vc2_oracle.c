@@ -1161,6 +1161,8 @@ int vc2o_encode_stream(const vc2o_params *p, const uint8_t *raw, int n_frames, u
     const uint32_t picture_number = (uint32_t)(pic + frame * frame_pics); /* Utils.cpp:52-63 */
     int num = picture_bytes, den = n_slices; /* utils::rationalise(pictureBytes, slices), EncodeStream.cpp:633 */
     { const int gg = gcd_i(num, den); if (gg) { num /= gg; den /= gg; } }
+    /* UnsignedVLC holds its code word in 32 bits (VLC.h:27): values from 65535 up are outside the reference's domain */
+    if (p->mode == 2 && (num >= 65535 || den >= 65535)) { rc = fail(VC2O_EINVAL, "oracle: LD slice bytes fraction does not fit a 32-bit exp-Golomb code"); goto done; }
     /* transform parameters, DataUnit.cpp:130-148 / :241-259 (whole picture: v3 flags by version;
      * fragments: always, :164-165 / :275-276) */
     uint8_t params[64];
@@ -1367,6 +1369,7 @@ int vc2o_decode_stream(const vc2o_params *p, const uint8_t *s, size_t len, uint8
         rc = vc2o_hq_unpack(data, data_len, &g, a, b, q[0], q[1], q[2], qidx, &used);
       } else { /* DecodeStream.cpp:312, :331-333: the reference halves the budget again for interlaced streams */
         sbytes = (int32_t *)realloc(sbytes, sizeof(int32_t) * n_slices);
+        if (b == 0) { rc = fail(VC2O_ESTREAM, "oracle: slice bytes denominator is zero"); break; }
         const int compressed = (a * g.y_slices * g.x_slices) / b;
         vc2o_slice_bytes(g.y_slices, g.x_slices, p->interlaced ? compressed / 2 : compressed, 1, sbytes);
         rc = vc2o_ld_unpack(data, data_len, &g, sbytes, q[0], q[1], q[2], qidx, &used);

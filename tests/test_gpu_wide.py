@@ -198,3 +198,15 @@ def test_cbr_search_register_kernel_and_hand_back(variants, oracle, amp, budget,
                 del os.environ["VC2HIP_CBR_GENERAL"]
             continue
         assert np.array_equal(got, want), name
+
+
+def test_random_wide_geometries_against_oracle():
+    """tools/fuzz_geometry.py in its wide mode: 120 random combinations with planes of 512 ... 2560 samples across, so
+    that streaming and tile transform levels, band planes and slice records, 16-bit and escaped coefficients mix."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_geometry.py"), "31", "120", "wide"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "120 cases, 0 bad" in out.stdout, out.stdout[-2000:]

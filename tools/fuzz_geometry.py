@@ -1,5 +1,10 @@
 """Random-geometry fuzz of the fused picture path against the oracle (GPU box): picture sizes (with padding),
-chroma formats, bit depths, kernels, depths, slice sizes, modes.  Prints the failing cases."""
+chroma formats, bit depths, kernels, depths, slice sizes, modes.  Prints the failing cases.
+
+  python tools/fuzz_geometry.py <seed> <cases> [wide]
+
+wide: planes of 512 ... 2560 samples across and a few slice rows, so that levels go through the streaming transform
+kernels and the decoder's band planes (the default sizes stay below them), mixed with tile-kernel levels underneath."""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vc2-reference_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,6 +14,7 @@ from vc2lib import load_oracle, make_params, KERNELS
 from synth import synth, noise_frame
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 rnd = random.Random(seed)
 hip = vc2hip_py.Vc2Hip(0)
 oracle = load_oracle()
@@ -24,6 +30,11 @@ while done < count:
     u = rnd.choice([1, 2, 3, 4]) * (2 if cf == "420" else 1)
     a = rnd.choice([1, 2, 3, 4, 6]) * (1 if cf == "444" else 2)
     ys, xs = rnd.choice([1, 2, 3, 5]), rnd.choice([1, 2, 3, 7])
+    if wide:
+        a = rnd.choice([1, 2, 4, 8]) * (1 if cf == "444" else 2)
+        xs = max(1, rnd.choice([512, 640, 768, 1024, 1536, 2560]) // (a * unit))
+        ys = rnd.choice([1, 2, 3])
+        u = rnd.choice([1, 2, 4]) * (2 if cf == "420" else 1)
     ph, pw = ys * u * unit, xs * a * unit
     # unpadded size: up to one unit less than padded (keeps chroma consistent: even crops)
     h = ph - rnd.choice([0, 0, 2, unit - 2 if unit > 2 else 0])
@@ -52,6 +63,8 @@ while done < count:
     except Exception as e:
         continue  # the reference itself rejects the case (scalar too small, index overflow, ...)
     done += 1
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case", done, desc, flush=True)
     try:
         dec, _ = oracle.decode_stream(p, stream, 1)
         fmt = vc2hip_py.picture_format(w, h, cf, bits, wb)
@@ -66,6 +79,8 @@ while done < count:
     except Exception as e:
         if "exceeds 65534" in str(e):
             continue  # outside the reference's own 32-bit code domain (undefined behaviour there): refused here
+        if "slice too large for the LD encode kernels" in str(e):
+            continue  # documented limit of the LD encoder here: a clean error
         bad += 1
         print("EXCEPTION", desc, str(e)[:120])
 print(f"seed {seed}: {done} cases, {bad} bad")
