@@ -154,10 +154,11 @@ template <int K, bool INV> struct VT {
 // Every sequence lives in a ring of RL register rows: the row of index i sits in slot i mod RL.  The walk is unrolled
 // RL times (phase U = (m - m0) mod RL is a compile-time constant inside each copy), so every slot number is a constant
 // and no row is ever moved; a new row overwrites the one RL indices older, which no consumer needs any more
-// (the window lengths of VT are at most RL for every wavelet but Fidelity).
-constexpr int RL = 4;
+// (the window lengths of VT are at most 4 for every wavelet but Fidelity, whose rings are 8 long).
+template <int K> constexpr int RLK = K == VC2HIP_FIDELITY ? 8 : 4; // (Fidelity: windows of 8 rows; the slots of a ring that no consumer reads any more are dead registers)
 template <int K, bool INV> struct VEng {
   using T = VT<K, INV>;
+  static constexpr int RL = RLK<K>;
   static_assert(T::len_raw(false) <= RL && T::len_raw(true) <= RL && T::len_x(0) <= RL && T::len_x(1) <= RL &&
                 (T::N < 3 || (T::len_x(2) <= RL && T::len_x(3) <= RL)), "row ring too short for this wavelet");
   Row rw[2][RL]; // raw rows: [0] even rows, [1] odd rows
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, false>;
   using T = typename VE::T;
+  constexpr int RL = RLK<K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ST *stg = (ST *)smem;
   const int lane = threadIdx.x;
@@ -426,7 +428,8 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
       if (r == bsh - 1) flush_sv = sv;                                                                       \
     } else ll_k = -1;                                                                                        \
   }
-#define VC2_FWD_BLOCK(MODE) { VC2_FWD_ITER(0, MODE) VC2_FWD_ITER(1, MODE) VC2_FWD_ITER(2, MODE) VC2_FWD_ITER(3, MODE) }
+#define VC2_FWD_BLOCK(MODE) { VC2_FWD_ITER(0, MODE) VC2_FWD_ITER(1, MODE) VC2_FWD_ITER(2, MODE) VC2_FWD_ITER(3, MODE) \
+    if constexpr (RL == 8) { VC2_FWD_ITER(4, MODE) VC2_FWD_ITER(5, MODE) VC2_FWD_ITER(6, MODE) VC2_FWD_ITER(7, MODE) } }
   int mb = m0;
   if (m0 == 0) { // (the host admits planes of at least 2 * RL row pairs: this block lies inside the plane)
     VC2_FWD_BLOCK(1)
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, true>;
   using T = typename VE::T;
+  constexpr int RL = RLK<K>;
   __shared__ int qtab[360]; // quant_factor / quant_offset / domain limit by adjusted index
   const int lane = threadIdx.x;
   const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
@@ -656,7 +660,8 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
       pend_k = k;                                                                                            \
     } else pend_k = -1;                                                                                      \
   }
-#define VC2_INV_BLOCK(MODE) { VC2_INV_ITER(0, MODE) VC2_INV_ITER(1, MODE) VC2_INV_ITER(2, MODE) VC2_INV_ITER(3, MODE) }
+#define VC2_INV_BLOCK(MODE) { VC2_INV_ITER(0, MODE) VC2_INV_ITER(1, MODE) VC2_INV_ITER(2, MODE) VC2_INV_ITER(3, MODE) \
+    if constexpr (RL == 8) { VC2_INV_ITER(4, MODE) VC2_INV_ITER(5, MODE) VC2_INV_ITER(6, MODE) VC2_INV_ITER(7, MODE) } }
   int mb = m0;
   if (m0 == 0) {
     VC2_INV_BLOCK(1)
@@ -704,6 +709,7 @@ template <bool INV, class ST> int dispatch_stream(Launcher &L, int kernel, bool 
     VC2_CASE(VC2HIP_DD137)
     VC2_CASE(VC2HIP_HAAR0)
     VC2_CASE(VC2HIP_HAAR1)
+    VC2_CASE(VC2HIP_FIDELITY)
     VC2_CASE(VC2HIP_DAUB97)
   }
 #undef VC2_CASE
@@ -717,6 +723,7 @@ int halo_lanes_of(int kernel) {
     case VC2HIP_DD137: return halo_lanes<VC2HIP_DD137>();
     case VC2HIP_HAAR0: return halo_lanes<VC2HIP_HAAR0>();
     case VC2HIP_HAAR1: return halo_lanes<VC2HIP_HAAR1>();
+    case VC2HIP_FIDELITY: return halo_lanes<VC2HIP_FIDELITY>();
     case VC2HIP_DAUB97: return halo_lanes<VC2HIP_DAUB97>();
   }
   return -1;
@@ -728,7 +735,7 @@ bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // The streaming kernels apply when every active component has a plane at least 64 chunks wide without horizontal
 // padding, power-of-two slice footprints of at least one chunk, band blocks that move in whole 16-byte pieces, and
 // raw samples (edge levels) in 16-bit words.  Fills the st_* fields of p and returns the dynamic LDS bytes, 0 if not
-// applicable.  (Fidelity's 8-tap steps keep 20 rows of 8 values per lane alive: it stays with the tile kernels.)
+// applicable.  (Fidelity's 8-tap steps keep ~21 rows of 8 values per lane alive: rings of 8, two wavefronts per SIMD.)
 size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool inverse, bool store16, int n_pictures) {
   const int hln = halo_lanes_of(kernel);
   if (hln < 0) return 0;
@@ -739,7 +746,8 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     p.st_strips[c] = p.st_segs[c] = 0;
     if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
     const int w = p.in_w[c], h = p.in_h[c], fw = p.fw[c], fh = p.fh[c];
-    if (w < 512 || (w & 7) || (h & 7) || h < 16) return 0; // whole blocks of four row pairs (see VEng)
+    const int rl = kernel == VC2HIP_FIDELITY ? 8 : 4;
+    if (w < 512 || (w & 7) || (h % (2 * rl)) || h < 4 * rl) return 0; // whole blocks of `rl` row pairs (see VEng)
     if (edge && (p.word_bytes != 2 || p.pic_w[c] != w)) return 0;
     if (!pow2i(fw) || !pow2i(fh) || fw < 8 || fh < 2 || fw > 64 * 8) return 0;
     const int bsh = fh / 2, bsw = fw / 2;
@@ -765,7 +773,8 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     if (!p.st_strips[c]) continue;
     const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2;
     int py = std::max(64, bsh);
-    while (py > std::max(16, bsh) && (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures * 3 < 16384) py /= 2;
+    const int py_min = kernel == VC2HIP_FIDELITY ? 64 : 16; // (a segment runs in over sum of reaches: 7 pairs for Fidelity)
+    while (py > std::max(py_min, bsh) && (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures * 3 < 16384) py /= 2;
     static const int force_py = [] { const char *e = getenv("VC2HIP_STREAM_PY"); return e ? atoi(e) : 0; }();
     if (force_py > 0) py = force_py;
     py = ((py + bsh - 1) / bsh) * bsh;
