@@ -192,17 +192,17 @@ template <int K, bool INV> struct VEng {
   }
   // The steady state carries no edge handling: a conditional fill of a ring would be turned into selects that read every
   // slot in every iteration and keep all of them alive.
-  // Walks start at multiples of RL and planes hold a multiple of RL row pairs (host check), so the phase is m mod RL
-  // everywhere and every edge decision is known at compile time:
+  // Walks start at multiples of RL, so the phase is m mod RL everywhere and every edge decision is known at compile time
+  // (the bottom of a plane whose pair count is not a multiple of RL: one tail per remainder, see the kernels):
   // MODE 0: steady state.  MODE 1: the first RL iterations of a walk that starts at the plane's top (a sequence
-  // receives its index 0 in iteration off(P)).  MODE 2: the OFFL iterations below the plane's last pair (m = np + U:
+  // receives its index 0 in iteration off(P)).  MODE 2: the OFFL iterations below the plane's last pair (m = np + D:
   // nothing is loaded; position P repeats its last row once U + 1 > off(P)).
-  template <int U, int P, int MODE> __device__ __forceinline__ void pos(int m, int np) {
+  template <int U, int P, int MODE, int D> __device__ __forceinline__ void pos(int m, int np) {
     if constexpr (P < T::N) {
       constexpr int dst = sl(U - T::off(P));
       constexpr int dmin = T::dmin(P), dmax = T::dmax(P);
       const int c = m - T::off(P);
-      if constexpr (MODE == 2 && (U + 1 > T::off(P))) copy<sl(U - T::off(P) - 1), dst>(x[P]); // below the plane: the last pair again
+      if constexpr (MODE == 2 && (D + 1 > T::off(P))) copy<sl(U - T::off(P) - 1), dst>(x[P]); // below the plane: the last pair again
       else {
         Row W[dmax - dmin + 1]; // rows c_P + dmin .. c_P + dmax of what position P reads
 #pragma unroll
@@ -216,14 +216,15 @@ template <int K, bool INV> struct VEng {
         else o = x[P - 2][dst];
         put<dst>(x[P], INV ? o - d : o + d, MODE == 1 && U == T::off(P));
       }
-      pos<U, P + 1, MODE>(m, np);
+      pos<U, P + 1, MODE, D>(m, np);
     }
   }
-  // row pair m (even row re, odd row ro; ignored below the plane) enters at phase U; afterwards pair m - OFFL is complete
-  template <int U, int MODE> __device__ __forceinline__ void step(int m, int np, const Row &re, const Row &ro) {
+  // row pair m (even row re, odd row ro; ignored below the plane) enters at phase U; afterwards pair m - OFFL is complete.
+  // MODE 2: m = np + D, D = 0 .. OFFL-1 (the phase is (np + D) mod RL: planes need not hold a multiple of RL pairs)
+  template <int U, int MODE, int D = U> __device__ __forceinline__ void step(int m, int np, const Row &re, const Row &ro) {
     if constexpr (MODE == 2) { copy<sl(U - 1), U>(rw[0]); copy<sl(U - 1), U>(rw[1]); }
     else { put<U>(rw[0], re, MODE == 1 && U == 0); put<U>(rw[1], ro, MODE == 1 && U == 0); }
-    pos<U, 0, MODE>(m, np);
+    pos<U, 0, MODE, D>(m, np);
   }
   // the completed pair m - OFFL: its even / odd row in the latest version
   template <int U> __device__ __forceinline__ const Row &out(bool odd_row) const {
@@ -265,7 +266,9 @@ __device__ __forceinline__ size_t mul24z(int a, int b) { return (size_t)__umul24
 // ------------------------------------------------------------------------------------------
 // forward level
 // ------------------------------------------------------------------------------------------
-template <int K, bool FIRST, class ST>
+// TAIL: the plane's pair count need not be a multiple of the ring length (its own instantiation, levels below the first
+// only: the tails cost registers -- 154 instead of 113 -- and the level-0 kernels of every BASELINE format do not need them)
+template <int K, bool FIRST, class ST, bool TAIL = false>
 __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, false>;
@@ -398,9 +401,10 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   static_assert(RL % PF == 0, "the prefetch ring shares the unrolled walk of the row rings");
   int ll_k = -1, flush_sv = -1; // deferred stores: LL row of pair ll_k (values in llv), image of block row flush_sv
   int llv[4] = {0, 0, 0, 0};
-#define VC2_FWD_ITER(U, MODE)                                                                                \
-  if constexpr (MODE != 2 || U < T::OFFL) {                                                                  \
-    const int m = mb + U;                                                                                    \
+#define VC2_FWD_ITER(U, MODE) VC2_FWD_ITERD(U, MODE, U)
+#define VC2_FWD_ITERD(U, MODE, D)                                                                            \
+  if constexpr (MODE != 2 || D < T::OFFL) {                                                                  \
+    const int m = MODE == 2 ? np + D : mb + U;                                                               \
     Row re, ro;                                                                                              \
     if constexpr (MODE != 2) {                                                                               \
       convert(min(m, mload), U % PF, 0, re);                                                                 \
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
       h_lift<K, false>(re);                                                                                  \
       h_lift<K, false>(ro);                                                                                  \
     }                                                                                                        \
-    eng.template step<U, MODE>(m, np, re, ro);                                                               \
+    eng.template step<U, MODE, D>(m, np, re, ro);                                                            \
     const int k = m - T::OFFL;                                                                               \
     if (k >= sp.kA && k < sp.kB) {                                                                           \
       const Row &oe = eng.template out<U>(false), &oo = eng.template out<U>(true);                           \
@@ -435,13 +439,24 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
     VC2_FWD_BLOCK(1)
     mb += RL;
   }
-  for (; mb < mend; mb += RL) VC2_FWD_BLOCK(0)
-  if (last) {
-    mb = np;
-    VC2_FWD_BLOCK(2)
+  const int mstop = last ? (np & ~(RL - 1)) : mend; // whole steady blocks (a walk that does not end at the bottom may run over)
+  for (; mb < mstop; mb += RL) VC2_FWD_BLOCK(0)
+  if (last) { // the np mod RL pairs left, then the OFFL iterations below the plane at the phases that follow
+#define VC2_FWD_DRAIN(R) { VC2_FWD_ITERD((R + 0) % RL, 2, 0) VC2_FWD_ITERD((R + 1) % RL, 2, 1) VC2_FWD_ITERD((R + 2) % RL, 2, 2) \
+    VC2_FWD_ITERD((R + 3) % RL, 2, 3) VC2_FWD_ITERD((R + 4) % RL, 2, 4) VC2_FWD_ITERD((R + 5) % RL, 2, 5) VC2_FWD_ITERD((R + 6) % RL, 2, 6) }
+    if constexpr (RL == 4 && TAIL) {
+      switch (np & 3) {
+        case 0: VC2_FWD_DRAIN(0) break;
+        case 1: VC2_FWD_ITER(0, 0) VC2_FWD_DRAIN(1) break;
+        case 2: VC2_FWD_ITER(0, 0) VC2_FWD_ITER(1, 0) VC2_FWD_DRAIN(2) break;
+        default: VC2_FWD_ITER(0, 0) VC2_FWD_ITER(1, 0) VC2_FWD_ITER(2, 0) VC2_FWD_DRAIN(3) break;
+      }
+    } else VC2_FWD_DRAIN(0) // (no TAIL, and rings of eight -- eight tails would not fit the instruction cache: the host admits whole blocks only)
+#undef VC2_FWD_DRAIN
   }
 #undef VC2_FWD_BLOCK
 #undef VC2_FWD_ITER
+#undef VC2_FWD_ITERD
   if (ll_k >= 0 && own) S_::store4(llp + mul24z(ll_k, ow), llp_w + mul24z(ll_k, ow), llv[0], llv[1], llv[2], llv[3]);
   if (flush_sv >= 0) flush(flush_sv);
 }
@@ -459,7 +474,7 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
   return v < 0 ? (int)(0u - (unsigned)a) : a;
 }
 
-template <int K, bool FINAL, class ST>
+template <int K, bool FINAL, class ST, bool TAIL = false>
 __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, true>;
@@ -638,9 +653,10 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   Pend pe, po;
 #pragma unroll
   for (int k = 0; k < OW; ++k) { pe.w[k] = 0; po.w[k] = 0; }
-#define VC2_INV_ITER(U, MODE)                                                                                \
-  if constexpr (MODE != 2 || U < T::OFFL) {                                                                  \
-    const int m = mb + U;                                                                                    \
+#define VC2_INV_ITER(U, MODE) VC2_INV_ITERD(U, MODE, U)
+#define VC2_INV_ITERD(U, MODE, D)                                                                            \
+  if constexpr (MODE != 2 || D < T::OFFL) {                                                                  \
+    const int m = MODE == 2 ? np + D : mb + U;                                                               \
     Row re, ro;                                                                                              \
     if constexpr (MODE != 2) {                                                                               \
       const int ml = min(m, mload), sv = ml >> lbsh;                                                         \
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     }                                                                                                        \
     if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }                               \
     if constexpr (MODE != 2) in_fetch(min(m + PFI, mload), U % PFI);                                         \
-    eng.template step<U, MODE>(m, np, re, ro);                                                               \
+    eng.template step<U, MODE, D>(m, np, re, ro);                                                            \
     const int k = m - T::OFFL;                                                                               \
     if (k >= sp.kA && k < sp.kB) {                                                                           \
       Row oe = eng.template out<U>(false), oo = eng.template out<U>(true);                                   \
@@ -667,32 +683,43 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     VC2_INV_BLOCK(1)
     mb += RL;
   }
-  for (; mb < mend; mb += RL) VC2_INV_BLOCK(0)
-  if (last) {
-    mb = np;
-    VC2_INV_BLOCK(2)
+  const int mstop = last ? (np & ~(RL - 1)) : mend;
+  for (; mb < mstop; mb += RL) VC2_INV_BLOCK(0)
+  if (last) { // as in the forward kernel
+#define VC2_INV_DRAIN(R) { VC2_INV_ITERD((R + 0) % RL, 2, 0) VC2_INV_ITERD((R + 1) % RL, 2, 1) VC2_INV_ITERD((R + 2) % RL, 2, 2) \
+    VC2_INV_ITERD((R + 3) % RL, 2, 3) VC2_INV_ITERD((R + 4) % RL, 2, 4) VC2_INV_ITERD((R + 5) % RL, 2, 5) VC2_INV_ITERD((R + 6) % RL, 2, 6) }
+    if constexpr (RL == 4 && TAIL) {
+      switch (np & 3) {
+        case 0: VC2_INV_DRAIN(0) break;
+        case 1: VC2_INV_ITER(0, 0) VC2_INV_DRAIN(1) break;
+        case 2: VC2_INV_ITER(0, 0) VC2_INV_ITER(1, 0) VC2_INV_DRAIN(2) break;
+        default: VC2_INV_ITER(0, 0) VC2_INV_ITER(1, 0) VC2_INV_ITER(2, 0) VC2_INV_DRAIN(3) break;
+      }
+    } else VC2_INV_DRAIN(0)
+#undef VC2_INV_DRAIN
   }
 #undef VC2_INV_BLOCK
 #undef VC2_INV_ITER
+#undef VC2_INV_ITERD
   if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }
 }
 
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-template <int K, bool EDGE, bool INV, class ST>
+template <int K, bool EDGE, bool INV, class ST, bool TAIL>
 void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds, hipStream_t s) {
   int gx = 0, gy = 0;
   for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.st_strips[c]); gy = std::max(gy, p.st_segs[c]); }
   dim3 grid(gx, gy, 3 * n_pictures), block(64);
   if constexpr (INV) {
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
-    vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST>, 64 * 1024);
-    VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST>), grid, block, lds, s, p);
+    vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST, TAIL>, 64 * 1024);
+    VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST, TAIL>), grid, block, lds, s, p);
   } else {
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
-    vc2_allow_lds((const void *)k_fwd_stream<K, EDGE, ST>, 64 * 1024);
-    VC2_LAUNCH(L, (k_fwd_stream<K, EDGE, ST>), grid, block, lds, s, p);
+    vc2_allow_lds((const void *)k_fwd_stream<K, EDGE, ST, TAIL>, 64 * 1024);
+    VC2_LAUNCH(L, (k_fwd_stream<K, EDGE, ST, TAIL>), grid, block, lds, s, p);
   }
   vc2_prof_end(L, s);
 }
@@ -700,8 +727,10 @@ void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds
 template <bool INV, class ST> int dispatch_stream(Launcher &L, int kernel, bool edge, const LevelParams &p, int n, size_t lds, hipStream_t s) {
 #define VC2_CASE(KK)                                                        \
   case KK:                                                                  \
-    if (edge) launch_stream<KK, true, INV, ST>(L, p, n, lds, s);            \
-    else launch_stream<KK, false, INV, ST>(L, p, n, lds, s);                \
+    if (edge) launch_stream<KK, true, INV, ST, false>(L, p, n, lds, s);     \
+    else if (p.st_tail) {                                                   \
+      if constexpr (KK != VC2HIP_FIDELITY) launch_stream<KK, false, INV, ST, true>(L, p, n, lds, s); \
+    } else launch_stream<KK, false, INV, ST, false>(L, p, n, lds, s);       \
     return 0;
   switch (kernel) {
     VC2_CASE(VC2HIP_DD97)
@@ -742,12 +771,18 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
   const int elem = store16 ? 2 : 4, ep = 16 / elem;
   size_t lds = 0;
   long long waves = 0;
+  p.st_tail = 0;
   for (int c = 0; c < 3; ++c) {
     p.st_strips[c] = p.st_segs[c] = 0;
     if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
     const int w = p.in_w[c], h = p.in_h[c], fw = p.fw[c], fh = p.fh[c];
     const int rl = kernel == VC2HIP_FIDELITY ? 8 : 4;
-    if (w < 512 || (w & 7) || (h % (2 * rl)) || h < 4 * rl) return 0; // whole blocks of `rl` row pairs (see VEng)
+    // whole blocks of `rl` row pairs; below the first / last level, rings of four: any even height (the TAIL kernels)
+    if (w < 512 || (w & 7) || (h & 1) || h < 4 * rl) return 0;
+    if (h % (2 * rl)) {
+      if (edge || rl == 8) return 0;
+      p.st_tail = 1;
+    }
     if (edge && (p.word_bytes != 2 || p.pic_w[c] != w)) return 0;
     if (!pow2i(fw) || !pow2i(fh) || fw < 8 || fh < 2 || fw > 64 * 8) return 0;
     const int bsh = fh / 2, bsw = fw / 2;

@@ -114,6 +114,7 @@ struct LevelParams {
   int st_out[3];                // chunks (8 samples) a strip owns
   int st_llps[3];               // log2 chunks per slice
   int st_py[3];                 // row pairs per segment
+  int st_tail;                  // some plane's pair count is not a multiple of four: the TAIL instantiation
   // inverse, streaming kernels: element offset (from the picture's store) of this level's HL band plane, LH and HH behind
   // it, when the decoder keeps the level's bands as planes (BandPlanes below); -1: in the slice records
   long long bp_base[3];
