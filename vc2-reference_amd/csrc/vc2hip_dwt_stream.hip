@@ -37,6 +37,9 @@ void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s) {
 
 namespace {
 
+#ifndef VC2_STREAM_MIN_W
+#define VC2_STREAM_MIN_W 192 // narrowest plane: a third of the wavefront's lanes at work (below it the tile kernels)
+#endif
 #ifndef VC2_STREAM_PF
 #define VC2_STREAM_PF 2
 #endif
@@ -91,7 +94,9 @@ template <int K> constexpr int halo_lanes() {
 // ------------------------------------------------------------------------------------------
 // horizontal lifting of one row in registers
 // ------------------------------------------------------------------------------------------
-template <int K, int S, bool INV> __device__ __forceinline__ void h_step(Row &r) {
+// redge: this lane holds the plane's last chunk, but is not the wavefront's last lane (planes narrower than a wavefront):
+// its taps beyond the chunk clamp to its own last pair like the last lane's do
+template <int K, int S, bool INV> __device__ __forceinline__ void h_step(Row &r, bool redge) {
   constexpr bool odd = step_targets_odd<K, S>();
   constexpr int dmin = step_dmin<K, S>(), dmax = step_dmax<K, S>();
   constexpr int TO = odd ? 4 : 0, UO = odd ? 0 : 4; // target / source parity inside the row
@@ -99,8 +104,10 @@ template <int K, int S, bool INV> __device__ __forceinline__ void h_step(Row &r)
 #pragma unroll
   for (int j = dmin; j <= 3 + dmax; ++j) {
     if (j < 0) W[j - dmin] = dppm<0x138>(r[UO], r[UO + 4 + j]);           // left neighbour (wave_shr:1)
-    else if (j > 3) W[j - dmin] = dppm<0x130>(r[UO + 3], r[UO + j - 4]);  // right neighbour (wave_shl:1)
-    else W[j - dmin] = r[UO + j];
+    else if (j > 3) {                                                     // right neighbour (wave_shl:1)
+      const int nb = dppm<0x130>(r[UO + 3], r[UO + j - 4]);
+      W[j - dmin] = redge ? r[UO + 3] : nb;
+    } else W[j - dmin] = r[UO + j];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -108,16 +115,16 @@ template <int K, int S, bool INV> __device__ __forceinline__ void h_step(Row &r)
     r[TO + i] = INV ? r[TO + i] - d : r[TO + i] + d;
   }
 }
-template <int K, bool INV> __device__ __forceinline__ void h_lift(Row &r) {
+template <int K, bool INV> __device__ __forceinline__ void h_lift(Row &r, bool redge) {
   constexpr int N = WT<K>::nsteps;
   if constexpr (!INV) {
-    h_step<K, 0, false>(r);
-    h_step<K, 1, false>(r);
-    if constexpr (N == 4) { h_step<K, 2, false>(r); h_step<K, 3, false>(r); }
+    h_step<K, 0, false>(r, redge);
+    h_step<K, 1, false>(r, redge);
+    if constexpr (N == 4) { h_step<K, 2, false>(r, redge); h_step<K, 3, false>(r, redge); }
   } else {
-    if constexpr (N == 4) { h_step<K, 3, true>(r); h_step<K, 2, true>(r); }
-    h_step<K, 1, true>(r);
-    h_step<K, 0, true>(r);
+    if constexpr (N == 4) { h_step<K, 3, true>(r, redge); h_step<K, 2, true>(r, redge); }
+    h_step<K, 1, true>(r, redge);
+    h_step<K, 0, true>(r, redge);
   }
 }
 
@@ -248,7 +255,7 @@ template <int K> __device__ __forceinline__ bool strip_of_block(const LevelParam
   const int strip = blockIdx.x, seg = blockIdx.y;
   if (strip >= p.st_strips[comp] || seg >= p.st_segs[comp]) return false;
   const int nch = p.in_w[comp] >> 3, np = p.in_h[comp] >> 1, out = p.st_out[comp];
-  s.c0 = min(max(strip * out - HLN, 0), nch - 64);
+  s.c0 = max(min(max(strip * out - HLN, 0), nch - 64), 0); // (a plane narrower than 64 chunks: one strip from chunk 0, idle lanes behind it)
   s.lo = strip * out - s.c0;
   s.hi = min((strip + 1) * out, nch) - s.c0;
   s.nsl = (s.hi - s.lo) >> p.st_llps[comp];
@@ -282,8 +289,9 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   if (!strip_of_block<K>(p, comp, sp)) return;
   constexpr int ACC = WT<K>::accuracy;
   const int in_h = p.in_h[comp], in_w = p.in_w[comp], np = in_h >> 1;
-  const int chunk = sp.c0 + lane;
+  const int chunk = min(sp.c0 + lane, (in_w >> 3) - 1); // (lanes behind a narrow plane repeat its last chunk and own nothing)
   const bool own = lane >= sp.lo && lane < sp.hi;
+  const bool redge = sp.c0 + lane == (in_w >> 3) - 1 && lane != 63;
 
   // ---- input rows
   const uint8_t *raw = nullptr;
@@ -414,8 +422,8 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
     if (flush_sv >= 0) { flush(flush_sv); flush_sv = -1; }                                                   \
     if constexpr (MODE != 2) {                                                                               \
       fetch(min(m + PF, mload), U % PF);                                                                     \
-      h_lift<K, false>(re);                                                                                  \
-      h_lift<K, false>(ro);                                                                                  \
+      h_lift<K, false>(re, redge);                                                                           \
+      h_lift<K, false>(ro, redge);                                                                           \
     }                                                                                                        \
     eng.template step<U, MODE, D>(m, np, re, ro);                                                            \
     const int k = m - T::OFFL;                                                                               \
@@ -496,8 +504,9 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   wave_sync();
   constexpr int ACC = WT<K>::accuracy;
   const int out_h = p.in_h[comp], out_w = p.in_w[comp], np = out_h >> 1, ow = out_w >> 1;
-  const int chunk = sp.c0 + lane;
+  const int chunk = min(sp.c0 + lane, (out_w >> 3) - 1); // (lanes behind a narrow plane repeat its last chunk and own nothing)
   const bool own = lane >= sp.lo && lane < sp.hi;
+  const bool redge = sp.c0 + lane == (out_w >> 3) - 1 && lane != 63;
   const int fh = p.fh[comp], fw = p.fw[comp];
   const int bsh = fh >> 1, bsw = fw >> 1, lbsh = ilog2d(bsh), bn = bsh * bsw;
   const int b0 = p.ll_from_store ? 0 : 1;               // first band that comes from the store
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   constexpr int OW = (FINAL || S_::narrow) ? 4 : 8;
   struct Pend { unsigned w[OW]; };
   auto make_out = [&](int y, Row &r, Pend &o) __attribute__((always_inline)) {
-    h_lift<K, true>(r);
+    h_lift<K, true>(r, redge);
     int s[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s[2 * k] = r[k]; s[2 * k + 1] = r[4 + k]; }
@@ -778,7 +787,7 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     const int w = p.in_w[c], h = p.in_h[c], fw = p.fw[c], fh = p.fh[c];
     const int rl = kernel == VC2HIP_FIDELITY ? 8 : 4;
     // whole blocks of `rl` row pairs; below the first / last level, rings of four: any even height (the TAIL kernels)
-    if (w < 512 || (w & 7) || (h & 1) || h < 4 * rl) return 0;
+    if (w < VC2_STREAM_MIN_W || (w & 7) || (h & 1) || h < 4 * rl) return 0;
     if (h % (2 * rl)) {
       if (edge || rl == 8) return 0;
       p.st_tail = 1;
