@@ -210,3 +210,31 @@ def test_random_wide_geometries_against_oracle():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "120 cases, 0 bad" in out.stdout, out.stdout[-2000:]
+
+
+def test_cbr_decode_offsets_from_budgets_and_fallback(variants, oracle):
+    """Decoding with HQ_CBR coding parameters claims the slice offsets from the byte budgets and verifies them against the
+    length bytes; a stream that does not fill the budgets (here: a constant-quantiser stream, and a CBR stream of another
+    budget) falls back to the general slice index and decodes to the same picture."""
+    hip = variants["default"]
+    w, h, depth = 1024, 64, 3
+    raw = synth(w, h, "422", 10, 75)
+    # a conforming CBR stream
+    p = make_params(w, h, "422", 10, "DD97", depth, 1, 2, mode="HQ_CBR", s=30000, scalar=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", depth, 1, 2, mode="HQ_CBR", s=30000, scalar=1)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+    # the same payload under CBR parameters of another budget: the claim fails, the index finds the slices
+    _, cp_other = _fmt_cp(hip, w, h, "422", 10, "DD97", depth, 1, 2, mode="HQ_CBR", s=31000, scalar=1)
+    assert hip.decode_picture(payload, fmt, cp_other) == dec
+    # a constant-quantiser payload under CBR parameters
+    pq = make_params(w, h, "422", 10, "DD97", depth, 1, 2, q=9, scalar=1)
+    sq = oracle.encode_stream(pq, raw, 1)
+    dq, _ = oracle.decode_stream(pq, sq, 1)
+    _, cpq = _fmt_cp(hip, w, h, "422", 10, "DD97", depth, 1, 2, q=9, scalar=1)
+    payq, _ = hip.encode_picture_hq(raw, fmt, cpq)
+    assert hip.decode_picture(payq, fmt, cp) == dq
+    assert hip.decode_picture(payq, fmt, cpq) == dq

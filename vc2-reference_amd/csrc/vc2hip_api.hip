@@ -130,6 +130,7 @@ struct vc2hip_ctx {
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
   bool allow_planes = true; // decode: band planes for the streaming levels (A/B and test switch VC2HIP_NO_BANDPLANES)
+  bool allow_cbr_index = true; // decode of HQ_CBR pictures: offsets from the budgets, verified (VC2HIP_NO_CBR_INDEX=1: always the general index)
   bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
   // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
@@ -299,6 +300,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_STREAM"); c->allow_stream = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_BANDPLANES"); c->allow_planes = !(e && e[0] == '1'); }
+  { const char *e = getenv("VC2HIP_NO_CBR_INDEX"); c->allow_cbr_index = !(e && e[0] == '1'); }
 #ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
 #endif
@@ -1098,15 +1100,24 @@ extern "C" int vc2hip_hq_pack(vc2hip_ctx *c, const int32_t *y, const int32_t *u,
 }
 
 // slice offsets of one VBR payload already on the device
+// cbr_budget / cbr_offs / cbr_total (device tables of the HQ_CBR slice budgets, or null): the offsets are first claimed
+// from the budgets and checked against the stream (vc2_launch_cbr_index); the general index only works if that fails
 static int build_index(vc2hip_ctx *c, const uint8_t *d_pay, long long stride, const unsigned long long *d_lens, int n, int ns,
-                       int prefix, int scalar, uint32_t **d_offs_out) {
+                       int prefix, int scalar, uint32_t **d_offs_out, const int32_t *cbr_budget = nullptr,
+                       const uint32_t *cbr_offs = nullptr, uint64_t cbr_total = 0) {
   uint32_t *d_offs; void *ws;
   NEED(c, B_OFFS, (size_t)n * ns * 4, d_offs);
   const size_t wsb = vc2_slice_index_workspace(n, (size_t)stride, prefix, scalar);
   NEED(c, B_INDEX, wsb, ws);
   HIPCHK(c, hipMemsetAsync(d_offs, 0xFF, (size_t)n * ns * 4, c->stream)); // unreachable slices read past the payload
+  unsigned *bad = nullptr;
+  if (cbr_budget && c->allow_cbr_index) {
+    bad = (unsigned *)((char *)c->d_err + 64); // (the error word's block: 256 bytes, the LD tables behind them)
+    HIPCHK(c, hipMemsetAsync(bad, 0, sizeof(unsigned), c->stream));
+  }
   vc2_prof_break(c->L);
-  vc2_launch_slice_index(c->L, d_pay, stride, d_lens, d_offs, ns, prefix, scalar, n, c->d_err, c->stream, ws, wsb);
+  if (bad) vc2_launch_cbr_index(c->L, d_pay, stride, d_lens, cbr_budget, cbr_offs, cbr_total, d_offs, ns, prefix, scalar, n, bad, c->stream);
+  vc2_launch_slice_index(c->L, d_pay, stride, d_lens, d_offs, ns, prefix, scalar, n, c->d_err, c->stream, ws, wsb, bad);
   *d_offs_out = d_offs;
   return VC2HIP_OK;
 }
@@ -1516,8 +1527,22 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
   if (!ld) {
     if (!d_lens || cp->scalar < 1 || cp->prefix < 0) return set_err(c, VC2HIP_EINVAL);
     uint32_t *d_offs;
+    const int32_t *d_cb = nullptr; const uint32_t *d_co = nullptr; uint64_t cbr_total = 0;
+    if (cp->mode == VC2HIP_HQ_CBR && cp->compressed_bytes > 0 && c->allow_cbr_index) { // the caller says CBR: the budgets predict the offsets
+      const int key[5] = {g.ys, g.xs, cp->compressed_bytes, cp->scalar, cp->prefix};
+      if (memcmp(key, c->cbr_key, sizeof key) || !c->buf[B_CBRB].p) {
+        std::vector<int32_t> sb(ns);
+        int32_t *db; uint32_t *dof; uint64_t total;
+        if (vc2hip_slice_bytes(g.ys, g.xs, cp->compressed_bytes, cp->scalar, sb.data()) == VC2HIP_OK &&
+            cbr_offsets_upload(c, sb.data(), ns, cp->prefix, &db, &dof, &total) == VC2HIP_OK) {
+          memcpy(c->cbr_key, key, sizeof key);
+          c->cbr_total = total;
+        }
+      }
+      if (!memcmp(key, c->cbr_key, sizeof key)) { d_cb = (const int32_t *)c->buf[B_CBRB].p; d_co = (const uint32_t *)c->buf[B_CBRO].p; cbr_total = c->cbr_total; }
+    }
     if ((rc = build_index(c, (const uint8_t *)d_payload, (long long)payload_stride, (const unsigned long long *)d_lens, n, ns,
-                          cp->prefix, cp->scalar, &d_offs))) return rc;
+                          cp->prefix, cp->scalar, &d_offs, d_cb, d_co, cbr_total))) return rc;
     UnpackParams p;
     memset(&p, 0, sizeof p);
     p.payload = (const uint8_t *)d_payload; p.payload_stride = (long long)payload_stride;

@@ -244,10 +244,13 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
                         int n_slices, int n_pictures, hipStream_t s);
 void vc2_launch_cbr(Launcher &L, const CbrParams &p, int n_pictures, hipStream_t s);
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p, int n_pictures, hipStream_t s);
+void vc2_launch_cbr_index(Launcher &L, const uint8_t *payload, long long stride, const unsigned long long *lens, const int32_t *budget,
+                          const uint32_t *cbr_offs, unsigned long long total, uint32_t *offsets, int n_slices, int prefix, int scalar,
+                          int n_pictures, unsigned *bad, hipStream_t s);
 void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
                             const unsigned long long *lens, uint32_t *offsets, int n_slices,
                             int prefix, int scalar, int n_pictures, unsigned *err, hipStream_t s,
-                            void *workspace, size_t workspace_bytes);
+                            void *workspace, size_t workspace_bytes, const unsigned *skip = nullptr);
 size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix, int scalar);
 
 // layout conversion for the fine-grained API (interleaved in-place plane <-> coefficient store)

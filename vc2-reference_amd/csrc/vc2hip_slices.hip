@@ -1801,7 +1801,8 @@ static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
 template <int CH>
 __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *payload, long long stride,
                                                                  const unsigned long long *lens, uint2 *tables,
-                                                                 int n_chunks, int E, int prefix, int scalar, unsigned *err) {
+                                                                 int n_chunks, int E, int prefix, int scalar, unsigned *err, const unsigned *skip) {
+  if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
   // a length beyond the picture's slot (hostile or uninitialised) is an error and is never followed out of the slot
@@ -1850,7 +1851,8 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
 static constexpr int IDX_GROUP = 16;
 
 __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const uint2 *tables,
-                                                     uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH) {
+                                                     uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH, const unsigned *skip) {
+  if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   const int g = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
   if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) return;
@@ -1870,7 +1872,8 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
 constexpr int IDX_MAX_GROUPS = 1024;
 __global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *lens, long long stride, const uint2 *tables,
                                                     const uint2 *groups, uint2 *entries, int n_chunks,
-                                                    int n_groups, int E, int IDX_CH) {
+                                                    int n_groups, int E, int IDX_CH, const unsigned *skip) {
+  if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   __shared__ uint2 g_entry[IDX_MAX_GROUPS]; // the launcher keeps n_groups within it (larger chunks for larger slots)
   const int pic = blockIdx.x;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
@@ -1902,7 +1905,8 @@ __global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *le
 __global__ __launch_bounds__(256) void k_index_emit(const uint8_t *payload, long long stride,
                                                    const unsigned long long *lens, const uint2 *entries,
                                                    uint32_t *offsets, int n_chunks, int E, int n_slices,
-                                                   int prefix, int scalar, unsigned *err, int IDX_CH) {
+                                                   int prefix, int scalar, unsigned *err, int IDX_CH, const unsigned *skip) {
+  if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride), c0 = (unsigned long long)chunk * IDX_CH;
@@ -1929,7 +1933,8 @@ static int idx_entries(int prefix, int scalar) { return prefix + 4 + 3 * 255 * s
 // length bytes through memory.  Correct for any stream, three dependent loads per slice.
 __global__ __launch_bounds__(64) void k_index_serial(const uint8_t *payload, long long stride, const unsigned long long *lens,
                                                      uint32_t *offsets, int n_slices, int prefix, int scalar, unsigned *err,
-                                                     int n_pictures) {
+                                                     int n_pictures, const unsigned *skip) {
+  if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   const int pic = blockIdx.x * 64 + threadIdx.x;
   if (pic >= n_pictures) return;
   const uint8_t *pay = payload + (size_t)pic * stride;
@@ -1943,6 +1948,42 @@ __global__ __launch_bounds__(64) void k_index_serial(const uint8_t *payload, lon
     for (int c = 0; c < 3; ++c) q += 1 + (q < plen ? (unsigned long long)pay[q] * scalar : 0ull);
     pos = q;
   }
+}
+
+// HQ_CBR pictures: every slice fills its byte budget exactly (Slices.cpp:352-368: the last component absorbs the
+// remainder), so the slice offsets of a conforming stream are the running sums of the budgets -- no chain to follow.
+// The decoder checks that claim against the stream itself: at every predicted offset the three length bytes must add up
+// to that slice's budget and the picture must be as long as all budgets together.  By induction over the slices that is
+// exactly "the chain through the length bytes visits these offsets"; one mismatch anywhere (*bad != 0) and the general
+// index kernels run as for any other stream (they return at once otherwise).
+__global__ __launch_bounds__(256) void k_cbr_index_check(const uint8_t *payload, long long stride, const unsigned long long *lens,
+                                                         const int32_t *budget, const uint32_t *cbr_offs, unsigned long long total,
+                                                         int n_slices, int prefix, int scalar, unsigned *bad) {
+  const int slice = blockIdx.x * 256 + threadIdx.x, pic = blockIdx.y;
+  if (slice >= n_slices) return;
+  const uint8_t *pay = payload + (size_t)pic * stride;
+  const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
+  bool ok = lens[pic] == total;
+  unsigned long long pos = (unsigned long long)cbr_offs[slice] + prefix + 1;
+  const unsigned long long end = (unsigned long long)cbr_offs[slice] + prefix + (unsigned)budget[slice];
+  for (int c = 0; c < 3 && ok; ++c) {
+    ok = pos < plen;
+    if (ok) pos += 1 + (unsigned long long)pay[pos] * scalar;
+  }
+  if (!ok || pos != end || end > plen) atomicOr(bad, 1u);
+}
+__global__ __launch_bounds__(256) void k_cbr_index_fill(const uint32_t *cbr_offs, uint32_t *offsets, int n_slices, const unsigned *bad) {
+  const int slice = blockIdx.x * 256 + threadIdx.x, pic = blockIdx.y;
+  if (slice < n_slices && *bad == 0) offsets[(size_t)pic * n_slices + slice] = cbr_offs[slice];
+}
+void vc2_launch_cbr_index(Launcher &L, const uint8_t *payload, long long stride, const unsigned long long *lens, const int32_t *budget,
+                          const uint32_t *cbr_offs, unsigned long long total, uint32_t *offsets, int n_slices, int prefix, int scalar,
+                          int n_pictures, unsigned *bad, hipStream_t s) {
+  vc2_prof_begin(L, "slice_index_cbr", s);
+  const dim3 grid((n_slices + 255) / 256, n_pictures);
+  VC2_LAUNCH(L, k_cbr_index_check, grid, dim3(256), 0, s, payload, stride, lens, budget, cbr_offs, total, n_slices, prefix, scalar, bad);
+  VC2_LAUNCH(L, k_cbr_index_fill, grid, dim3(256), 0, s, cbr_offs, offsets, n_slices, bad);
+  vc2_prof_end(L, s);
 }
 
 bool vc2_slice_index_supported(int prefix, int scalar);
@@ -1961,7 +2002,7 @@ size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix,
 void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
                             const unsigned long long *lens, uint32_t *offsets, int n_slices,
                             int prefix, int scalar, int n_pictures, unsigned *err, hipStream_t s,
-                            void *workspace, size_t workspace_bytes) {
+                            void *workspace, size_t workspace_bytes, const unsigned *skip) {
   const int E = idx_entries(prefix, scalar);
   (void)workspace_bytes;
   // the chain kernel holds one entry per group of 16 chunks in LDS: slots beyond IDX_MAX_GROUPS groups (256 MiB at
@@ -1971,7 +2012,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   if (E > IDX_MAX_E || too_many) {
     vc2_prof_begin(L, "slice_index_serial", s);
     VC2_LAUNCH(L, k_index_serial, dim3((n_pictures + 63) / 64), dim3(64), 0, s, payload, payload_stride, lens,
-                       offsets, n_slices, prefix, scalar, err, n_pictures);
+                       offsets, n_slices, prefix, scalar, err, n_pictures, skip);
     vc2_prof_end(L, s);
     return;
   }
@@ -1988,23 +2029,23 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     if (ch == 16384) {
       vc2_allow_lds((const void *)k_index_tables_nx<16384>, lds);
       VC2_LAUNCH(L, (k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, err);
+                         lens, tables, n_chunks, E, prefix, scalar, err, skip);
     } else {
       vc2_allow_lds((const void *)k_index_tables_nx<32768>, lds);
       VC2_LAUNCH(L, (k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, err);
+                         lens, tables, n_chunks, E, prefix, scalar, err, skip);
     }
   }
   vc2_prof_end(L, s);
   const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 256 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
-  VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch);
-  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch);
+  VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch, skip);
+  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch, skip);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
   VC2_LAUNCH(L, k_index_emit, dim3(n_chunks, n_pictures), dim3(256), stage_bytes, s, payload,
-                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch);
+                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch, skip);
   vc2_prof_end(L, s);
 }
 
