@@ -1801,7 +1801,8 @@ static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
 template <int CH>
 __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *payload, long long stride,
                                                                  const unsigned long long *lens, uint2 *tables,
-                                                                 int n_chunks, int E, int prefix, int scalar, unsigned *err, const unsigned *skip) {
+                                                                 int n_chunks, int E, int prefix, int scalar, unsigned *err, const unsigned *skip,
+                                                                 int merge) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
@@ -1836,11 +1837,54 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
   }
   __syncthreads();
   uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
-  for (int e = threadIdx.x; e < E; e += IDX_THREADS) {
-    int pos = e, cnt = 0;
-    if (e >= lim) pos = CH; // starts behind the payload end: no slice
+  if (!merge) {
+    for (int e = threadIdx.x; e < E; e += IDX_THREADS) {
+      int pos = e, cnt = 0;
+      if (e >= lim) pos = CH; // starts behind the payload end: no slice
+      while (pos < CH) { pos = nx[pos]; ++cnt; }
+      tab[e] = make_uint2((unsigned)(pos - CH), (unsigned)cnt);
+    }
+    return;
+  }
+  // The E walks merge: two of them that ever stand on the same byte stay together, and after their first hops out of
+  // the entry region [0, E) most stand on one of a few bytes of [E, 2E).  So every entry walks only until it has left
+  // [0, E); the distinct landing bytes are collected, walked once each to the chunk's end, and every entry adds its own
+  // hops to its landing byte's result -- a fraction of the dependent LDS reads of E full walks (the kernel's time is
+  // those reads).
+  unsigned *need = (unsigned *)(nx + CH);            // per byte of [E, 2E): some walk landed here
+  unsigned *W = need + E;                            // its result: exit offset << 16 | slices
+  unsigned short *list = (unsigned short *)(W + E);  // the landing bytes, dense
+  __shared__ unsigned s_count;
+  for (int t = threadIdx.x; t < E; t += IDX_THREADS) need[t] = 0;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  constexpr int EPT = 2; // entries per thread (merge needs E <= 2 * IDX_THREADS)
+  int la[EPT], ca[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = threadIdx.x + k * IDX_THREADS;
+    la[k] = CH; ca[k] = 0;
+    if (e < E && e < lim) {
+      int pos = e, cnt = 0;
+      while (pos < E) { pos = nx[pos]; ++cnt; }
+      la[k] = pos; ca[k] = cnt;
+      if (pos < CH && atomicExch(&need[pos - E], 1u) == 0u) list[atomicAdd(&s_count, 1u)] = (unsigned short)(pos - E);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)s_count; i += IDX_THREADS) {
+    const int t = list[i];
+    int pos = E + t, cnt = 0;
     while (pos < CH) { pos = nx[pos]; ++cnt; }
-    tab[e] = make_uint2((unsigned)(pos - CH), (unsigned)cnt);
+    W[t] = (unsigned)(pos - CH) << 16 | (unsigned)cnt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = threadIdx.x + k * IDX_THREADS;
+    if (e >= E) continue;
+    if (la[k] >= CH) tab[e] = make_uint2((unsigned)(la[k] - CH), (unsigned)ca[k]);
+    else { const unsigned w = W[la[k] - E]; tab[e] = make_uint2(w >> 16, (unsigned)ca[k] + (w & 0xFFFFu)); }
   }
 }
 
@@ -2025,15 +2069,18 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   vc2_allow_lds((const void *)k_index_emit, stage_bytes);
   vc2_prof_begin(L, "slice_index_tables", s);
   {
-    const size_t lds = stage_bytes + (size_t)ch * 2;
+    // merged walks (see the kernel): entry regions of up to 2048 bytes whose landing region lies inside the chunk
+    static const bool no_merge = [] { const char *e = getenv("VC2HIP_IDX_NO_MERGE"); return e && e[0] == '1'; }();
+    const int merge = !no_merge && E <= 2 * IDX_THREADS && 2 * E <= ch;
+    const size_t lds = stage_bytes + (size_t)ch * 2 + (merge ? (size_t)E * 10 + 16 : 0);
     if (ch == 16384) {
       vc2_allow_lds((const void *)k_index_tables_nx<16384>, lds);
       VC2_LAUNCH(L, (k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, err, skip);
+                         lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);
     } else {
       vc2_allow_lds((const void *)k_index_tables_nx<32768>, lds);
       VC2_LAUNCH(L, (k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, err, skip);
+                         lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);
     }
   }
   vc2_prof_end(L, s);
