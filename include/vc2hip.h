@@ -221,6 +221,9 @@ int vc2hip_decode_batch_dev(vc2hip_ctx *ctx, const void *d_payload, size_t paylo
  * measurement: per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg)
  * ------------------------------------------------------------------------------------------- */
 int vc2hip_profile_enable(vc2hip_ctx *ctx, int on); /* on: every launch carries a start / stop event pair */
+/* name != NULL: only the launches of that profile entry carry events (a timed region that should pay for the events of one
+ * kernel, not of thirty launches per step); NULL: all of them again */
+int vc2hip_profile_only(vc2hip_ctx *ctx, const char *name);
 /* after vc2hip_sync(): number of distinct kernel names seen since enable */
 int vc2hip_profile_count(vc2hip_ctx *ctx);
 /* i-th entry: name, launches, total milliseconds */

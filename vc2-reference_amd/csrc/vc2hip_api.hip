@@ -49,6 +49,7 @@ struct ProfEntry {
 };
 struct Launcher {
   bool on = false;
+  std::string only;               // non-empty: event pairs for the launches of this name only (vc2hip_profile_only)
   const char *last_name = nullptr;
   std::string launch_error;
   std::vector<ProfEntry> entries;
@@ -76,7 +77,7 @@ struct Launcher {
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
   (void)s;
   L.last_name = name;
-  if (!L.on) return;
+  if (!L.on || (!L.only.empty() && L.only != name)) return;
   int idx = -1;
   for (size_t i = 0; i < L.entries.size(); ++i) if (L.entries[i].name == name) { idx = (int)i; break; }
   if (idx < 0) { L.entries.push_back(ProfEntry{name, 0, 0}); idx = (int)L.entries.size() - 1; }
@@ -500,6 +501,12 @@ extern "C" int vc2hip_profile_enable(vc2hip_ctx *c, int on) {
   if (!c) return VC2HIP_EINVAL;
   c->L.on = on != 0;
   for (vc2hip_ctx *l : c->lanes) l->L.on = on != 0;
+  return 0;
+}
+extern "C" int vc2hip_profile_only(vc2hip_ctx *c, const char *name) {
+  if (!c) return VC2HIP_EINVAL;
+  c->L.only = name ? name : "";
+  for (vc2hip_ctx *l : c->lanes) l->L.only = c->L.only;
   return 0;
 }
 // entries of the context and of its lanes, merged by kernel name

@@ -50,7 +50,7 @@ EXPORTS = [
     "vc2hip_ld_qindices", "vc2hip_encode_picture_ld", "vc2hip_set_streams", "vc2hip_raw_picture_bytes",
     "vc2hip_max_payload_bytes", "vc2hip_encode_picture_hq", "vc2hip_decode_picture_hq",
     "vc2hip_decode_picture_ld", "vc2hip_encode_batch_dev", "vc2hip_decode_batch_dev",
-    "vc2hip_profile_enable", "vc2hip_profile_count", "vc2hip_profile_get", "vc2hip_profile_reset",
+    "vc2hip_profile_enable", "vc2hip_profile_only", "vc2hip_profile_count", "vc2hip_profile_get", "vc2hip_profile_reset",
     "vc2hip_host_alloc", "vc2hip_host_free", "vc2hip_encode_picture_begin", "vc2hip_encode_picture_end",
     "vc2hip_decode_picture_begin", "vc2hip_decode_picture_end",
 ]
@@ -109,6 +109,7 @@ def load_library():
     lib.vc2hip_decode_batch_dev.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, C.POINTER(PictureFormat),
                                             C.POINTER(CodingParams), vp]
     lib.vc2hip_profile_enable.argtypes = [vp, C.c_int]
+    lib.vc2hip_profile_only.argtypes = [vp, C.c_char_p]
     lib.vc2hip_profile_count.argtypes = [vp]
     lib.vc2hip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_double)]
@@ -398,6 +399,9 @@ class Vc2Hip:
     # ---- profiling
     def profile_enable(self, on=True):
         self.lib.vc2hip_profile_enable(self.h, 1 if on else 0)
+
+    def profile_only(self, name=None):
+        self.lib.vc2hip_profile_only(self.h, name.encode() if name else None)
 
     def profile_reset(self):
         self.lib.vc2hip_profile_reset(self.h)
