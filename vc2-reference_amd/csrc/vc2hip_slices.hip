@@ -47,11 +47,24 @@ __device__ __forceinline__ int quant_dev(int v, int aq) {
   return quant_core(v, c_qs.qf[aq], c_qs.magic[aq], c_qs.shift[aq]);
 }
 // band index of coefficient j when n0 is (usually) a power of two: no integer division
-__device__ __forceinline__ int band_of_index_fast(int j, int n0, int n0_shift) {
+__host__ __device__ __forceinline__ int band_of_index_fast(int j, int n0, int n0_shift) {
   const int m = n0_shift >= 0 ? (j >> n0_shift) : (j / n0);
   if (m == 0) return 0;
-  const int L = (31 - __clz(m)) / 2 + 1;
+  const int L = (31 - __builtin_clz((unsigned)m)) / 2 + 1;
   return 3 * (L - 1) + (m >> (2 * (L - 1)));
+}
+// subband of every coefficient index of the common geometry (components of up to 512 / 256 coefficients): 512 luma
+// entries, 256 chroma entries.  Filled by the launchers, carried in the kernel arguments, copied into LDS by every
+// workgroup (computing it there cost every workgroup of four slices ~45 instructions per thread).
+static void fill_band_lut(unsigned char *lut, const int comp_n[3], const int comp_n0[3]) {
+  const int n0y = comp_n0[0], n0c = comp_n0[1];
+  const int sy = n0y > 0 && (n0y & (n0y - 1)) == 0 ? 31 - __builtin_clz((unsigned)n0y) : -1;
+  const int sc = n0c > 0 && (n0c & (n0c - 1)) == 0 ? 31 - __builtin_clz((unsigned)n0c) : -1;
+  for (int j = 0; j < 512; ++j) lut[j] = n0y > 0 ? (unsigned char)band_of_index_fast(std::min(j, comp_n[0] - 1), n0y, sy) : 0;
+  for (int j = 0; j < 256; ++j) lut[512 + j] = n0c > 0 ? (unsigned char)band_of_index_fast(std::min(j, comp_n[1] - 1), n0c, sc) : 0;
+}
+__device__ __forceinline__ void copy_band_lut(unsigned char *band_y, const unsigned char *arg) { // band_c = band_y + 512
+  for (int j = threadIdx.x; j < 192; j += blockDim.x) ((unsigned *)band_y)[j] = ((const unsigned *)arg)[j];
 }
 // Quantisation.cpp:86-95
 __device__ __forceinline__ int scale_dev(int v, int aq) {
@@ -463,12 +476,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   if (!GIMG || active) for (int i = sl; i < img_words; i += W) img[i] = 0;
   if (GIMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zeros are in place before the first atomic OR
   build_vlc_lut(lut);
-  if (fast && p.quantise) {
-    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
-    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
-    for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
-    for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
-  }
+  if (fast && p.quantise) copy_band_lut(band_y, p.band_lut);
   const bool mid = MID && W == 64 && !fast && p.quantise && p.big_lut; // its own instantiation: the one-round kernel keeps its 71 registers
   if (mid) {
     const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
@@ -671,6 +679,7 @@ int vc2_pack_image_mode(int prefix, int scalar) {
 size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
+  fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
   if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
 #ifdef VC2HIP_ABLATE
@@ -864,12 +873,7 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
   const bool fast = !GLOBAL && p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32;
   unsigned char *band_y = (unsigned char *)(lds_i + (GLOBAL ? 0 : wpw * p.slice_coefs)), *band_c = band_y + 512;
   uint4 *qtab = (uint4 *)(band_c + 256) + wave * 32;
-  if (fast) {
-    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
-    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
-    for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
-    for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
-  }
+  if (fast) copy_band_lut(band_y, p.band_lut);
   __syncthreads();
   // no workgroup barriers below.  only_marked: the second pass behind k_cbr_search_reg -- a small grid walks the slices and
   // searches those the register kernel handed back
@@ -1024,16 +1028,14 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
 // Needs the common geometry (components of at most 512 / 256 coefficients, multiples of 8).
 template <class ST>
 __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
-  __shared__ __attribute__((aligned(8))) unsigned char band_y[512], band_c[256];
+  __shared__ __attribute__((aligned(8))) unsigned char band_lds[768];
+  unsigned char *band_y = band_lds, *band_c = band_lds + 512;
   __shared__ uint4 s_tab[80];  // by quantiser index: (rounded-up 4 / factor as a float, factor, offset + 2, -)
   __shared__ int s_qm[32];     // 16 x the quantisation matrix entry of every subband (byte offsets into s_tab)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
   {
-    const int n0y = p.comp_n0[0], n0c = p.comp_n0[1];
-    const int sy = (n0y & (n0y - 1)) == 0 ? 31 - __clz(n0y) : -1, sc = (n0c & (n0c - 1)) == 0 ? 31 - __clz(n0c) : -1;
-    for (int j = threadIdx.x; j < 512; j += blockDim.x) band_y[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[0] - 1), n0y, sy);
-    for (int j = threadIdx.x; j < 256; j += blockDim.x) band_c[j] = (unsigned char)band_of_index_fast(min(j, p.comp_n[1] - 1), n0c, sc);
+    copy_band_lut(band_y, p.band_lut);
     if (threadIdx.x < 80)
       s_tab[threadIdx.x] = make_uint4(__float_as_uint(c_qs.inv4[threadIdx.x]), (unsigned)c_qs.qf[threadIdx.x], (unsigned)c_qs.off[threadIdx.x] + 2u, 0u);
     if (threadIdx.x < 32) s_qm[threadIdx.x] = threadIdx.x < p.n_bands ? 16 * p.qmatrix[threadIdx.x] : 0;
@@ -1163,6 +1165,7 @@ int vc2_waves_for_lds(size_t per_wave) {
 }
 void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_t s) {
   CbrParams p = p0;
+  fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
   const size_t per_wave = (size_t)p.slice_coefs * 4 + 32 * 16, tables = 768; // + the wavefront's quantiser table; + band tables
   vc2_prof_begin(L, "cbr_search", s);
   p.only_marked = 0;
