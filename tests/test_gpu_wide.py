@@ -238,3 +238,64 @@ def test_cbr_decode_offsets_from_budgets_and_fallback(variants, oracle):
     payq, _ = hip.encode_picture_hq(raw, fmt, cpq)
     assert hip.decode_picture(payq, fmt, cp) == dq
     assert hip.decode_picture(payq, fmt, cpq) == dq
+
+
+def test_hostile_lengths_stay_inside_their_slot(variants, oracle):
+    """Device-resident decode with a per-picture length beyond the payload stride (hostile or uninitialised): the kernels
+    clamp it to the slot, the call reports a stream error, the neighbouring pictures of the batch are untouched by it."""
+    import torch
+    hip = variants["default"]
+    w, h, depth, n = 1024, 64, 3, 3
+    raw = b"".join(synth(w, h, "422", 10, 400 + k) for k in range(n))
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", depth, 1, 2, q=8, scalar=1)
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+    hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    good = d_out.cpu().numpy().tobytes()
+    lens = d_len.clone()
+    for bad_len in (stride + 1, 1 << 40):
+        d_len2 = lens.clone()
+        d_len2[1] = bad_len
+        d_out.zero_()
+        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len2.data_ptr(), n, fmt, cp, d_out.data_ptr())
+        with pytest.raises(Exception):
+            hip.sync()
+        out = d_out.cpu().numpy().tobytes()
+        assert out[:rb] == good[:rb] and out[2 * rb:] == good[2 * rb:]
+    # the context is usable afterwards
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, lens.data_ptr(), n, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    assert d_out.cpu().numpy().tobytes() == good
+
+
+def test_payload_slot_beyond_the_index_chain_table(variants, oracle):
+    """A payload slot of more than 256 MiB has more chunk groups than the per-picture chain table of the slice index holds
+    (1024 groups of 16 chunks of 16 KiB): the index then walks the length bytes serially -- same offsets, same picture."""
+    import torch
+    hip = variants["default"]
+    w, h, depth = 1024, 64, 3
+    raw = synth(w, h, "422", 10, 77)
+    p = make_params(w, h, "422", 10, "LeGall", depth, 1, 2, q=6, scalar=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "LeGall", depth, 1, 2, q=6, scalar=1)
+    rb = hip.raw_picture_bytes(fmt)
+    stride = 300 * 1024 * 1024
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(rb, dtype=torch.uint8, device=dev)
+    hip.encode_batch_dev(d_raw.data_ptr(), 1, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), 1, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    n = int(d_len.cpu()[0])
+    assert d_pay[:n].cpu().numpy().tobytes() == stream[-13 - n:-13]
+    assert d_out.cpu().numpy().tobytes() == dec
