@@ -558,6 +558,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     }
   };
   // unpack band b of row m (escapes resolved) and dequantise
+  // unpack band b of row m (escapes resolved) and dequantise: band by band (the Fidelity kernels)
   auto band4 = [&](int m, int slot, int b) __attribute__((always_inline)) -> int4 {
     const bool from_plane = b == 0 && !p.ll_from_store;
     int v[4];
@@ -576,8 +577,6 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     if (p.dequant && !from_plane) {
       const int mx = max(max(v[0], v[1]), max(v[2], v[3])), mn = min(min(v[0], v[1]), min(v[2], v[3]));
       if (mx <= ql[b] && mn >= -ql[b]) {
-        // scale(), Quantisation.cpp:86-95, inside its domain: sign(v) * ((|v| * factor + offset + 2) >> 2), 0 for 0.
-        // sg = sign(v) in {-1, 0, 1}; |v| = v * sg; the final product with sg restores the sign and zeroes the v = 0 case
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int sg = min(max(v[k], -1), 1);
@@ -590,6 +589,67 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
       }
     }
     return make_int4(v[0], v[1], v[2], v[3]);
+  };
+  // the lane's four coefficients of all four bands of row m (escapes resolved, dequantised): ONE test for escapes and
+  // ONE for the dequantiser's fast domain over the sixteen values -- a branch per band cost more than the arithmetic
+  auto bands16 = [&](int m, int slot, int (&v)[16]) __attribute__((always_inline)) {
+    if constexpr (S_::narrow) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint2 w = bq[slot][b];
+        v[4 * b] = vc2_lo16(w.x); v[4 * b + 1] = vc2_hi16(w.x); v[4 * b + 2] = vc2_lo16(w.y); v[4 * b + 3] = vc2_hi16(w.y);
+      }
+      int lowest = v[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) lowest = min(lowest, v[k]);
+      if (lowest == VC2_ST_SENTINEL) { // (the sentinel is the smallest 16-bit value)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bool from_plane = b == 0 && !p.ll_from_store;
+          const int32_t *wq = from_plane ? llp_w + mul24z(m, ow) : wide + rec_at(m, b);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (v[4 * b + k] == VC2_ST_SENTINEL) v[4 * b + k] = wq[k];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint4 w = bq[slot][b];
+        v[4 * b] = (int)w.x; v[4 * b + 1] = (int)w.y; v[4 * b + 2] = (int)w.z; v[4 * b + 3] = (int)w.w;
+      }
+    }
+    if (p.dequant) {
+      const int bf = p.ll_from_store ? 0 : 1; // bands that come from the store
+      bool fast = true;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b < bf) continue;
+        const int mx = max(max(v[4 * b], v[4 * b + 1]), max(v[4 * b + 2], v[4 * b + 3]));
+        const int mn = min(min(v[4 * b], v[4 * b + 1]), min(v[4 * b + 2], v[4 * b + 3]));
+        fast &= mx <= ql[b] && mn >= -ql[b];
+      }
+      if (fast) {
+        // scale(), Quantisation.cpp:86-95, inside its domain: sign(v) * ((|v| * factor + offset + 2) >> 2), 0 for 0.
+        // sg = sign(v) in {-1, 0, 1}; |v| = v * sg; the final product with sg restores the sign and zeroes the v = 0 case
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b < bf) continue;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int x = v[4 * b + k], sg = min(max(x, -1), 1);
+            const unsigned t = (__umul24((unsigned)__mul24(x, sg), (unsigned)qf[b]) + (unsigned)(qo[b] + 2)) >> 2;
+            v[4 * b + k] = __mul24((int)t, sg);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b < bf) continue;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[4 * b + k] = dequant_full(v[4 * b + k], qf[b], qo[b]);
+        }
+      }
+    }
   };
 
   // ---- output rows
@@ -670,9 +730,16 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     if constexpr (MODE != 2) {                                                                               \
       const int ml = min(m, mload), sv = ml >> lbsh;                                                         \
       if (sv != sv_have) { load_q(sv); sv_have = sv; }                                                       \
-      const int4 t0 = band4(ml, U % PFI, 0), t1 = band4(ml, U % PFI, 1), t2 = band4(ml, U % PFI, 2), t3 = band4(ml, U % PFI, 3); \
-      re = Row{{t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}};                                            \
-      ro = Row{{t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w}};                                            \
+      if constexpr (RL == 4) {                                                                               \
+        int bv[16];                                                                                          \
+        bands16(ml, U % PFI, bv);                                                                            \
+        re = Row{{bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], bv[6], bv[7]}};                                  \
+        ro = Row{{bv[8], bv[9], bv[10], bv[11], bv[12], bv[13], bv[14], bv[15]}};                            \
+      } else { /* rings of eight: no registers to spare for sixteen values at once */                        \
+        const int4 t0 = band4(ml, U % PFI, 0), t1 = band4(ml, U % PFI, 1), t2 = band4(ml, U % PFI, 2), t3 = band4(ml, U % PFI, 3); \
+        re = Row{{t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}};                                          \
+        ro = Row{{t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w}};                                          \
+      }                                                                                                      \
     }                                                                                                        \
     if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }                               \
     if constexpr (MODE != 2) in_fetch(min(m + PFI, mload), U % PFI);                                         \
