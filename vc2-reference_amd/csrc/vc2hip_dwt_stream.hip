@@ -879,16 +879,26 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     lds = std::max(lds, img);
   }
   if (lds > 40 * 1024) return 0;
-  // rows per segment: whole block rows, enough wavefronts to fill the chip (~8 per SIMD) but at least 16 row pairs
+  // Rows per segment: whole block rows.  A segment runs in over the filter's reach before its first output (4 pairs for
+  // DD97, 14 for Fidelity), so short segments waste work -- 16-pair segments 20 % of it -- while long ones leave the
+  // chip without wavefronts.  Measured on 16 UHD pictures: 32 pairs beat 16 (level 0: 0.339 -> 0.322 ms forward,
+  // 0.425 -> 0.388 ms inverse; level 1 a little) and 64 (deeper levels); small batches take 16 to have wavefronts at all.
+  static const int force_py = [] { const char *e = getenv("VC2HIP_STREAM_PY"); return e ? atoi(e) : 0; }();
+  const int py_long = kernel == VC2HIP_FIDELITY ? 64 : 32, py_short = kernel == VC2HIP_FIDELITY ? 64 : 16;
+  auto count = [&](int py0) {
+    long long w = 0;
+    for (int c = 0; c < 3; ++c) {
+      if (!p.st_strips[c]) continue;
+      const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2, py = ((std::max(py0, bsh) + bsh - 1) / bsh) * bsh;
+      w += (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures;
+    }
+    return w;
+  };
+  const int py0 = force_py > 0 ? force_py : (count(py_long) >= 2048 ? py_long : py_short);
   for (int c = 0; c < 3; ++c) {
     if (!p.st_strips[c]) continue;
     const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2;
-    int py = std::max(64, bsh);
-    const int py_min = kernel == VC2HIP_FIDELITY ? 64 : 16; // (a segment runs in over sum of reaches: 7 pairs for Fidelity)
-    while (py > std::max(py_min, bsh) && (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures * 3 < 16384) py /= 2;
-    static const int force_py = [] { const char *e = getenv("VC2HIP_STREAM_PY"); return e ? atoi(e) : 0; }();
-    if (force_py > 0) py = force_py;
-    py = ((py + bsh - 1) / bsh) * bsh;
+    const int py = ((std::max(py0, bsh) + bsh - 1) / bsh) * bsh;
     p.st_py[c] = py;
     p.st_segs[c] = (np + py - 1) / py;
     waves += (long long)p.st_strips[c] * p.st_segs[c];
