@@ -299,3 +299,16 @@ def test_payload_slot_beyond_the_index_chain_table(variants, oracle):
     n = int(d_len.cpu()[0])
     assert d_pay[:n].cpu().numpy().tobytes() == stream[-13 - n:-13]
     assert d_out.cpu().numpy().tobytes() == dec
+
+
+@pytest.mark.parametrize("kernel", ["DD97", "LeGall", "DD137", "Haar1", "Daub97", "Fidelity"])
+def test_streaming_levels_with_odd_pair_counts_and_narrow_planes(variants, oracle, kernel):
+    """4:4:4, 768 x 88, depth 3, slices 8 x 64: the three levels are 768 x 88 (44 row pairs), 384 x 44 (22: remainder 2 of
+    the ring of four) and 192 x 22 (11: remainder 3) -- the tail instantiations of the streaming kernels, and planes
+    narrower than a wavefront of 8-sample chunks (48 and 24 of 64 lanes at work).  Fidelity (rings of eight, whole blocks
+    only) takes the tile kernels below the first level."""
+    w, h, depth = 768, 88, 3
+    raw = noise_frame(w, h, "444", 10, seed=91)
+    _check(variants, oracle, raw, w, h, "444", 10, kernel, depth, 1, 8, q=9, scalar=8)
+    raw = synth(w, h, "444", 10, 92)
+    _check(variants, oracle, raw, w, h, "444", 10, kernel, depth, 1, 8, q=0, scalar=8)
