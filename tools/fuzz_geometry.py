@@ -79,8 +79,8 @@ while done < count:
     except Exception as e:
         if "exceeds 65534" in str(e):
             continue  # outside the reference's own 32-bit code domain (undefined behaviour there): refused here
-        if "slice too large for the LD encode kernels" in str(e):
-            continue  # documented limit of the LD encoder here: a clean error
+        if mode == "LD" and ("slice too large for the LD encode kernels" in str(e) or "slice too large for one LDS tile" in str(e)):
+            continue  # documented limits of the LD path here: clean errors
         bad += 1
         print("EXCEPTION", desc, str(e)[:120])
 print(f"seed {seed}: {done} cases, {bad} bad")
