@@ -268,6 +268,7 @@ def main():
             perm = torch.arange(B - 1, -1, -1, device=dev)
             d_raw2 = d_raw.view(B, rb)[perm].contiguous().view(-1)
             d_out2 = torch.zeros_like(d_out)
+            torch.cuda.synchronize()   # torch built these on ITS stream; the library reads them on its own
             hip.encode_batch_dev(d_raw2.data_ptr(), B, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
             hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out2.data_ptr())
             hip.sync()

@@ -578,6 +578,7 @@ def test_multi_stream_batches_are_identical(oracle):
     fmt2, cp2 = _fmt_cp(hip, w, h, "422", 10, "DD97", 3, 1, 2, q=0, scalar=1)
     d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
     d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     hip.encode_batch_dev(d_bad.data_ptr(), n, fmt2, cp2, d_pay.data_ptr(), stride, d_len.data_ptr())
     with pytest.raises(Exception, match="Slice scalar is too small"):
         hip.sync()

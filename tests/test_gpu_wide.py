@@ -255,6 +255,7 @@ def test_hostile_lengths_stay_inside_their_slot(variants, oracle):
     d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
     d_len = torch.zeros(n, dtype=torch.int64, device=dev)
     d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()   # (torch fills on its stream, the library works on its own)
     hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
     hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
     hip.sync()
@@ -264,6 +265,7 @@ def test_hostile_lengths_stay_inside_their_slot(variants, oracle):
         d_len2 = lens.clone()
         d_len2[1] = bad_len
         d_out.zero_()
+        torch.cuda.synchronize()
         hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len2.data_ptr(), n, fmt, cp, d_out.data_ptr())
         with pytest.raises(Exception):
             hip.sync()
@@ -293,6 +295,7 @@ def test_payload_slot_beyond_the_index_chain_table(variants, oracle):
     d_pay = torch.zeros(stride, dtype=torch.uint8, device=dev)
     d_len = torch.zeros(1, dtype=torch.int64, device=dev)
     d_out = torch.zeros(rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()   # (torch fills on its stream, the library works on its own)
     hip.encode_batch_dev(d_raw.data_ptr(), 1, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
     hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), 1, fmt, cp, d_out.data_ptr())
     hip.sync()
