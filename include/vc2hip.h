@@ -205,7 +205,10 @@ int vc2hip_decode_picture_end(vc2hip_ctx *ctx, int ticket);
  * d_raw, d_payload and payload_stride must be multiples of 16 bytes (VC2HIP_EINVAL otherwise); when a
  * picture's raw size is not a multiple of 16 the pictures of a batch are still packed back to back.
  * Nothing is allocated or synchronised inside these calls once the ctx has seen the geometry
- * (first call sizes the workspace). */
+ * (first call sizes the workspace).  The kernels run on the ctx stream (vc2hip_create makes its own,
+ * vc2hip_create_on_stream takes the caller's): buffers that another stream has written -- a framework's
+ * fill or gather kernel, a copy -- must be complete before the call, and the results are complete after
+ * vc2hip_sync (or an event the caller records on the ctx stream). */
 /* Cut every device-resident batch into k contiguous sub-batches, each on its own HIP stream and workspace,
  * forked from and joined to the context's stream (k = 1: off, the default).  The launches of the sub-batches
  * overlap on the GPU; results are identical.  Extension, no counterpart in the reference. */
