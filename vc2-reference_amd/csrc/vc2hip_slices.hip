@@ -558,6 +558,30 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         Coef8 c;
         int run = 0, count = 0;
         const unsigned char *band_lut = cc ? big_c : big_y;
+        if constexpr (MID) {
+          if (mid && n <= 1024) { // at most two rounds: codes of both kept in registers, quantised once (no measuring pass)
+            Coef8 c1;
+            load8_tab(c, src, srcw, lane * 8, n, band_lut, qtab, p.err, lut);
+            const bool two = n > 512;
+            if (two) load8_tab(c1, src, srcw, 512 + lane * 8, n, band_lut, qtab, p.err, lut);
+            else {
+              c1.sum = 0; c1.last_end = 0;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { c1.nb[k] = 0; c1.code[k] = 0; }
+            }
+            const int incl0 = wave_incl_scan(c.sum, lane), run0 = __builtin_amdgcn_readlane(incl0, 63);
+            const int incl1 = wave_incl_scan(c1.sum, lane);
+            count = max(wave_max(c.last_end ? incl0 - c.sum + c.last_end : 0),
+                        wave_max(c1.last_end ? run0 + incl1 - c1.sum + c1.last_end : 0));
+            bytes[cc] = comp_len(count);
+            if (cc == 2) bytes[2] = cbr_v(bytes[2]);
+            write8(img, 8 * (base + 1) + incl0 - c.sum, 8 * (base + 1 + bytes[cc]), c);
+            if (two) write8(img, 8 * (base + 1) + run0 + incl1 - c1.sum, 8 * (base + 1 + bytes[cc]), c1);
+            if (lane == 0) put_byte(img, base, (unsigned)(bytes[cc] / p.scalar));
+            base += 1 + bytes[cc];
+            continue;
+          }
+        }
         for (int r0 = 0; r0 < n; r0 += 512) {
           if (mid) bits8_tab(src, srcw, r0 + lane * 8, n, band_lut, qtab, p.err, c.sum, c.last_end); // lengths only
           else if (p.quantise) load8<true>(c, src, srcw, r0 + lane * 8, n, n0, n0s, qtab, p.err, lut);
