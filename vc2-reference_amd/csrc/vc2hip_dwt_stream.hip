@@ -1,4 +1,5 @@
-// Streaming DWT / IDWT level kernels: the hot configuration (planes at least 512 samples wide).
+// Streaming DWT / IDWT level kernels: the hot configuration (planes from 192 samples wide, slices of whole 8-sample
+// chunks; all seven wavelets).
 //
 // One wavefront owns a strip of 64 chunks (8 samples each: one 16-byte load per lane and row, 1 KiB per wavefront) and
 // walks down the rows of its segment.  Nothing is shared between wavefronts and there is no workgroup barrier:
@@ -7,17 +8,20 @@
 //     a wavefront has no such neighbour and keeps the `old` operand, which is set to the lane's own edge pair: when
 //     the strip starts / ends at the plane edge that IS the reference's tap clamping (WaveletTransform.cpp:478-1265:
 //     even taps clamp to [0, n-2], odd taps to [1, n-1]); inside the plane those lanes are halo lanes whose results
-//     are not written (strips overlap by the halo).
-//   * vertical lifting is a line-based scheme: the rows still needed by a later lifting step stay in registers (a
-//     window of a few rows per step); every new row pair completes one output row pair a few rows higher up.
-//     Rows above / below the plane replicate the first / last pair (the same clamping).
-//   * rows are prefetched several pairs ahead into registers, so a wavefront always has ~8 KiB of loads in flight.
-//   * the coefficient store keeps every slice's coefficients together, so the three detail bands pass
-//     through a small wavefront-private LDS image laid out [band][row][slice][column]: rows are written / read by
-//     the lanes without bank conflicts and move to / from the slice records as whole 16-byte pieces of the
-//     contiguous [HL | LH | HH] run of a slice, one block row of slices at a time.
+//     are not written (strips overlap by the halo).  A plane narrower than the wavefront ends at an inner lane, which
+//     clamps by a select; the lanes behind it idle.
+//   * vertical lifting is a line-based scheme: the rows still needed by a later lifting step stay in registers (rings
+//     of 4 rows per sequence, 8 for Fidelity's 8-tap steps); every new row pair completes one output row pair a few
+//     rows higher up.  Rows above / below the plane replicate the first / last pair (the same clamping).
+//   * rows are prefetched ahead into registers; every iteration's stores are issued at the top of the next one.
+//   * forward: the coefficient store keeps every slice's coefficients together, so the three detail bands
+//     pass through a small wavefront-private LDS image laid out [band][row][slice][column] and move to the slice
+//     records as whole 16-byte pieces of the contiguous [HL | LH | HH] run of a slice, one block row of slices at a time.
+//   * inverse: four coefficients per band and lane straight from the decoder's band planes (BandPlanes,
+//     vc2hip_internal.h) or, for levels that have none, from the slice records.
 // Same LevelParams and the same results as the tile kernels of vc2hip_dwt_fast.hip, which remain for every geometry
-// this scheme does not cover (narrow planes, deep levels, padded widths).
+// this scheme does not cover (slice footprints below one chunk, very narrow planes, padded widths, Fidelity planes
+// that are not whole blocks of eight row pairs).
 #include <stdlib.h>
 
 #include <algorithm>
