@@ -1922,21 +1922,59 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
 static constexpr int IDX_GROUP = 16;
 
 __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const uint2 *tables,
-                                                     uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH, const unsigned *skip) {
+                                                     uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH, const unsigned *skip,
+                                                     int dedupe) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
+  extern __shared__ __attribute__((aligned(8))) unsigned lds_g[];
   const int g = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
   if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) return;
+  if (!dedupe) {
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      unsigned x = (unsigned)e, cnt = 0;
+      for (int k = 0; k < IDX_GROUP; ++k) {
+        const int c = g * IDX_GROUP + k;
+        if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
+        const uint2 t = tables[((size_t)pic * n_chunks + c) * E + x];
+        x = t.x;
+        cnt += t.y;
+      }
+      groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(x, cnt);
+    }
+    return;
+  }
+  // The E entries leave the group's first chunk at only a few distinct offsets (chains that meet stay together): the
+  // other fifteen chunks are followed once per distinct offset instead of once per entry.
+  unsigned *need = lds_g;                                // per offset: some entry leaves the first chunk here
+  uint2 *res = (uint2 *)(need + ((E + 1) & ~1));         // its way through the rest of the group
+  unsigned short *list = (unsigned short *)(res + E);    // the distinct offsets, dense
+  __shared__ unsigned s_count;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) need[e] = 0;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const int c0 = g * IDX_GROUP;
+  const uint2 *t0 = tables + ((size_t)pic * n_chunks + c0) * E;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    unsigned x = (unsigned)e, cnt = 0;
-    for (int k = 0; k < IDX_GROUP; ++k) {
-      const int c = g * IDX_GROUP + k;
+    const unsigned x = t0[e].x;
+    if (atomicExch(&need[x], 1u) == 0u) list[atomicAdd(&s_count, 1u)] = (unsigned short)x;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)s_count; i += blockDim.x) {
+    unsigned x = list[i], cnt = 0;
+    const unsigned x0 = x;
+    for (int k = 1; k < IDX_GROUP; ++k) {
+      const int c = c0 + k;
       if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
       const uint2 t = tables[((size_t)pic * n_chunks + c) * E + x];
       x = t.x;
       cnt += t.y;
     }
-    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(x, cnt);
+    res[x0] = make_uint2(x, cnt);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    const uint2 t = t0[e], r = res[t.x];
+    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(r.x, t.y + r.y);
   }
 }
 
@@ -2114,7 +2152,14 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 256 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
-  VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), 0, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch, skip);
+  {
+    // (exit offsets are below E and fit 16 bits up to IDX_MAX_E; the dedupe tables need 14 bytes of LDS per entry)
+    static const bool no_dedupe = [] { const char *e = getenv("VC2HIP_IDX_NO_DEDUPE"); return e && e[0] == '1'; }();
+    const int dedupe = !no_dedupe && E <= 8192;
+    const size_t glds = dedupe ? ((size_t)((E + 1) & ~1) * 4 + (size_t)E * 8 + (size_t)E * 2 + 16) : 0;
+    if (glds) vc2_allow_lds((const void *)k_index_group, glds);
+    VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), glds, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch, skip, dedupe);
+  }
   VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch, skip);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
