@@ -6,6 +6,7 @@ import torch, vc2hip_py
 from synth import synth
 CFG = {
     "cfg1": dict(w=1920, h=1080, cf="422", bits=10, k="LeGall", d=2, u=2, a=4, B=32, kw=dict(q=12)),
+    "cfg2": dict(w=3840, h=2160, cf="422", bits=10, k="DD97", d=4, u=1, a=2, B=16, kw=dict(q=16, scalar=2)),
     "cfg3": dict(w=3840, h=2160, cf="422", bits=10, k="DD97", d=4, u=1, a=2, B=16, kw=dict(mode="HQ_CBR", s=8294400, scalar=2)),
     "cfg4": dict(w=7680, h=4320, cf="444", bits=12, k="Fidelity", d=5, u=1, a=1, B=4, kw=dict(q=40, scalar=8)),
     "cfg5": dict(w=1920, h=1080, cf="422", bits=8, k="LeGall", d=3, u=1, a=2, B=16, wb=1, kw=dict(mode="LD", s=1036800)),
@@ -13,7 +14,10 @@ CFG = {
 dev = torch.device("cuda:0")
 hip = vc2hip_py.Vc2Hip(0)
 for name in sys.argv[1:] or list(CFG):
-    c = CFG[name]
+    batch = None
+    if "@" in name: name, batch = name.split("@")[0], int(name.split("@")[1])   # cfg2@32: another batch size
+    c = dict(CFG[name])
+    if batch: c["B"] = batch
     wb = c.get("wb", 2)
     fmt = vc2hip_py.picture_format(c["w"], c["h"], c["cf"], c["bits"], wb)
     cp = vc2hip_py.coding_params(hip.lib, fmt, c["k"], c["d"], c["u"], c["a"], **c["kw"])

@@ -22,10 +22,15 @@
 // Same LevelParams and the same results as the tile kernels of vc2hip_dwt_fast.hip, which remain for every geometry
 // this scheme does not cover (slice footprints below one chunk, very narrow planes, padded widths, Fidelity planes
 // that are not whole blocks of eight row pairs).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 #include "vc2hip_internal.h"
 #include "vc2hip_store.h"
@@ -38,6 +43,18 @@ __constant__ QuantTables c_qst;
 void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s) {
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_qst), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
 }
+
+#ifdef VC2HIP_STAMPS // diagnostic build only (tools/stamps.py): per-wavefront start / end times of the streaming kernels
+__device__ unsigned long long *g_stamps;
+#define VC2_STAMP_BEGIN const unsigned long long stamp_t0 = wall_clock64();
+#define VC2_STAMP_END(work) do { if (threadIdx.x == 0 && g_stamps) { \
+    const size_t bid = blockIdx.x; \
+    unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+    g_stamps[4 * bid] = stamp_t0; g_stamps[4 * bid + 1] = wall_clock64(); g_stamps[4 * bid + 2] = ((unsigned long long)xcc << 32) | hw; g_stamps[4 * bid + 3] = (work); } } while (0)
+#else
+#define VC2_STAMP_BEGIN
+#define VC2_STAMP_END(work)
+#endif
 
 namespace {
 
@@ -254,21 +271,50 @@ struct Strip {
   int nsl, sx0;     // slices across the owned lanes, first slice
   int kA, kB;       // output row pairs [kA, kB)
 };
-template <int K> __device__ __forceinline__ bool strip_of_block(const LevelParams &p, int comp, Strip &s) {
+// Work items are (picture, component, strip, segment); all of them cost the same.  The grid is one-dimensional and holds
+// working items only, numbered so that the eight XCDs (consecutive workgroups go to consecutive XCDs: block b runs on
+// XCD b mod 8) get equal shares and an XCD walks down the segments of one strip -- neighbouring segments share their
+// run-in rows in that XCD's L2: b = (group * segments + segment) * 8 + column mod 8, column = group * 8 + b mod 8, the
+// columns being all (picture, strip) of the luma planes, then of the U planes, then of the V planes.
+// (Round 2 launched a strips x segments x (3 * pictures) grid: with 8 luma and 4 chroma strips the XCD was the strip
+// number, XCDs 0-3 got three times the work of XCDs 4-7 and half the chip idled for half of the kernel.)
+template <int K> __device__ __forceinline__ bool strip_of_block(const LevelParams &p, int &comp, int &pic, Strip &s) {
   constexpr int HLN = halo_lanes<K>();
-  const int strip = blockIdx.x, seg = blockIdx.y;
-  if (strip >= p.st_strips[comp] || seg >= p.st_segs[comp]) return false;
-  const int nch = p.in_w[comp] >> 3, np = p.in_h[comp] >> 1, out = p.st_out[comp];
+  const int b = blockIdx.x, x = b & 7, t = b >> 3;
+  const int seg = t % p.st_segmax, col = (t / p.st_segmax) * 8 + x;
+  const int n0 = p.st_npic * p.st_strips[0], n1 = p.st_npic * p.st_strips[1], n2 = p.st_npic * p.st_strips[2];
+  int within;
+  if (col < n0) { comp = 0; within = col; }
+  else if (col < n0 + n1) { comp = 1; within = col - n0; }
+  else if (col < n0 + n1 + n2) { comp = 2; within = col - n0 - n1; }
+  else return false;
+  if (seg >= p.st_segs[comp]) return false; // (components of different heights: 4:2:0)
+  pic = within / p.st_strips[comp];
+  const int strip = within - pic * p.st_strips[comp];
+  const int nch = p.in_w[comp] >> 3, out = p.st_out[comp];
   s.c0 = max(min(max(strip * out - HLN, 0), nch - 64), 0); // (a plane narrower than 64 chunks: one strip from chunk 0, idle lanes behind it)
   s.lo = strip * out - s.c0;
   s.hi = min((strip + 1) * out, nch) - s.c0;
   s.nsl = (s.hi - s.lo) >> p.st_llps[comp];
   s.sx0 = (strip * out) >> p.st_llps[comp];
-  s.kA = seg * p.st_py[comp];
-  s.kB = min(s.kA + p.st_py[comp], np);
+  const int bsh = p.fh[comp] >> 1; // segment = the slice rows [seg * ys / nseg, (seg + 1) * ys / nseg)
+  s.kA = (int)(__umul24(seg, p.ys) / (unsigned)p.st_segmax) * bsh;
+  s.kB = (int)(__umul24(seg + 1, p.ys) / (unsigned)p.st_segmax) * bsh;
   return true;
 }
 
+// Issue priority in turn.  A SIMD serves its oldest wavefront first; with every wavefront slot filled by one launch the
+// first-dispatched wavefront of a SIMD finished in 150 us and the last-dispatched in 260 (measured, inverse level 0), and
+// the chip idled through that tail.  Wavefronts that take turns at the highest priority (a new turn every ring block) run
+// at the same pace and end together.
+__device__ __forceinline__ void prio_turn(int v) {
+  switch (v & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
 __device__ __forceinline__ int ilog2d(int v) { return 31 - __clz(v); }
 // address arithmetic: row / slice numbers and row / record lengths are far below 2^24 and their products (element offsets
 // inside one picture) below 2^32, so the full-rate 24-bit multiply serves instead of 64-bit multiplies
@@ -279,8 +325,15 @@ __device__ __forceinline__ size_t mul24z(int a, int b) { return (size_t)__umul24
 // ------------------------------------------------------------------------------------------
 // TAIL: the plane's pair count need not be a multiple of the ring length (its own instantiation, levels below the first
 // only: the tails cost registers -- 154 instead of 113 -- and the level-0 kernels of every BASELINE format do not need them)
+// wavefronts per SIMD the register allocator must leave room for: the steady instantiations live on occupancy (their
+// budgets -- 128 registers, 256 for Fidelity's rings of eight -- are met without scratch; a few registers more would halve
+// or quarter the wavefronts), the TAIL ones (rarely used, small planes) take what they need
+#ifndef VC2_STREAM_WPE
+#define VC2_STREAM_WPE 4
+#endif
+template <int K, bool TAIL> constexpr int stream_wpe() { return TAIL ? 1 : K == VC2HIP_FIDELITY ? 2 : VC2_STREAM_WPE; }
 template <int K, bool FIRST, class ST, bool TAIL = false>
-__global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
+__global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_fwd_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, false>;
   using T = typename VE::T;
@@ -288,9 +341,10 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ST *stg = (ST *)smem;
   const int lane = threadIdx.x;
-  const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
+  int comp, pic;
+  VC2_STAMP_BEGIN
   Strip sp;
-  if (!strip_of_block<K>(p, comp, sp)) return;
+  if (!strip_of_block<K>(p, comp, pic, sp)) { VC2_STAMP_END(0); return; }
   constexpr int ACC = WT<K>::accuracy;
   const int in_h = p.in_h[comp], in_w = p.in_w[comp], np = in_h >> 1;
   const int chunk = min(sp.c0 + lane, (in_w >> 3) - 1); // (lanes behind a narrow plane repeat its last chunk and own nothing)
@@ -405,7 +459,9 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
   // and the load of the pair PF ahead.  The compiler's wait for the consumed rows (a wait for everything outstanding:
   // the waits inside this loop are not counted ones) then finds operations that had a whole iteration to complete.
   const int m0 = max(sp.kA + T::sum_dmin(), 0) & ~(RL - 1); // walks start at multiples of RL (a longer run-in is harmless)
-  const bool last = sp.kB == np;                            // the segment ends at the plane's bottom
+  // the walk reaches the plane's bottom (its steady blocks would run past the last pair): the bottom handling, whether or
+  // not the segment's own rows end there (rows beyond kB are computed and not stored)
+  const bool last = sp.kB + T::OFFL + RL - 1 > np;
   const int mend = last ? np : sp.kB + T::OFFL;             // steady-state iterations: [m0, mend) in whole blocks of RL
   const int mload = np - 1;                                 // loads beyond it repeat the last pair (their results are not used)
 #pragma unroll
@@ -452,7 +508,8 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
     mb += RL;
   }
   const int mstop = last ? (np & ~(RL - 1)) : mend; // whole steady blocks (a walk that does not end at the bottom may run over)
-  for (; mb < mstop; mb += RL) VC2_FWD_BLOCK(0)
+  const int prio0 = (int)(blockIdx.x >> 10);
+  for (; mb < mstop; mb += RL) { if (p.st_prio) prio_turn(prio0 + (mb >> p.st_prio)); VC2_FWD_BLOCK(0) }
   if (last) { // the np mod RL pairs left, then the OFFL iterations below the plane at the phases that follow
 #define VC2_FWD_DRAIN(R) { VC2_FWD_ITERD((R + 0) % RL, 2, 0) VC2_FWD_ITERD((R + 1) % RL, 2, 1) VC2_FWD_ITERD((R + 2) % RL, 2, 2) \
     VC2_FWD_ITERD((R + 3) % RL, 2, 3) VC2_FWD_ITERD((R + 4) % RL, 2, 4) VC2_FWD_ITERD((R + 5) % RL, 2, 5) VC2_FWD_ITERD((R + 6) % RL, 2, 6) }
@@ -471,6 +528,7 @@ __global__ __launch_bounds__(64) void k_fwd_stream(const LevelParams p) {
 #undef VC2_FWD_ITERD
   if (ll_k >= 0 && own) S_::store4(llp + mul24z(ll_k, ow), llp_w + mul24z(ll_k, ow), llv[0], llv[1], llv[2], llv[3]);
   if (flush_sv >= 0) flush(flush_sv);
+  VC2_STAMP_END(1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -487,16 +545,17 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
 }
 
 template <int K, bool FINAL, class ST, bool TAIL = false>
-__global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
+__global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_inv_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, true>;
   using T = typename VE::T;
   constexpr int RL = RLK<K>;
   __shared__ int qtab[360]; // quant_factor / quant_offset / domain limit by adjusted index
   const int lane = threadIdx.x;
-  const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
+  int comp, pic;
+  VC2_STAMP_BEGIN
   Strip sp;
-  if (!strip_of_block<K>(p, comp, sp)) return;
+  if (!strip_of_block<K>(p, comp, pic, sp)) { VC2_STAMP_END(0); return; }
   for (int i = lane; i < 120; i += 64) {
     const int qf = c_qst.qf[i], off = c_qst.off[i];
     qtab[i] = qf; qtab[120 + i] = off;
@@ -715,7 +774,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
   VE eng;
   eng.clear();
   const int m0 = max(sp.kA + T::sum_dmin(), 0) & ~(RL - 1);
-  const bool last = sp.kB == np;
+  const bool last = sp.kB + T::OFFL + RL - 1 > np; // (as in the forward kernel)
   const int mend = last ? np : sp.kB + T::OFFL;
   const int mload = np - 1;
   int sv_have = -1;
@@ -764,7 +823,8 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
     mb += RL;
   }
   const int mstop = last ? (np & ~(RL - 1)) : mend;
-  for (; mb < mstop; mb += RL) VC2_INV_BLOCK(0)
+  const int prio0 = (int)(blockIdx.x >> 10);
+  for (; mb < mstop; mb += RL) { if (p.st_prio) prio_turn(prio0 + (mb >> p.st_prio)); VC2_INV_BLOCK(0) }
   if (last) { // as in the forward kernel
 #define VC2_INV_DRAIN(R) { VC2_INV_ITERD((R + 0) % RL, 2, 0) VC2_INV_ITERD((R + 1) % RL, 2, 1) VC2_INV_ITERD((R + 2) % RL, 2, 2) \
     VC2_INV_ITERD((R + 3) % RL, 2, 3) VC2_INV_ITERD((R + 4) % RL, 2, 4) VC2_INV_ITERD((R + 5) % RL, 2, 5) VC2_INV_ITERD((R + 6) % RL, 2, 6) }
@@ -782,6 +842,7 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
 #undef VC2_INV_ITER
 #undef VC2_INV_ITERD
   if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }
+  VC2_STAMP_END(1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -789,9 +850,19 @@ __global__ __launch_bounds__(64) void k_inv_stream(const LevelParams p) {
 // ------------------------------------------------------------------------------------------
 template <int K, bool EDGE, bool INV, class ST, bool TAIL>
 void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds, hipStream_t s) {
-  int gx = 0, gy = 0;
-  for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.st_strips[c]); gy = std::max(gy, p.st_segs[c]); }
-  dim3 grid(gx, gy, 3 * n_pictures), block(64);
+  const int cols = (p.st_strips[0] + p.st_strips[1] + p.st_strips[2]) * n_pictures;
+  const int gx = ((cols + 7) / 8) * p.st_segmax * 8, gy = 1;
+  dim3 grid(gx), block(64);
+#ifdef VC2HIP_STAMPS
+  const char *stamp_file = getenv("VC2HIP_STAMPS_FILE");
+  const size_t stamp_n = (size_t)gx * 4;
+  unsigned long long *d_st = nullptr;
+  if (stamp_file) {
+    (void)hipMalloc((void **)&d_st, stamp_n * 8);
+    (void)hipMemsetAsync(d_st, 0, stamp_n * 8, s);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stamps), &d_st, sizeof d_st, 0, hipMemcpyHostToDevice, s);
+  }
+#endif
   if constexpr (INV) {
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
     vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST, TAIL>, 64 * 1024);
@@ -801,6 +872,22 @@ void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds
     vc2_allow_lds((const void *)k_fwd_stream<K, EDGE, ST, TAIL>, 64 * 1024);
     VC2_LAUNCH(L, (k_fwd_stream<K, EDGE, ST, TAIL>), grid, block, lds, s, p);
   }
+#ifdef VC2HIP_STAMPS
+  if (stamp_file) {
+    std::vector<unsigned long long> h(stamp_n);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), d_st, stamp_n * 8, hipMemcpyDeviceToHost);
+    unsigned long long *none = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &none, sizeof none);
+    (void)hipFree(d_st);
+    if (FILE *fp = fopen(stamp_file, "ab")) {
+      const int hdr[8] = {INV ? 1 : 0, EDGE ? 1 : 0, gx, gy, 1, (int)lds, 0, 0};
+      fwrite(hdr, sizeof hdr, 1, fp);
+      fwrite(h.data(), 8, stamp_n, fp);
+      fclose(fp);
+    }
+  }
+#endif
   vc2_prof_end(L, s);
 }
 
@@ -839,6 +926,67 @@ int halo_lanes_of(int kernel) {
 }
 bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// row pairs a segment walks besides its own: the run-in above (rounded down to a ring block) and the run-out below
+template <int K> constexpr int runin_pairs() { return -VT<K, false>::sum_dmin() + VT<K, false>::OFFL + RLK<K>; }
+int runin_of(int kernel) {
+  switch (kernel) {
+    case VC2HIP_DD97: return runin_pairs<VC2HIP_DD97>();
+    case VC2HIP_LEGALL: return runin_pairs<VC2HIP_LEGALL>();
+    case VC2HIP_DD137: return runin_pairs<VC2HIP_DD137>();
+    case VC2HIP_HAAR0: return runin_pairs<VC2HIP_HAAR0>();
+    case VC2HIP_HAAR1: return runin_pairs<VC2HIP_HAAR1>();
+    case VC2HIP_FIDELITY: return runin_pairs<VC2HIP_FIDELITY>();
+    case VC2HIP_DAUB97: return runin_pairs<VC2HIP_DAUB97>();
+  }
+  return 8;
+}
+// wavefront slots of the device for one streaming kernel: the runtime's answer per CU, in whole wavefronts per SIMD
+// (one-wavefront workgroups are dealt to the four SIMDs in turn: 13 per CU by LDS ran as 12), times the CUs
+template <int K, bool EDGE, bool INV, class ST, bool TAIL> int slots_of(size_t lds) {
+  int nb = 0, dev = 0;
+  hipDeviceProp_t prop;
+  const void *fn = INV ? (const void *)k_inv_stream<K, EDGE, ST, TAIL> : (const void *)k_fwd_stream<K, EDGE, ST, TAIL>;
+  vc2_allow_lds(fn, 64 * 1024);
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, lds) != hipSuccess || nb < 1)
+    return 256 * 8;
+  if (nb >= 4) nb &= ~3;
+  return nb * prop.multiProcessorCount;
+}
+template <bool INV, class ST> int slots_dispatch(int kernel, bool edge, bool tail, size_t lds) {
+#define VC2_CASE(KK)                                                                       \
+  case KK:                                                                                 \
+    if (edge) return slots_of<KK, true, INV, ST, false>(lds);                              \
+    if (tail) { if constexpr (KK != VC2HIP_FIDELITY) return slots_of<KK, false, INV, ST, true>(lds); return 2048; } \
+    return slots_of<KK, false, INV, ST, false>(lds);
+  switch (kernel) {
+    VC2_CASE(VC2HIP_DD97)
+    VC2_CASE(VC2HIP_LEGALL)
+    VC2_CASE(VC2HIP_DD137)
+    VC2_CASE(VC2HIP_HAAR0)
+    VC2_CASE(VC2HIP_HAAR1)
+    VC2_CASE(VC2HIP_FIDELITY)
+    VC2_CASE(VC2HIP_DAUB97)
+  }
+#undef VC2_CASE
+  return 2048;
+}
+int stream_slots(int kernel, bool edge, bool inverse, bool store16, bool tail, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int, int, size_t, int>, int> cache; // (per device: one process may drive several GPUs)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const auto key = std::make_tuple(kernel, (int)edge, (int)inverse, (int)store16, (int)tail, lds, dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int v;
+  if (inverse) v = store16 ? slots_dispatch<true, int16_t>(kernel, edge, tail, lds) : slots_dispatch<true, int32_t>(kernel, edge, tail, lds);
+  else v = store16 ? slots_dispatch<false, int16_t>(kernel, edge, tail, lds) : slots_dispatch<false, int32_t>(kernel, edge, tail, lds);
+  cache[key] = v;
+  return v;
+}
+
 } // namespace
 
 // The streaming kernels apply when every active component has a plane at least 64 chunks wide without horizontal
@@ -850,8 +998,8 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
   if (hln < 0) return 0;
   const int elem = store16 ? 2 : 4, ep = 16 / elem;
   size_t lds = 0;
-  long long waves = 0;
   p.st_tail = 0;
+  p.st_segmax = 0;
   for (int c = 0; c < 3; ++c) {
     p.st_strips[c] = p.st_segs[c] = 0;
     if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
@@ -883,31 +1031,33 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     lds = std::max(lds, img);
   }
   if (lds > 40 * 1024) return 0;
-  // Rows per segment: whole block rows.  A segment runs in over the filter's reach before its first output (4 pairs for
-  // DD97, 14 for Fidelity), so short segments waste work -- 16-pair segments 20 % of it -- while long ones leave the
-  // chip without wavefronts.  Measured on 16 UHD pictures: 32 pairs beat 16 (level 0: 0.339 -> 0.322 ms forward,
-  // 0.425 -> 0.388 ms inverse; level 1 a little) and 64 (deeper levels); small batches take 16 to have wavefronts at all.
-  static const int force_py = [] { const char *e = getenv("VC2HIP_STREAM_PY"); return e ? atoi(e) : 0; }();
-  const int py_long = kernel == VC2HIP_FIDELITY ? 64 : 32, py_short = kernel == VC2HIP_FIDELITY ? 64 : 16;
-  auto count = [&](int py0) {
-    long long w = 0;
-    for (int c = 0; c < 3; ++c) {
-      if (!p.st_strips[c]) continue;
-      const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2, py = ((std::max(py0, bsh) + bsh - 1) / bsh) * bsh;
-      w += (long long)p.st_strips[c] * ((np + py - 1) / py) * n_pictures;
-    }
-    return w;
-  };
-  const int py0 = force_py > 0 ? force_py : (count(py_long) >= 2048 ? py_long : py_short);
-  for (int c = 0; c < 3; ++c) {
-    if (!p.st_strips[c]) continue;
-    const int np = p.in_h[c] / 2, bsh = p.fh[c] / 2;
-    const int py = ((std::max(py0, bsh) + bsh - 1) / bsh) * bsh;
-    p.st_py[c] = py;
-    p.st_segs[c] = (np + py - 1) / py;
-    waves += (long long)p.st_strips[c] * p.st_segs[c];
+  // Segments: whole rows of slices, `nseg` per strip, the same for every component; segment g of a strip covers the
+  // slice rows [g * ys / nseg, (g + 1) * ys / nseg) -- heights differ by at most one slice row.  A segment runs in over
+  // the filter's reach before its first output row (about 8 row pairs for DD97, 22 for Fidelity): short segments waste
+  // work, long ones leave the chip without wavefronts, and a launch whose wavefronts do not fill whole rounds of the
+  // chip's wavefront slots idles through its last round (round 2: 8704 equal wavefronts for 4096 slots).  So: the nseg
+  // that minimises rounds * (rows of the tallest segment + run-in), rounds = ceil(strips * nseg / slots).
+  static const int force_nseg = [] { const char *e = getenv("VC2HIP_STREAM_NSEG"); return e ? atoi(e) : 0; }();
+  int cols = 0, bsh_max = 1;
+  for (int c = 0; c < 3; ++c) if (p.st_strips[c]) { cols += p.st_strips[c] * n_pictures; bsh_max = std::max(bsh_max, p.fh[c] / 2); }
+  const int slots = stream_slots(kernel, edge, inverse, store16, p.st_tail != 0, lds);
+  const int runin = runin_of(kernel);
+  int nseg = 1;
+  long long best = -1;
+  for (int g = 1; g <= p.ys; ++g) {
+    const long long rounds = ((long long)cols * g + slots - 1) / slots;
+    const long long cost = rounds * ((long long)((p.ys + g - 1) / g) * bsh_max + runin);
+    if (best < 0 || cost <= best) { best = cost; nseg = g; } // (ties: more wavefronts)
   }
-  (void)waves;
+  if (force_nseg > 0) nseg = std::min(force_nseg, p.ys);
+#ifdef VC2HIP_STAMPS
+  fprintf(stderr, "stream level: kernel %d edge %d inv %d lds %zu cols %d slots %d runin %d -> nseg %d\n", kernel, (int)edge, (int)inverse, lds, cols, slots, runin, nseg);
+#endif
+  for (int c = 0; c < 3; ++c) if (p.st_strips[c]) p.st_segs[c] = nseg;
+  p.st_segmax = nseg;
+  p.st_npic = n_pictures;
+  static const int prio = [] { const char *e = getenv("VC2HIP_STREAM_PRIO"); return e ? atoi(e) : 2; }();
+  p.st_prio = prio; // a new turn at the highest priority every four row pairs (measured: 2, 3 and 4 alike; off: inverse level 0 9 % slower)
   return lds;
 }
 int vc2_launch_forward_stream(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s) {

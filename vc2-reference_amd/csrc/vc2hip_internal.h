@@ -110,11 +110,12 @@ struct LevelParams {
   int debug_skip;             // -DVC2HIP_ABLATE builds only (tools/ablate_*.py): 1 no loads, 2 no lifting, 4 no stores
   int qmatrix[VC2_MAX_BANDS];
   // streaming kernels (vc2hip_dwt_stream.hip), set by vc2_stream_level_applicable
-  int st_strips[3], st_segs[3]; // wavefronts across / down a plane
+  int st_strips[3], st_segs[3]; // wavefronts across / down a plane (segments: whole rows of slices)
   int st_out[3];                // chunks (8 samples) a strip owns
   int st_llps[3];               // log2 chunks per slice
-  int st_py[3];                 // row pairs per segment
   int st_tail;                  // some plane's pair count is not a multiple of four: the TAIL instantiation
+  int st_prio;                  // > 0: wavefronts take turns at the highest issue priority, a new turn every 2^st_prio row pairs
+  int st_segmax, st_npic;       // most segments of any component; pictures of the launch (the kernels' work-item numbering)
   // inverse, streaming kernels: element offset (from the picture's store) of this level's HL band plane, LH and HH behind
   // it, when the decoder keeps the level's bands as planes (BandPlanes below); -1: in the slice records
   long long bp_base[3];
