@@ -1533,16 +1533,24 @@ void vc2_upload_unpack_lut(hipStream_t s) {
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_unp_lut), host, sizeof host, 0, hipMemcpyHostToDevice, s);
 }
 
-// 33..64 unread bits at the top of `acc`; the next stream word is already in a register.  Words are fetched as aligned
-// dwords from the picture's payload (a wave-uniform base + a 32-bit offset per lane); bits past the bounded data read
-// as 1 (VLC.cpp:182-185) and no word without a data bit is ever loaded.
+// 33..64 unread bits at the top of `acc`; behind them a queue of up to four stream words in registers, and behind that
+// the next sixteen bytes of the stream, already requested.  A lane reads ITS OWN stream: the 64 loads of a wavefront
+// instruction go to 64 different cache lines, and with one dword per load every 128-byte line of the payload crossed
+// the L2 -> L1 path 32 times (the streams of a CU's wavefronts do not fit its 32 KiB L1: 3.4 - 6.7 x the payload even
+// from beyond L2, round 2).  Sixteen bytes per load make that a quarter of the requests, each a quarter as often, and
+// put two to five words of distance between a request and its use.  Words are dword-aligned (a wave-uniform base + a
+// 32-bit offset per lane); bits past the bounded data read as 1 (VLC.cpp:182-185) and no word without a data bit is
+// ever loaded.
+struct __attribute__((aligned(4))) Dword4 { unsigned x, y, z, w; };
 struct Reader32 {
   unsigned long long acc;
-  int have;      // valid bits in acc, 33..64 between turns
-  unsigned nw;   // the word after those in acc
-  unsigned off;  // byte offset (from the payload base) of the word after nw
-  int left;      // data bits from that word on (<= 0: none)
-  __device__ __forceinline__ unsigned fetch(const uint8_t *pay) {
+  int have;                // valid bits in acc, 33..64 between turns
+  unsigned q0, q1, q2, q3; // the words after those in acc (q0 first); qn of them are valid, 1..4 between turns
+  int qn;
+  unsigned n0, n1, n2, n3; // the four words after the queue
+  unsigned off;            // byte offset (from the payload base) of the word after those
+  int left;                // data bits from that word on (<= 0: none)
+  __device__ __forceinline__ unsigned fetch1(const uint8_t *pay) {
     unsigned v = ~0u;
     if (left > 0) {
       v = __builtin_bswap32(*(const unsigned *)(pay + off));
@@ -1552,24 +1560,34 @@ struct Reader32 {
     left -= 32;
     return v;
   }
+  __device__ __forceinline__ void fetch4(const uint8_t *pay) {
+    if (left >= 128) { // sixteen bytes of data: one load
+      const Dword4 v = *(const Dword4 *)(pay + off);
+      n0 = __builtin_bswap32(v.x); n1 = __builtin_bswap32(v.y); n2 = __builtin_bswap32(v.z); n3 = __builtin_bswap32(v.w);
+      off += 16;
+      left -= 128;
+    } else { n0 = fetch1(pay); n1 = fetch1(pay); n2 = fetch1(pay); n3 = fetch1(pay); } // the stream's end: word by word
+  }
   // nbytes of data at byte offset pos of the payload
   __device__ __forceinline__ void init(const uint8_t *pay, unsigned pos, int nbytes) {
     const int lead = 8 * (int)(pos & 3u);
     off = pos & ~3u;
     left = nbytes > 0 ? 8 * nbytes + lead : 0;
-    const unsigned w0 = fetch(pay), w1 = fetch(pay);
-    acc = (((unsigned long long)w0 << 32) | w1) << lead;
+    fetch4(pay);
+    acc = (((unsigned long long)n0 << 32) | n1) << lead;
     have = 64 - lead;
-    nw = fetch(pay);
+    q0 = n2; q1 = n3; q2 = ~0u; q3 = ~0u; qn = 2;
+    fetch4(pay);
   }
   __device__ __forceinline__ unsigned top() const { return (unsigned)(acc >> 32); }
   __device__ __forceinline__ void skip(const uint8_t *pay, int n) { // n <= 32
     acc <<= n;
     have -= n;
     if (have <= 32) {
-      acc |= (unsigned long long)nw << (32 - have);
+      acc |= (unsigned long long)q0 << (32 - have);
       have += 32;
-      nw = fetch(pay);
+      q0 = q1; q1 = q2; q2 = q3;
+      if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; fetch4(pay); }
     }
   }
 };
