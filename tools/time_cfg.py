@@ -23,15 +23,22 @@ for name in sys.argv[1:] or list(CFG):
     cp = vc2hip_py.coding_params(hip.lib, fmt, c["k"], c["d"], c["u"], c["a"], **c["kw"])
     B = c["B"]
     rb = hip.raw_picture_bytes(fmt); stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    tight = int(os.environ.get("TIME_CFG_STRIDE", "0"))   # (experiments: the decoder reads from tighter payload slots)
     raw = synth(c["w"], c["h"], c["cf"], c["bits"], 1234, frames=1, word_bytes=wb)
     one = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
     d_raw = one.repeat(B)
     d_pay = torch.zeros(B * stride, dtype=torch.uint8, device=dev); d_len = torch.zeros(B, dtype=torch.int64, device=dev)
     d_out = torch.zeros(B * rb, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    d_pay2 = torch.zeros(B * tight, dtype=torch.uint8, device=dev) if tight else None
     def step():
         hip.encode_batch_dev(d_raw.data_ptr(), B, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
-        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out.data_ptr())
+        if tight:
+            hip.sync()
+            d_pay2.view(B, tight).copy_(d_pay.view(B, stride)[:, :tight]); torch.cuda.synchronize()
+            hip.decode_batch_dev(d_pay2.data_ptr(), tight, d_len.data_ptr(), B, fmt, cp, d_out.data_ptr())
+        else:
+            hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out.data_ptr())
     for _ in range(2): step()
     hip.sync()
     hip.profile_reset(); hip.profile_enable(True)

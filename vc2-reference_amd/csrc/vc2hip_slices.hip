@@ -1810,7 +1810,11 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipS
 // ------------------------------------------------------------------------------------------
 // chunk size: 16 KiB, or 32 KiB when a slice can be longer than 8191 bytes (entry offsets must stay below the
 // chunk size and chunk-relative positions below 2^16)
-static int idx_chunk(int E) { return E <= 8191 ? 16384 : 32768; }
+// (8 KiB while an entry region and its landing region fit one: four workgroups per CU instead of two, half the hops per
+// walk -- the table kernel's time is its chain of dependent LDS reads)
+// (measured, same box, table + chain + emit: scalar 1 (E = 769, 1080p) 0.229 -> 0.203 ms with 8 KiB chunks; scalar 2 (E = 1534, UHD)
+// 0.248 -> 0.254 ms: the E entries and the table of a chunk do not shrink with it)
+static int idx_chunk(int E) { return E <= 1024 ? 8192 : E <= 8191 ? 16384 : 32768; }
 
 __device__ __forceinline__ int slice_len_lds(const uint8_t *b, int pos, int prefix, int scalar) {
   int q = pos + prefix + 1;
@@ -1836,18 +1840,26 @@ __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long
   }
 }
 
-static constexpr int IDX_THREADS = 1024;
 static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
+constexpr int idx_threads(int CH) { return CH <= 8192 ? 512 : 1024; }
 
 // Chunk function by table walk.  One pass fills next[i] = the position reached if a slice started at byte i
 // of the chunk, from the three length bytes behind every byte position (throughput-bound LDS work: PER
 // independent reads per thread and step).  Then every entry offset walks next[] -- one LDS read per hop
 // instead of three dependent ones -- until it leaves the chunk.
+// A table entry is one word: exit offset << 16 | slices (both below 2^15: E <= IDX_MAX_E, a chunk holds at most CH / 4 slices).
+// (Per-phase stamps of a workgroup's life, 8 KiB chunks, scalar 2: chunk in 1.9 us, next[] 1.8, entry walks 1.2, landing
+// walks 0.6, table out ~2: a chain of latencies at ~55 % of the CU's LDS instruction rate.  Tried on it and measured no
+// better: next[] in place of the staged bytes with 256-thread workgroups (six chunks per CU in flight, but next[] alone then
+// took 5 us: LDS-bound), a thread's walks advanced side by side, a persistent grid that takes the chunks from the
+// lengths and fetches the next chunk's bytes while it works (same time at 8 KiB, 0.24 against 0.16 ms at 16 KiB),
+// the workgroups of chunks beyond the payload last in the grid instead of between those of every picture.)
 template <int CH>
-__global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *payload, long long stride,
-                                                                 const unsigned long long *lens, uint2 *tables,
+__global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8_t *payload, long long stride,
+                                                                 const unsigned long long *lens, unsigned *tables,
                                                                  int n_chunks, int E, int prefix, int scalar, unsigned *err, const unsigned *skip,
                                                                  int merge) {
+  constexpr int NT = idx_threads(CH);
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
@@ -1860,11 +1872,11 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
   __syncthreads();
   const int lim = (int)min((unsigned long long)CH, plen - c0); // never walk the zero fill behind the payload
-  constexpr int PER = CH / IDX_THREADS;
+  constexpr int PER = CH / NT;
   {
     int q[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) q[k] = threadIdx.x + k * IDX_THREADS + prefix + 1;
+    for (int k = 0; k < PER; ++k) q[k] = threadIdx.x + k * NT + prefix + 1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       int len[PER];
@@ -1877,17 +1889,17 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
     for (int k = 0; k < PER; ++k) {
       const int n = q[k];
       // a slice that ends behind the payload end leaves the chunk at offset 0 unless it really reaches the next chunk
-      nx[threadIdx.x + k * IDX_THREADS] = (unsigned short)(n >= lim ? (n >= CH ? n : CH) : n);
+      nx[threadIdx.x + k * NT] = (unsigned short)(n >= lim ? (n >= CH ? n : CH) : n);
     }
   }
   __syncthreads();
-  uint2 *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
+  unsigned *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
   if (!merge) {
-    for (int e = threadIdx.x; e < E; e += IDX_THREADS) {
+    for (int e = threadIdx.x; e < E; e += NT) {
       int pos = e, cnt = 0;
       if (e >= lim) pos = CH; // starts behind the payload end: no slice
       while (pos < CH) { pos = nx[pos]; ++cnt; }
-      tab[e] = make_uint2((unsigned)(pos - CH), (unsigned)cnt);
+      tab[e] = (unsigned)(pos - CH) << 16 | (unsigned)cnt;
     }
     return;
   }
@@ -1896,28 +1908,31 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
   // [0, E); the distinct landing bytes are collected, walked once each to the chunk's end, and every entry adds its own
   // hops to its landing byte's result -- a fraction of the dependent LDS reads of E full walks (the kernel's time is
   // those reads).
-  unsigned *need = (unsigned *)(nx + CH);            // per byte of [E, 2E): some walk landed here
-  unsigned *W = need + E;                            // its result: exit offset << 16 | slices
-  unsigned short *list = (unsigned short *)(W + E);  // the landing bytes, dense
+  unsigned *W = (unsigned *)(nx + CH);               // per byte of [E, 2E): the result of a walk from it (exit offset << 16 | slices)
+  unsigned *need = W + E;                            // one bit per byte of [E, 2E): some walk landed here
+  unsigned short *list = (unsigned short *)(need + (E + 31) / 32);  // the landing bytes, dense
   __shared__ unsigned s_count;
-  for (int t = threadIdx.x; t < E; t += IDX_THREADS) need[t] = 0;
+  for (int t = threadIdx.x; t < (E + 31) / 32; t += NT) need[t] = 0;
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
-  constexpr int EPT = 2; // entries per thread (merge needs E <= 2 * IDX_THREADS)
+  constexpr int EPT = 4096 / NT; // entries per thread (the launcher merges only entry regions of up to 4096 bytes)
   int la[EPT], ca[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
-    const int e = threadIdx.x + k * IDX_THREADS;
+    const int e = threadIdx.x + k * NT;
     la[k] = CH; ca[k] = 0;
     if (e < E && e < lim) {
       int pos = e, cnt = 0;
       while (pos < E) { pos = nx[pos]; ++cnt; }
       la[k] = pos; ca[k] = cnt;
-      if (pos < CH && atomicExch(&need[pos - E], 1u) == 0u) list[atomicAdd(&s_count, 1u)] = (unsigned short)(pos - E);
+      if (pos < CH) {
+        const int t = pos - E;
+        if (!(atomicOr(&need[t >> 5], 1u << (t & 31)) >> (t & 31) & 1u)) list[atomicAdd(&s_count, 1u)] = (unsigned short)t;
+      }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < (int)s_count; i += IDX_THREADS) {
+  for (int i = threadIdx.x; i < (int)s_count; i += NT) {
     const int t = list[i];
     int pos = E + t, cnt = 0;
     while (pos < CH) { pos = nx[pos]; ++cnt; }
@@ -1926,10 +1941,10 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
-    const int e = threadIdx.x + k * IDX_THREADS;
+    const int e = threadIdx.x + k * NT;
     if (e >= E) continue;
-    if (la[k] >= CH) tab[e] = make_uint2((unsigned)(la[k] - CH), (unsigned)ca[k]);
-    else { const unsigned w = W[la[k] - E]; tab[e] = make_uint2(w >> 16, (unsigned)ca[k] + (w & 0xFFFFu)); }
+    if (la[k] >= CH) tab[e] = (unsigned)(la[k] - CH) << 16 | (unsigned)ca[k];
+    else tab[e] = W[la[k] - E] + (unsigned)ca[k];
   }
 }
 
@@ -1939,7 +1954,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_tables_nx(const uint8_t *
 //   chain  : per picture, follow entry -> exit through the group functions, then expand every group
 static constexpr int IDX_GROUP = 16;
 
-__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const uint2 *tables,
+__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const unsigned *tables,
                                                      uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH, const unsigned *skip,
                                                      int dedupe) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
@@ -1953,9 +1968,9 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
       for (int k = 0; k < IDX_GROUP; ++k) {
         const int c = g * IDX_GROUP + k;
         if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
-        const uint2 t = tables[((size_t)pic * n_chunks + c) * E + x];
-        x = t.x;
-        cnt += t.y;
+        const unsigned t = tables[((size_t)pic * n_chunks + c) * E + x];
+        x = t >> 16;
+        cnt += t & 0xFFFFu;
       }
       groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(x, cnt);
     }
@@ -1971,9 +1986,9 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int c0 = g * IDX_GROUP;
-  const uint2 *t0 = tables + ((size_t)pic * n_chunks + c0) * E;
+  const unsigned *t0 = tables + ((size_t)pic * n_chunks + c0) * E;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    const unsigned x = t0[e].x;
+    const unsigned x = t0[e] >> 16;
     if (atomicExch(&need[x], 1u) == 0u) list[atomicAdd(&s_count, 1u)] = (unsigned short)x;
   }
   __syncthreads();
@@ -1983,21 +1998,22 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
     for (int k = 1; k < IDX_GROUP; ++k) {
       const int c = c0 + k;
       if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
-      const uint2 t = tables[((size_t)pic * n_chunks + c) * E + x];
-      x = t.x;
-      cnt += t.y;
+      const unsigned t = tables[((size_t)pic * n_chunks + c) * E + x];
+      x = t >> 16;
+      cnt += t & 0xFFFFu;
     }
     res[x0] = make_uint2(x, cnt);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    const uint2 t = t0[e], r = res[t.x];
-    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(r.x, t.y + r.y);
+    const unsigned t = t0[e];
+    const uint2 r = res[t >> 16];
+    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(r.x, (t & 0xFFFFu) + r.y);
   }
 }
 
 constexpr int IDX_MAX_GROUPS = 1024;
-__global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *lens, long long stride, const uint2 *tables,
+__global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *lens, long long stride, const unsigned *tables,
                                                     const uint2 *groups, uint2 *entries, int n_chunks,
                                                     int n_groups, int E, int IDX_CH, const unsigned *skip) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
@@ -2022,35 +2038,39 @@ __global__ __launch_bounds__(64) void k_index_chain(const unsigned long long *le
       if (c >= n_chunks) break;
       entries[(size_t)pic * n_chunks + c] = make_uint2(entry, base);
       if ((unsigned long long)c * IDX_CH >= plen) continue;
-      const uint2 t = tables[((size_t)pic * n_chunks + c) * E + entry];
-      entry = t.x;
-      base += t.y;
+      const unsigned t = tables[((size_t)pic * n_chunks + c) * E + entry];
+      entry = t >> 16;
+      base += t & 0xFFFFu;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_index_emit(const uint8_t *payload, long long stride,
+// One lane per chunk walks from the chunk's (now known) entry and writes the offsets: three dependent byte loads per
+// slice, served by L2 -- a chunk's lane needs ~60 of its 8192 bytes, and all chunks of the batch walk at the same time
+// (round 2 staged every chunk whole into LDS for one walking lane: eight chunks per CU at a time, 0.047 ms).
+__global__ __launch_bounds__(64) void k_index_emit(const uint8_t *payload, long long stride,
                                                    const unsigned long long *lens, const uint2 *entries,
                                                    uint32_t *offsets, int n_chunks, int E, int n_slices,
                                                    int prefix, int scalar, unsigned *err, int IDX_CH, const unsigned *skip) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
-  const int chunk = blockIdx.x, pic = blockIdx.y;
+  (void)E;
+  const int chunk = blockIdx.x * 64 + threadIdx.x, pic = blockIdx.y;
+  if (chunk >= n_chunks) return;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride), c0 = (unsigned long long)chunk * IDX_CH;
   if (c0 >= plen) return;
   const uint2 en = entries[(size_t)pic * n_chunks + chunk];
   if ((int)en.y >= n_slices || (int)en.x >= IDX_CH) return;
-  const int nbytes = (IDX_CH + E + 16 + 15) & ~15;
-  stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int pos = (int)en.x, k = (int)en.y;
-    while (pos < IDX_CH && k < n_slices) {
-      offsets[(size_t)pic * n_slices + k] = (uint32_t)(c0 + pos);
-      if (c0 + pos >= plen) atomicOr(err, VC2_DEVERR_STREAM);
-      pos += slice_len_lds(lds_b, pos, prefix, scalar);
-      ++k;
-    }
+  const uint8_t *pay = payload + (size_t)pic * stride;
+  unsigned long long pos = c0 + en.x;
+  const unsigned long long end = c0 + IDX_CH;
+  int k = (int)en.y;
+  while (pos < end && k < n_slices) {
+    offsets[(size_t)pic * n_slices + k] = (uint32_t)pos;
+    if (pos >= plen) { atomicOr(err, VC2_DEVERR_STREAM); break; } // (what follows starts behind the payload too)
+    unsigned long long q = pos + prefix + 1;
+    for (int c = 0; c < 3; ++c) q += 1 + (q < plen ? (unsigned long long)pay[q] * scalar : 0ull);
+    pos = q;
+    ++k;
   }
 }
 
@@ -2123,7 +2143,7 @@ size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix,
   const size_t n_chunks = (max_payload + ch - 1) / ch + 1;
   if (n_chunks > (size_t)1024 * 16) return 256; // serial walk (see vc2_launch_slice_index)
   const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
-  return (size_t)n_pictures * (n_chunks * (E + 1) + n_groups * E) * sizeof(uint2) + 256;
+  return (size_t)n_pictures * (n_chunks * E * sizeof(unsigned) + (n_chunks + n_groups * E) * sizeof(uint2)) + 512;
 }
 
 void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
@@ -2146,28 +2166,28 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   const int ch = idx_chunk(E);
   // chunk count is bounded by the payload slot size (lens live on the device)
   const int n_chunks = (int)(((size_t)payload_stride + ch - 1) / ch) + 1;
-  uint2 *tables = (uint2 *)workspace;
-  uint2 *entries = tables + (size_t)n_pictures * n_chunks * E;
+  unsigned *tables = (unsigned *)workspace;
+  uint2 *entries = (uint2 *)(((size_t)(tables + (size_t)n_pictures * n_chunks * E) + 15) & ~(size_t)15);
   const size_t stage_bytes = (size_t)((ch + E + 16 + 15) & ~15);
-  vc2_allow_lds((const void *)k_index_emit, stage_bytes);
   vc2_prof_begin(L, "slice_index_tables", s);
   {
-    // merged walks (see the kernel): entry regions of up to 2048 bytes whose landing region lies inside the chunk
+    // merged walks (see the kernel): entry regions of up to 4096 bytes whose landing region lies inside the chunk
     static const bool no_merge = [] { const char *e = getenv("VC2HIP_IDX_NO_MERGE"); return e && e[0] == '1'; }();
-    const int merge = !no_merge && E <= 2 * IDX_THREADS && 2 * E <= ch;
-    const size_t lds = stage_bytes + (size_t)ch * 2 + (merge ? (size_t)E * 10 + 16 : 0);
-    if (ch == 16384) {
-      vc2_allow_lds((const void *)k_index_tables_nx<16384>, lds);
-      VC2_LAUNCH(L, (k_index_tables_nx<16384>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);
-    } else {
-      vc2_allow_lds((const void *)k_index_tables_nx<32768>, lds);
-      VC2_LAUNCH(L, (k_index_tables_nx<32768>), dim3(n_chunks, n_pictures), dim3(IDX_THREADS), lds, s, payload, payload_stride,
-                         lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);
-    }
+    const int merge = !no_merge && E <= 4096 && 2 * E <= ch;
+    const size_t lds = stage_bytes + (size_t)ch * 2 + (merge ? (size_t)E * 6 + ((size_t)(E + 31) / 32) * 4 + 16 : 0);
+#define VC2_IDX_TABLES(CH)                                                                                                    \
+  do {                                                                                                                        \
+    vc2_allow_lds((const void *)k_index_tables_nx<CH>, lds);                                                                  \
+    VC2_LAUNCH(L, (k_index_tables_nx<CH>), dim3(n_chunks, n_pictures), dim3(idx_threads(CH)), lds, s, payload, payload_stride, \
+               lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);                                                  \
+  } while (0)
+    if (ch == 8192) VC2_IDX_TABLES(8192);
+    else if (ch == 16384) VC2_IDX_TABLES(16384);
+    else VC2_IDX_TABLES(32768);
+#undef VC2_IDX_TABLES
   }
   vc2_prof_end(L, s);
-  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 256 MiB
+  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 128 MiB
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
   vc2_prof_begin(L, "slice_index_chain", s);
   {
@@ -2178,10 +2198,11 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     if (glds) vc2_allow_lds((const void *)k_index_group, glds);
     VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), glds, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch, skip, dedupe);
   }
-  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(64), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch, skip);
+  // (one lane follows the groups of a picture; then a thread per group expands it: sixteen dependent reads, all groups at once)
+  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(std::min(1024, (n_groups + 63) / 64 * 64)), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch, skip);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
-  VC2_LAUNCH(L, k_index_emit, dim3(n_chunks, n_pictures), dim3(256), stage_bytes, s, payload,
+  VC2_LAUNCH(L, k_index_emit, dim3((n_chunks + 63) / 64, n_pictures), dim3(64), 0, s, payload,
                      payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch, skip);
   vc2_prof_end(L, s);
 }

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvc2hip.so")
+LIB_PATH = os.environ.get("VC2HIP_LIB") or os.path.join(HERE, "libvc2hip.so")   # (VC2HIP_LIB: A/B of two builds, tools only)
 
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
