@@ -14,8 +14,14 @@ collective on the data path).  Prints ONE JSON line on rank 0:
   cpu_baseline     the oracle (a port of the reference algorithm) on the host cores: 1 thread, and one process per core;
                    the run that also supplies the expected bytes of EVERY slot of the batch
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--no-e2e]
+  other_configs    the other BASELINE configurations (cfg 1, 3, 4, 5-decode), 5 device-resident steps each, digest-checked
+                   against tests/golden/reference_digests.json (cfg 5: against the oracle) -- beside `value`, never part of it
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--no-e2e] [--no-other-configs]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+N > 1: one process per GPU over RCCL (backend nccl); every rank checks its own slots and the verdicts are AND-reduced
+before rank 0 prints.  --dist-backend gloo with VC2_BENCH_DEVICE_MAP=0,0 runs two ranks on ONE GPU (tests/test_multi_rank_gpu.py:
+the real HIP path under torch.distributed.run on the one-GPU box; a correctness exercise, not a scaling measurement).
 """
 import argparse
 import glob
@@ -134,6 +140,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the per-core CPU run (0: one per core)")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the barrier and the MAX-over-ranks (nccl = RCCL; gloo: CPU tensors, for ranks that share a GPU)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the library cuts each batch over (vc2hip_set_streams); 1 = one launch per kernel and "
                          "batch, which is what the roofline figures describe")
@@ -153,8 +162,13 @@ def main():
     from synth import synth
 
     B = args.batch
-    # synthetic pictures: SURVEY Appendix-B generator (seed 1234), B distinct frames
-    frames = synth(W, H, CFMT, BITS, 1234, frames=B)
+    # synthetic pictures: SURVEY Appendix-B generator.  Rank 0: seed 1234, B distinct frames (frames 0-1 are the pair whose
+    # reference digests tests/golden holds).  Every other rank keeps that pair in its slots 0-1 (its own golden check) and
+    # fills the rest with frames of its own seed 1234 + rank: the ranks code different pictures.
+    if rank == 0 or B <= 2:
+        frames = synth(W, H, CFMT, BITS, 1234, frames=B)
+    else:
+        frames = synth(W, H, CFMT, BITS, 1234, frames=2) + synth(W, H, CFMT, BITS, 1234 + rank, frames=B - 2)
     rb = len(frames) // B
 
     # ---- CPU baseline first: nothing has touched the GPU yet, so forking worker processes is safe
@@ -168,14 +182,22 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rank -> HIP device: its local rank, or VC2_BENCH_DEVICE_MAP (comma list indexed by local rank; "0,0" = two ranks on one GPU)
+    dev_map = [int(x) for x in os.environ.get("VC2_BENCH_DEVICE_MAP", "").split(",") if x.strip() != ""]
+    dev_index = dev_map[local_rank] if local_rank < len(dev_map) else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    gloo = args.dist_backend == "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    red_dev = torch.device("cpu") if gloo else dev   # where the reduced scalars live
 
     import vc2hip_py
-    hip = vc2hip_py.Vc2Hip(local_rank)
+    hip = vc2hip_py.Vc2Hip(dev_index)
     if args.streams > 1:
         hip.set_streams(args.streams)
     fmt = vc2hip_py.picture_format(W, H, CFMT, BITS)
@@ -242,45 +264,69 @@ def main():
     dt_enc = timed(enc, args.steps)
     dt_dec = timed(dec, args.steps)
     hip.sync()
-    tmax = torch.tensor([dt, dt_noev, dt_enc, dt_dec], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, dt_noev, dt_enc, dt_dec], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt, dt_noev, dt_enc, dt_dec = tmax.tolist()
 
-    # ---- parity of what was timed: EVERY slot of the batch
+    # ---- parity of what was timed: EVERY slot of the batch, on EVERY rank; the verdicts are AND-reduced and a failure on
+    # any rank suppresses the line
     lens = d_len.cpu().numpy().astype(np.int64)
     coded = int(lens.sum()) / B
-    parity = None
-    if rank == 0:
-        out_host = d_out.cpu().numpy()
-        pay_host = d_pay.cpu().numpy()
-        if cpu is not None:   # against the oracle's bytes of every picture
-            for (k, _, _, stream, sha_dec) in cpu[1]:
-                pay = pay_host[k * stride:k * stride + int(lens[k])].tobytes()
-                if pay != stream[-13 - len(pay):-13] or hashlib.sha256(out_host[k * rb:(k + 1) * rb].tobytes()).hexdigest() != sha_dec:
-                    raise SystemExit(f"slot {k}: HIP output differs from the oracle: refusing to report a number")
-            parity = f"all {B} slots: slice payload and decoded picture byte for byte against the oracle"
-        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_digests.json")))["cfg2"]
-        if B >= 2 and hashlib.sha256(out_host[:2 * rb].tobytes()).hexdigest() != gold["decoded"]["sha256"]:
-            raise SystemExit("decoded pictures 0-1 differ from the reference digest: refusing to report a number")
-        if parity is None:   # no CPU run: slots 0-1 against the reference digest, the rest must decode to what slot 0-1's
-            # sibling pictures decode to when the batch is coded again in another order (slot independence)
-            perm = torch.arange(B - 1, -1, -1, device=dev)
-            d_raw2 = d_raw.view(B, rb)[perm].contiguous().view(-1)
-            d_out2 = torch.zeros_like(d_out)
-            torch.cuda.synchronize()   # torch built these on ITS stream; the library reads them on its own
-            hip.encode_batch_dev(d_raw2.data_ptr(), B, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
-            hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out2.data_ptr())
-            hip.sync()
-            if not torch.equal(d_out2.view(B, rb)[perm].contiguous().view(-1), d_out):
-                raise SystemExit("a picture decodes differently in another slot: refusing to report a number")
-            parity = "slots 0-1 against the reference digest; every slot against the same picture coded in another slot"
-        del out_host, pay_host
+    parity, failure = None, None
+    if os.environ.get("VC2_BENCH_SABOTAGE") == "1" and B >= 2:   # tests/test_multi_rank_gpu.py: the guard must catch a wrong slot
+        d_out.view(B, rb)[[0, 1]] = d_out.view(B, rb)[[1, 0]]
+    out_host = d_out.cpu().numpy()
+    pay_host = d_pay.cpu().numpy()
+    if cpu is not None:   # (rank 0 of a one-rank run) against the oracle's bytes of every picture
+        for (k, _, _, stream, sha_dec) in cpu[1]:
+            pay = pay_host[k * stride:k * stride + int(lens[k])].tobytes()
+            if pay != stream[-13 - len(pay):-13] or hashlib.sha256(out_host[k * rb:(k + 1) * rb].tobytes()).hexdigest() != sha_dec:
+                failure = f"slot {k}: HIP output differs from the oracle"
+                break
+        parity = f"all {B} slots: slice payload and decoded picture byte for byte against the oracle"
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_digests.json")))["cfg2"]
+    if failure is None and B >= 2 and hashlib.sha256(out_host[:2 * rb].tobytes()).hexdigest() != gold["decoded"]["sha256"]:
+        failure = "decoded pictures 0-1 differ from the reference digest"
+    if failure is None and parity is None:   # no CPU run: slots 0-1 against the reference digest, every slot must decode to
+        # what it decodes to when the batch is coded again in another order (slot independence)
+        perm = torch.arange(B - 1, -1, -1, device=dev)
+        d_raw2 = d_raw.view(B, rb)[perm].contiguous().view(-1)
+        d_out2 = torch.zeros_like(d_out)
+        d_pay2 = torch.zeros_like(d_pay)
+        d_len2 = torch.zeros_like(d_len)
+        torch.cuda.synchronize()   # torch built these on ITS stream; the library reads them on its own
+        hip.encode_batch_dev(d_raw2.data_ptr(), B, fmt, cp, d_pay2.data_ptr(), stride, d_len2.data_ptr())
+        hip.decode_batch_dev(d_pay2.data_ptr(), stride, d_len2.data_ptr(), B, fmt, cp, d_out2.data_ptr())
+        hip.sync()
+        if not torch.equal(d_out2.view(B, rb)[perm].contiguous().view(-1), d_out):
+            failure = "a picture decodes differently in another slot"
+        elif not torch.equal(d_len2[perm], d_len):
+            failure = "a picture codes to another length in another slot"
+        parity = "slots 0-1 against the reference digest; every slot against the same picture coded in another slot"
+        del d_raw2, d_out2, d_pay2, d_len2
+    del out_host, pay_host
+    ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=red_dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if failure:
+        print(f"rank {rank}: {failure}: refusing to report a number", file=sys.stderr)
+    if int(ok.item()) == 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(failure or "another rank's output failed its check: refusing to report a number")
+    if world > 1:
+        parity = f"every rank: {parity}; verdicts AND-reduced over {world} ranks (slots 2.. differ from rank to rank)"
 
     # ---- end to end: pictures start and end in pinned host memory; two streams, copies overlapped with kernels
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e:
         e2e = run_e2e(torch, vc2hip_py, dev, frames, rb, fmt, cp, stride, lens, B, d_out)
+
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        other = run_other_configs(torch, vc2hip_py, hip, dev, frames, rb)
 
     pixels = W * H
     total_px = pixels * B * world * args.steps
@@ -300,7 +346,7 @@ def main():
         path_achieved = 2 * alg_dir * B / (sum(kern_step_ms.values()) / 1e3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
         # separate runs, gfx950 correction applied).  Only valid for the kernel sources it was measured on.
-        traffic, traffic_note = None, "no committed PMC profile"
+        traffic, traffic_note, path_traffic = None, "no committed PMC profile", None
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
                 pmc = json.load(open(f))
@@ -311,6 +357,8 @@ def main():
                 continue
             if pmc.get("pictures_per_launch") == per_launch and dom in pmc.get("kernels", {}):
                 traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                # the whole path: every kernel of a step (launches per step x bytes per launch), as counted and with the guide's 2 x FETCH_SIZE
+                path_traffic = pmc.get("path_bytes_per_step")
                 traffic_note = f"committed profile {os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench), not collected by this run"
                 break
         out = {
@@ -325,7 +373,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int32",
-            "data": f"synthetic (SURVEY Appendix-B generator, seed 1234; {B} distinct pictures per GPU)",
+            "dtype_note": "the reference's arithmetic: every transform, quantiser and code value is computed as int32 in registers; "
+                          "the coefficient store between kernels holds int16 with an escape to int32 (exact for every input)",
+            "data": f"synthetic (SURVEY Appendix-B generator, seed 1234; {B} distinct pictures per GPU" +
+                    ("" if world == 1 else "; slots 2.. of rank r from seed 1234 + r") + ")",
             "config": {"workload": "BASELINE cfg2: UHD-1 3840x2160 4:2:2 10-bit HQ_ConstQ DD97 depth 4, -u 1 -a 2 -q 16 -S 2",
                        "pictures_per_gpu_per_step": B, "coded_bytes_per_picture": round(coded, 1), "streams": args.streams,
                        "parallelism": f"frame-parallel x{world}, no collective"},
@@ -337,12 +388,16 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_dir * per_launch),
                          "path_achieved_GBs": round(path_achieved, 1),
                          "path_frac": round(path_achieved / HBM_PEAK_GBS, 4),
+                         "path_algorithmic_bytes_per_step": int(2 * alg_dir * B),
+                         "path_traffic_bytes": path_traffic,
+                         "path_traffic_ratio": ({k: round(v / (2 * alg_dir * B), 2) for k, v in path_traffic.items()} if path_traffic else None),
                          "kernel_events": f"the {dom_launches} launches of `{dom}` inside the timed region",
                          "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_step_ms.items())},
                          "kernel_ms_per_step_source": f"event pairs on every launch of {w_steps} untimed steps between the warm-up and the timed region"},
             "value_without_kernel_events": round(total_px / dt_noev / 1e6, 1),
             "parity_checked": parity,
             "e2e": e2e,
+            "other_configs": other,
         }
         if cpu is not None:
             one, res, wall, cores, procs = cpu
@@ -364,6 +419,143 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+OTHER_CFGS = {
+    # name: geometry and coding parameters of BASELINE.json configs[0], [2], [3], [4]; B pictures per step
+    "cfg1": dict(w=1920, h=1080, cf="422", bits=10, wb=2, k="LeGall", d=2, u=2, a=4, B=16, kw=dict(q=12, scalar=1),
+                 workload="BASELINE cfg1: 1920x1080 4:2:2 10-bit HQ_ConstQ LeGall depth 2, -u 2 -a 4 -q 12"),
+    "cfg3": dict(w=3840, h=2160, cf="422", bits=10, wb=2, k="DD97", d=4, u=1, a=2, B=16, kw=dict(mode="HQ_CBR", s=8294400, scalar=2),
+                 workload="BASELINE cfg3: UHD-1 3840x2160 4:2:2 10-bit HQ_CBR DD97 depth 4, -u 1 -a 2 -s 8294400 -S 2"),
+    "cfg4": dict(w=7680, h=4320, cf="444", bits=12, wb=2, k="Fidelity", d=5, u=1, a=1, B=4, kw=dict(q=40, scalar=8),
+                 workload="BASELINE cfg4: UHD-2 7680x4320 4:4:4 12-bit HQ_ConstQ Fidelity depth 5, -u 1 -a 1 -q 40 -S 8 (4 pictures on ONE GPU)"),
+    "cfg5": dict(w=1920, h=1080, cf="422", bits=8, wb=1, k="LeGall", d=3, u=1, a=2, B=16, kw=dict(mode="LD", s=1036800),
+                 workload="BASELINE cfg5: 1920x1080 4:2:2 8-bit LD LeGall depth 3, -u 1 -a 2 -s 1036800, DECODE only"),
+}
+
+
+def kernel_own_bytes(name, S, w, rawb, C, depth):
+    """compulsory bytes of one kernel per picture: S samples, w bytes per store element, rawb bytes per raw
+    sample, C coded bytes"""
+    deep = sum(4.0 ** -l for l in range(1, depth))   # levels 1 .. depth-1 relative to level 0
+    return {"dwt_level_first": (rawb + w) * S, "idwt_level_final": (rawb + w) * S, "dwt_level": 2 * w * S * deep, "idwt_level": 2 * w * S * deep,
+            "hq_pack": w * S + C, "hq_unpack": C + w * S, "cbr_search": w * S, "ld_search": 2 * 4 * S, "ld_pack": 4 * S + C,
+            "ld_unpack": C + 4 * S}.get(name)
+
+
+def run_other_configs(torch, vc2hip_py, hip, dev, frames_cfg2, rb_cfg2):
+    """cfg 1, 3, 4 and 5 (decode) through the same device-resident batch path, 5 steps each.  Picture 0 of every batch is the
+    SURVEY generator's frame 0 (what the reference digests were recorded on) and is checked against them (cfg 5: against
+    the oracle); the other pictures of a batch are that frame rolled by 64 k rows (distinct content without minutes of
+    numpy), cfg 3 takes the cfg-2 batch as it is.  A mismatch refuses the whole line."""
+    import ctypes as C
+    import numpy as np
+    from synth import synth
+    from vc2lib import load_oracle, make_params
+    oracle = load_oracle()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_digests.json")))
+    res = {}
+    for name, c in OTHER_CFGS.items():
+        w, h, cf, bits, wb, B = c["w"], c["h"], c["cf"], c["bits"], c["wb"], c["B"]
+        fmt = vc2hip_py.picture_format(w, h, cf, bits, wb)
+        cp = vc2hip_py.coding_params(hip.lib, fmt, c["k"], c["d"], c["u"], c["a"], **c["kw"])
+        rb = hip.raw_picture_bytes(fmt)
+        stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+        if name == "cfg3":
+            B = min(B, len(frames_cfg2) // rb_cfg2)
+            d_raw = torch.frombuffer(bytearray(frames_cfg2[:B * rb]), dtype=torch.uint8).to(dev)
+        else:
+            one = torch.frombuffer(bytearray(synth(w, h, cf, bits, 1234, frames=1, word_bytes=wb)), dtype=torch.uint8).to(dev)
+            cw = w if cf == "444" else w // 2
+            planes = [(0, w * h * wb, w * wb), (w * h * wb, (rb - w * h * wb) // 2, cw * wb), (w * h * wb + (rb - w * h * wb) // 2, (rb - w * h * wb) // 2, cw * wb)]
+            pics = [one]
+            for k in range(1, B):   # picture k: every plane rolled down by 64 k rows
+                pics.append(torch.cat([torch.roll(one[o:o + n].view(-1, rowb), 64 * k, 0).reshape(-1) for (o, n, rowb) in planes]))
+            d_raw = torch.cat(pics)
+            del pics
+        d_pay = torch.zeros(B * stride, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(B, dtype=torch.int64, device=dev)
+        d_out = torch.zeros(B * rb, dtype=torch.uint8, device=dev)
+        p = make_params(w, h, cf, bits, c["k"], c["d"], c["u"], c["a"], word_bytes=wb, **c["kw"])
+        decode_only = name == "cfg5"
+        if decode_only:   # the oracle's LD stream of frame 0 in every slot; the GPU's LD encoder must produce the same bytes
+            raw0 = bytes(d_raw[:rb].cpu().numpy())
+            stream = oracle.encode_stream(p, raw0, 1)
+            want_dec, _ = oracle.decode_stream(p, stream, 1)
+            nbytes = c["kw"]["s"]
+            payload = np.frombuffer(stream[-13 - nbytes:-13], np.uint8)
+            hp = torch.zeros(B, stride, dtype=torch.uint8)
+            hp[:, :nbytes] = torch.from_numpy(payload.copy())
+            d_pay.copy_(hp.view(-1))
+            d_len.fill_(nbytes)
+        torch.cuda.synchronize()
+
+        def step():
+            if not decode_only:
+                hip.encode_batch_dev(d_raw.data_ptr(), B, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+            hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B, fmt, cp, d_out.data_ptr())
+        for _ in range(2):
+            step()
+        hip.sync()
+        torch.cuda.synchronize()
+        K = 5
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        hip.sync()
+        dt = (time.perf_counter() - t0) / K
+        hip.profile_reset()
+        hip.profile_enable(True)   # the per-kernel table: two more steps, outside the timed ones
+        for _ in range(2):
+            step()
+        hip.sync()
+        hip.profile_enable(False)
+        prof = {k: v[1] / 2 for k, v in hip.profile().items() if v[0] > 0 and k != "fill"}
+        hip.profile_reset()
+        # ---- check picture 0 (and that the other slots are not copies of it)
+        lens = d_len.cpu().numpy().astype(np.int64)
+        dec0 = d_out[:rb].cpu().numpy().tobytes()
+        if decode_only:
+            ok = dec0 == want_dec
+            got, _ = hip.encode_picture_hq(raw0, fmt, cp)
+            ok = ok and got == payload.tobytes()
+            checked = "picture 0 decoded == the oracle's decode of the oracle's LD stream; the GPU's LD encoder reproduces that stream"
+        else:
+            g = gold[name]
+            pay0 = d_pay[:int(lens[0])].cpu().numpy().tobytes()
+            hdr = np.zeros(64, np.uint8); n = C.c_size_t(); major = C.c_int()
+            oracle.lib.vc2o_write_sequence_header_payload(C.byref(p), hdr.ctypes.data_as(C.c_void_p), 64, C.byref(n), C.byref(major))
+            seq = bytes(hdr[:n.value])
+            ph = np.zeros(64, np.uint8); m = C.c_size_t()
+            oracle.lib.vc2o_write_hq_picture_header(0, p.kernel, c["d"], cp.x_slices, cp.y_slices, cp.prefix, cp.scalar, major.value,
+                                                    ph.ctypes.data_as(C.c_void_p), 64, C.byref(m))
+
+            def pi(code, nxt, prev):
+                return b"BBCD" + bytes([code]) + nxt.to_bytes(4, "big") + prev.to_bytes(4, "big")
+            n1, n2 = 13 + len(seq), 13 + m.value + len(pay0)
+            stream = pi(0x00, n1, 0) + seq + pi(0xE8, n2, n1) + bytes(ph[:m.value]) + pay0 + pi(0x10, 0, n2)
+            ok = hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"] and hashlib.sha256(dec0).hexdigest() == g["decoded"]["sha256"]
+            ok = ok and (B < 2 or not torch.equal(d_out[:rb], d_out[rb:2 * rb]))
+            checked = "picture 0: stream (oracle header writers around the GPU payload) and decoded picture against the reference digests"
+        if not ok:
+            raise SystemExit(f"{name}: HIP output differs from the reference digest / the oracle: refusing to report a number")
+        S = rb // wb
+        coded = float(lens.mean())
+        domk = max(prof, key=prof.get)
+        own = kernel_own_bytes(domk, S, 4 if decode_only else 2, wb, coded, c["d"])
+        alg = (4 if decode_only else 2) * S + coded   # per picture and direction
+        res[name] = {"workload": c["workload"], "pictures_per_step": B, "steps": K,
+                     "value": round(w * h * B / dt / 1e6, 1), "unit": "Mpixels/s " + ("decode" if decode_only else "encode+decode"),
+                     "ms_per_step": round(dt * 1e3, 4),
+                     "path_frac": round((1 if decode_only else 2) * alg * B / dt / 1e9 / HBM_PEAK_GBS, 4),
+                     "dominant_kernel": domk, "dominant_kernel_ms": round(prof[domk], 4),
+                     "dominant_kernel_own_GBs": (round(own * B / (prof[domk] / 1e3) / 1e9, 1) if own else None),
+                     "dominant_kernel_frac": (round(own * B / (prof[domk] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if own else None),
+                     "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(prof.items())},
+                     "coded_bytes_per_picture": round(coded, 1), "checked": checked}
+        del d_raw, d_pay, d_len, d_out
+        torch.cuda.empty_cache()
+    return res
 
 
 def run_e2e(torch, vc2hip_py, dev, frames, rb, fmt, cp, stride, lens, B, d_out):

@@ -666,3 +666,96 @@ def test_random_geometries_against_oracle():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "80 cases, 0 bad" in out.stdout, out.stdout[-2000:]
+
+
+# ---- round-3 additions: the top of the quantiser table, and the LD search's hand-over failure path
+def test_quantiser_indices_116_to_119_fine_grained(hip, oracle):
+    """Indices 116..119: the reference's quant_factor table overflows `int` there (Quantisation.cpp:42-58 through
+    static_cast<int>): negative factors.  quantise / dequantise must wrap exactly like the oracle."""
+    rng = np.random.default_rng(316)
+    depth, ys, xs = 2, 2, 2
+    coef = rng.integers(-(1 << 28), 1 << 28, size=(ys * 8, xs * 16)).astype(np.int32)
+    coef[::2, ::3] = rng.integers(-2000, 2000, size=coef[::2, ::3].shape)
+    qidx = np.array([[116, 117], [118, 119]], np.int32)
+    qm = np.zeros(7, np.int32)
+    want = oracle.quantise_np(coef, depth, qidx, qm)
+    assert np.array_equal(hip.quantise_np(coef, depth, qidx, qm), want)
+    small = rng.integers(-3, 4, size=coef.shape).astype(np.int32)
+    assert np.array_equal(hip.dequantise_np(small, depth, qidx, qm), oracle.dequantise_np(small, depth, qidx, qm))
+
+
+@pytest.mark.parametrize("kernel", ["Haar1", "DD97"])
+@pytest.mark.parametrize("q", [116, 117, 118, 119])
+def test_constq_indices_116_to_119_pictures(hip, oracle, kernel, q):
+    """HQ_ConstQ -q 116..119 through the picture path (the float-reciprocal quantiser of k_hq_pack, the fused dequantiser
+    of the inverse transform): payload and decoded picture against the oracle.  12-bit noise: coefficients large enough
+    that some bands (matrix entry > 0: adjusted index below 116) still quantise to non-zero values."""
+    w, h, depth = 256, 128, 3
+    raw = noise_frame(w, h, "422", 12, seed=1160 + q)
+    p = make_params(w, h, "422", 12, kernel, depth, 1, 2, q=q, scalar=2)
+    stream, dec = _oracle_payload(oracle, p, raw)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 12, kernel, depth, 1, 2, q=q, scalar=2)
+    payload, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert payload == stream[-13 - len(payload):-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+    # and through the device-resident batch path (16-bit store, streaming / tile kernels)
+    import torch
+    dev = torch.device("cuda:0")
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    d_raw = torch.frombuffer(bytearray(raw + raw), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(2 * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(2 * rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    hip.encode_batch_dev(d_raw.data_ptr(), 2, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), 2, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    assert d_len.cpu().tolist() == [len(payload)] * 2
+    assert d_pay.cpu().numpy()[stride:stride + len(payload)].tobytes() == payload
+    assert d_out.cpu().numpy()[rb:].tobytes() == dec
+
+
+def test_ld_handoff_failure_path(tmp_path):
+    """k_ld_search_rows hands reconstructed LL samples from one workgroup to another inside one launch (bounded wait, poison
+    flag, VC2_DEVERR_HANDOFF, per-diagonal fallback from then on: DESIGN.md 'LD index search').  The failure path cannot
+    be reached by a healthy GPU, so the -DVC2HIP_ABLATE library (never loaded by the product path) lets one row of
+    slices of picture 0 never come: the batch must fail with the documented message, write nothing silently wrong, and
+    the SAME batch submitted again must come out bit-exact through the fallback.  Own process: the fallback is a
+    process-wide state."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "..", "vc2-reference_amd", "libvc2hip_ablate.so")
+    if not os.path.exists(lib):
+        pytest.fail("libvc2hip_ablate.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    script = tmp_path / "handoff.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {os.path.join(here, "..", "vc2-reference_amd")!r}); sys.path.insert(0, {here!r})
+import vc2hip_py
+from synth import synth
+from vc2lib import load_oracle, make_params
+w, h, depth, nbytes = 256, 120, 3, 12000
+raw = synth(w, h, "422", 8, 77, word_bytes=1)
+hip = vc2hip_py.Vc2Hip(0)
+fmt = vc2hip_py.picture_format(w, h, "422", 8, 1)
+cp = vc2hip_py.coding_params(hip.lib, fmt, "LeGall", depth, 1, 2, mode="LD", s=nbytes)
+try:
+    hip.encode_picture_hq(raw, fmt, cp)
+    print("NOERROR")
+except vc2hip_py.Vc2HipError as e:
+    print("ERROR:", e)
+os.environ.pop("VC2HIP_DEBUG_LD_DEAD_ROW")          # (read at every launch in the ablation build)
+payload, _ = hip.encode_picture_hq(raw, fmt, cp)   # the same batch again: the per-diagonal launches
+oracle = load_oracle()
+p = make_params(w, h, "422", 8, "LeGall", depth, 1, 2, mode="LD", s=nbytes, word_bytes=1)
+stream = oracle.encode_stream(p, raw, 1)
+print("SECOND", "OK" if payload == stream[-13 - len(payload):-13] else "DIFFERS")
+''')
+    env = dict(os.environ, VC2HIP_LIB=os.path.abspath(lib), VC2HIP_DEBUG_LD_DEAD_ROW="3")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ERROR: LD index search: a hand-over between workgroups timed out" in out.stdout, out.stdout + out.stderr
+    assert "submit the batch again" in out.stdout
+    assert "SECOND OK" in out.stdout, out.stdout

@@ -4,7 +4,7 @@
 # another size and would mix into the per-kernel averages).
 #   tools/prof_kernels.sh <tag> [bench args]
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}" || exit 1
 out=gpurun_out/prof_$tag
 mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e "$@" > $out/bench_under_rocprof.json 2> $out/stats.err

@@ -1689,8 +1689,8 @@ static int flight_begin(vc2hip_ctx *c, bool encode, vc2hip_ctx::Flight **out, in
   if (!f.lane) {
     const int rc = vc2hip_create(c->device, &f.lane);
     if (rc) return set_err(c, rc, "cannot create a stream for a picture in flight");
-    HIPCHK(c, hipHostMalloc((void **)&f.h_len, 64));
   }
+  if (!f.h_len) HIPCHK(c, hipHostMalloc((void **)&f.h_len, 64)); // (its own test: a failure here must not leave a lane without it)
   f.open = true;
   f.encode = encode;
   *ticket = c->flight_next;
@@ -1715,9 +1715,10 @@ extern "C" int vc2hip_encode_picture_begin(vc2hip_ctx *c, const void *raw, const
       (rc = need(l, B_LENS, 64, (void **)&d_len))) return fail(rc);
   if (hipMemcpyAsync(d_raw, raw, rb, hipMemcpyHostToDevice, l->stream) != hipSuccess) return fail(VC2HIP_EHIP);
   if ((rc = vc2hip_encode_batch_dev(l, d_raw, 1, f, cp, d_pay, pcap, (uint64_t *)d_len))) return fail(rc);
-  (void)hipMemcpyAsync(fl->h_len, d_len, 8, hipMemcpyDeviceToHost, l->stream);
-  if (qidx_out)
-    (void)hipMemcpyAsync(qidx_out, l->buf[B_QIDX].p, (size_t)cp->y_slices * cp->x_slices * 4, hipMemcpyDeviceToHost, l->stream);
+  if (hipMemcpyAsync(fl->h_len, d_len, 8, hipMemcpyDeviceToHost, l->stream) != hipSuccess) return fail(VC2HIP_EHIP);
+  if (qidx_out && // (from vc2hip_host_alloc like every buffer of a _begin call: a pageable destination makes the call block)
+      hipMemcpyAsync(qidx_out, l->buf[B_QIDX].p, (size_t)cp->y_slices * cp->x_slices * 4, hipMemcpyDeviceToHost, l->stream) != hipSuccess)
+    return fail(VC2HIP_EHIP);
   return VC2HIP_OK;
 }
 

@@ -319,6 +319,7 @@ struct LdEncParams {
   uint8_t *payload;
   long long payload_stride;
   unsigned *err;
+  int debug_dead_row;         // -DVC2HIP_ABLATE builds only: the workgroup of this slice row of picture 0 exits at once (hand-over failure test)
 };
 void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s);
 void vc2_launch_ld_pack(Launcher &L, const LdEncParams &p, int n_pictures, hipStream_t s);

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 #include "vc2hip_internal.h"
 #include "vc2hip_store.h"
@@ -268,7 +270,9 @@ __device__ __forceinline__ void build_vlc_lut(unsigned *lut) {
   for (int m = threadIdx.x * 4; m < VLC_LUT_N; m += blockDim.x * 4) *(uint4 *)(lut + m) = *(const uint4 *)(g_vlc_lut + m);
 }
 void vc2_upload_vlc_lut(hipStream_t s) {
-  static unsigned host[VLC_LUT_N];
+  static unsigned host[VLC_LUT_N]; // built once, see vc2_upload_unpack_lut
+  static std::once_flag once;
+  std::call_once(once, [] {
   for (unsigned m = 0; m < (unsigned)VLC_LUT_N; ++m) {
     unsigned code = 1, nb = 1;
     if (m) {
@@ -282,6 +286,7 @@ void vc2_upload_vlc_lut(hipStream_t s) {
     }
     host[m] = (code << 6) | nb;
   }
+  });
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_vlc_lut), host, sizeof host, 0, hipMemcpyHostToDevice, s);
 }
 __device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, unsigned *err, const unsigned *lut);
@@ -1197,7 +1202,7 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_
   for (int b = 1; b < p.n_bands; ++b) p.qm_min = std::min(p.qm_min, p.qmatrix[b]);
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
   if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
-  const char *e_gen = getenv("VC2HIP_CBR_GENERAL"); const bool no_reg = e_gen && e_gen[0] == '1'; // A/B and test switch: the general kernel only
+  static const bool no_reg = [] { const char *e = getenv("VC2HIP_CBR_GENERAL"); return e && e[0] == '1'; }(); // A/B and test switch: the general kernel only
   const bool reg = !no_reg && p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32 &&
                    p.comp_n[0] % 8 == 0 && p.comp_n[1] % 8 == 0 && (p.store_stride % 8) == 0 && (p.slice_coefs % 8) == 0 &&
                    p.comp_off[1] % 8 == 0 && p.comp_off[2] % 8 == 0;
@@ -1505,7 +1510,10 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 constexpr int UNP_LUT_BITS = 10, UNP_LUT_N = 1 << UNP_LUT_BITS;
 __device__ unsigned g_unp_lut[UNP_LUT_N];
 void vc2_upload_unpack_lut(hipStream_t s) {
+  // built once (contexts are created from several worker threads at a time: the copy below may still be reading it)
   static unsigned host[UNP_LUT_N];
+  static std::once_flag once;
+  std::call_once(once, [] {
   for (int idx = 0; idx < UNP_LUT_N; ++idx) {
     auto bit = [&](int i) { return (idx >> (UNP_LUT_BITS - 1 - i)) & 1; };
     int pos = 0, nc = 0, nnz = 0, at[2] = {0, 0}, val[2] = {0, 0};
@@ -1530,6 +1538,7 @@ void vc2_upload_unpack_lut(hipStream_t s) {
                         : (unsigned)pos | (unsigned)nc << 4 | (unsigned)at[0] << 8 | (unsigned)at[1] << 12 |
                               (unsigned)(val[0] & 0xFF) << 16 | (unsigned)(val[1] & 0xFF) << 24;
   }
+  });
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_unp_lut), host, sizeof host, 0, hipMemcpyHostToDevice, s);
 }
 
@@ -2664,6 +2673,9 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
   int *llpack = llq + LD_SLOTS * 16;       // per candidate and component: code lengths of the residuals, a byte each
   int *acres = llpack + LD_SLOTS * 8;      // per candidate: luma count, chroma count (behind the LL blocks), bad index
   const int sv = ROWS ? (int)blockIdx.x / p8 : max(0, d - (p.xs - 1)) + (int)blockIdx.x;
+#ifdef VC2HIP_ABLATE // tests/test_gpu_parity.py::test_ld_handoff_failure_path: one row of slices of picture 0 never comes
+  if (ROWS && p.debug_dead_row >= 0 && sv == p.debug_dead_row && pic == 0) return;
+#endif
   const int sh_first = ROWS ? 0 : d - sv, sh_end = ROWS ? p.xs : sh_first + 1;
   constexpr bool dual = DUAL; // n_y, n_uv <= 32 CPL: luma on lanes 0-31, chroma on lanes 32-63, one pass per candidate
   const bool ch = dual && lane >= 32;
@@ -3074,7 +3086,7 @@ __global__ __launch_bounds__(256) void k_ld_pack(const LdEncParams p) {
 
 // set once a hand-over of the single-launch search timed out (vc2hip_sync saw VC2_DEVERR_HANDOFF): from then on the
 // search runs as one launch per anti-diagonal of slices, which needs no hand-over inside a launch
-static bool g_ld_rows_disabled = false;
+static std::atomic<bool> g_ld_rows_disabled{false}; // (set by any context's error path, read by every launcher thread)
 bool vc2_ld_rows_disabled() { return g_ld_rows_disabled; }
 void vc2_ld_disable_rows() { g_ld_rows_disabled = true; }
 
@@ -3091,6 +3103,11 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     const bool dual = p.comp_n[0] <= reach && 2 * p.comp_n[1] <= reach; // half a wavefront covers a stream
     VC2_LAUNCH(L, k_ld_tables, dim3(1), dim3(256), 0, s, p);
     static const int rows = [] { const char *e = getenv("VC2HIP_LD_ROWS"); return e ? atoi(e) : 1; }();
+#ifdef VC2HIP_ABLATE
+    LdEncParams pd = p;
+    { const char *e = getenv("VC2HIP_DEBUG_LD_DEAD_ROW"); pd.debug_dead_row = e ? atoi(e) : -1; }
+    const LdEncParams &p = pd; // (shadows the argument for the launches below)
+#endif
     if (rows && p.search && !vc2_ld_rows_disabled()) {
       // 3 wavefronts (LL chains + 2 x subbands) measured fastest: 3.2 ms per 16 HD pictures, 4 wavefronts 3.6, one launch per anti-diagonal 3.7-3.9
       static const int nwr = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : v > 4 ? 4 : v; }();

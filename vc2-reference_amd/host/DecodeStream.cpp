@@ -147,7 +147,7 @@ int main(int argc, char *argv[]) {
         vc2hip_coding_params cp = {(int)pre.wavelet_kernel, pre.depth, pre.slices_y, pre.slices_x, ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0,
                                    compressedBytes, pre.slice_prefix, pre.slice_size_scalar};
         if (!workers) workers.reset(new GpuWorkers(devices, std::max(maxUnit, dlen), vc2hip_raw_picture_bytes(&pf)));
-        std::memcpy(workers->inputBuffer(seq), data, dlen);
+        std::memcpy(workers->inputBuffer(seq, dlen), data, dlen); // (grows the slot's buffer when this picture is larger than the bound: fragmented VBR streams)
         workers->submitDecode(seq++, dlen, pf, cp, ld);
         PictureResult r;
         while (workers->poll(r)) writeDecoded(r);

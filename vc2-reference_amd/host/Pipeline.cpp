@@ -5,8 +5,8 @@
 
 #include "Hip.h"
 
-GpuWorkers::GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, std::size_t out_bytes)
-    : in_bytes_(in_bytes), out_bytes_(out_bytes) {
+GpuWorkers::GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, std::size_t out_bytes, std::size_t qidx_ints)
+    : in_bytes_(in_bytes), out_bytes_(out_bytes), qidx_ints_(qidx_ints) {
   for (int d : devices) (void)hipContext(d); // fails loudly here when a device is missing: there is no CPU fallback
   for (int d : devices) {
     Worker *w = new Worker;
@@ -14,8 +14,10 @@ GpuWorkers::GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, st
     w->busy.assign(SLOTS, false);
     for (int i = 0; i < SLOTS; ++i) {
       w->in.push_back((unsigned char *)vc2hip_host_alloc(in_bytes + 64));
+      w->in_cap.push_back(in_bytes + 64);
       w->out.push_back((unsigned char *)vc2hip_host_alloc(out_bytes + 64));
-      if (!w->in.back() || !w->out.back()) throw std::runtime_error("vc2hip: cannot allocate pinned staging buffers");
+      w->qidx.push_back(qidx_ints ? (int *)vc2hip_host_alloc(qidx_ints * sizeof(int)) : nullptr);
+      if (!w->in.back() || !w->out.back() || (qidx_ints && !w->qidx.back())) throw std::runtime_error("vc2hip: cannot allocate pinned staging buffers");
     }
     workers_.push_back(w);
   }
@@ -28,11 +30,12 @@ GpuWorkers::~GpuWorkers() {
     if (w->th.joinable()) w->th.join();
     for (unsigned char *p : w->in) vc2hip_host_free(p);
     for (unsigned char *p : w->out) vc2hip_host_free(p);
+    for (int *p : w->qidx) vc2hip_host_free(p);
     delete w;
   }
 }
 
-unsigned char *GpuWorkers::inputBuffer(unsigned long long seq) {
+unsigned char *GpuWorkers::inputBuffer(unsigned long long seq, std::size_t bytes) {
   Worker &w = *workers_[(std::size_t)(seq % workers_.size())];
   std::unique_lock<std::mutex> lock(w.m);
   w.cv.wait(lock, [&]() { return !w.busy[(std::size_t)w.next_slot]; });
@@ -40,6 +43,13 @@ unsigned char *GpuWorkers::inputBuffer(unsigned long long seq) {
   w.busy[(std::size_t)slot] = true;
   w.next_slot = (slot + 1) % SLOTS;
   lock.unlock();
+  if (bytes + 64 > w.in_cap[(std::size_t)slot]) { // the slot is free (nothing in flight reads it): a larger buffer takes its place
+    unsigned char *bigger = (unsigned char *)vc2hip_host_alloc(bytes + bytes / 4 + 64);
+    if (!bigger) throw std::runtime_error("vc2hip: cannot allocate a pinned staging buffer for a picture of " + std::to_string(bytes) + " bytes");
+    vc2hip_host_free(w.in[(std::size_t)slot]);
+    w.in[(std::size_t)slot] = bigger;
+    w.in_cap[(std::size_t)slot] = bytes + bytes / 4 + 64;
+  }
   std::lock_guard<std::mutex> rl(rm_);
   slot_of_[seq] = slot;
   return w.in[(std::size_t)slot];
@@ -114,7 +124,10 @@ void GpuWorkers::run(Worker &w) {
         std::size_t len = 0;
         const int e = vc2hip_encode_picture_end(ctx, o.ticket, &len);
         if (e) o.res.error = vc2hip_last_error(ctx);
-        else o.res.bytes.assign(w.out[(std::size_t)o.job.slot], w.out[(std::size_t)o.job.slot] + len);
+        else {
+          o.res.bytes.assign(w.out[(std::size_t)o.job.slot], w.out[(std::size_t)o.job.slot] + len);
+          if (qidx_ints_) o.res.qidx.assign(w.qidx[(std::size_t)o.job.slot], w.qidx[(std::size_t)o.job.slot] + (std::size_t)o.job.cp.y_slices * o.job.cp.x_slices);
+        }
       }
     }
     { std::lock_guard<std::mutex> lock(w.m); w.busy[(std::size_t)o.job.slot] = false; }
@@ -141,9 +154,11 @@ void GpuWorkers::run(Worker &w) {
       const int e = vc2hip_decode_picture_begin(ctx, w.in[(std::size_t)j.slot], j.len, &j.pf, &j.cp, w.out[(std::size_t)j.slot], &o.ticket);
       if (e) o.res.error = vc2hip_last_error(ctx);
     } else {
-      o.res.qidx.assign((std::size_t)j.cp.y_slices * j.cp.x_slices, 0);
+      // (the indices, when wanted, land in the slot's pinned buffer: a pageable destination would make _begin block until the
+      // picture's kernels have run -- no second picture in flight)
+      int *qdst = qidx_ints_ >= (std::size_t)j.cp.y_slices * j.cp.x_slices ? w.qidx[(std::size_t)j.slot] : nullptr;
       const int e = vc2hip_encode_picture_begin(ctx, w.in[(std::size_t)j.slot], &j.pf, &j.cp, w.out[(std::size_t)j.slot], out_bytes_,
-                                                o.res.qidx.data(), &o.ticket);
+                                                qdst, &o.ticket);
       if (e) o.res.error = vc2hip_last_error(ctx);
     }
     open.push_back(std::move(o));

@@ -30,10 +30,13 @@ class GpuWorkers {
  public:
   // devices[g]: HIP device of worker g (a device may appear more than once: more pictures in flight on it).
   // in_bytes / out_bytes: upper bounds of one picture's input and output
-  GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, std::size_t out_bytes);
+  // qidx_ints: quantiser indices per picture that encode results carry (0: none wanted -- the stream writer does not use them)
+  GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, std::size_t out_bytes, std::size_t qidx_ints = 0);
   ~GpuWorkers();
-  // a pinned buffer to put picture `seq`'s input in (blocks until the worker of seq has one free); then submit it
-  unsigned char *inputBuffer(unsigned long long seq);
+  // a pinned buffer of at least `bytes` (0: the in_bytes of the constructor) to put picture `seq`'s input in -- blocks
+  // until the worker of seq has one free, and replaces it by a larger one when a picture needs more than the bound
+  // given at construction (fragmented variable-size streams: the payload is the sum of its fragments) -- then submit it
+  unsigned char *inputBuffer(unsigned long long seq, std::size_t bytes = 0);
   void submitEncode(unsigned long long seq, const vc2hip_picture_format &pf, const vc2hip_coding_params &cp, bool ld);
   void submitDecode(unsigned long long seq, std::size_t len, const vc2hip_picture_format &pf, const vc2hip_coding_params &cp, bool ld);
   bool poll(PictureResult &r); // the next picture in order, if it is done
@@ -56,6 +59,8 @@ class GpuWorkers {
     std::condition_variable cv;
     std::deque<Job> queue;
     std::vector<unsigned char *> in, out; // pinned, SLOTS each
+    std::vector<std::size_t> in_cap;      // bytes of in[i]
+    std::vector<int *> qidx;              // pinned: the quantiser indices of an encoded picture come back here
     std::vector<bool> busy;               // input slot handed out and not yet finished
     int next_slot = 0;
     bool closing = false;
@@ -65,7 +70,7 @@ class GpuWorkers {
   void run(Worker &w);
   void publish(PictureResult &&r);
   std::vector<Worker *> workers_;
-  std::size_t in_bytes_, out_bytes_;
+  std::size_t in_bytes_, out_bytes_, qidx_ints_;
   std::mutex rm_;
   std::condition_variable rcv_;
   std::map<unsigned long long, PictureResult> done_;

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "Picture.h"
+#include "Pipeline.h"
 #include "Quantisation.h"
 #include "Slices.h"
 #include "WaveletTransform.h"
@@ -84,6 +85,54 @@ int main() {
     long want = 0;
     for (std::size_t i = 0; i < sliceBytes.num_elements(); ++i) want += sliceBytes.data()[i];
     EXPECT((long)outStream.str().size() == want);
+  }
+  { // The tools' worker pool (Pipeline.h) with pictures LARGER than the input bound it was built with -- what a fragmented
+    // variable-size stream does to DecodeStream (the bound comes from the largest data unit, a picture is the sum of its
+    // fragments): the slot's pinned buffer must grow, not overflow.  Eight pictures of growing payload through two workers
+    // on device 0; the encoder side returns the quantiser indices through its pinned per-slot buffer.
+    const vc2hip_picture_format pf = {width, height, (int)CF422, 10, 2};
+    const std::size_t rawBytes = vc2hip_raw_picture_bytes(&pf);
+    std::vector<std::vector<unsigned char> > raws, payloads;
+    std::vector<vc2hip_coding_params> cps;
+    {
+      GpuWorkers enc(std::vector<int>(2, 0), rawBytes, 200000, (std::size_t)ySlices * xSlices);
+      for (int k = 0; k < 8; ++k) {
+        std::vector<unsigned char> raw(rawBytes);
+        unsigned seed = 99u + (unsigned)k;
+        const int amp = 4 << k; // more detail, longer payload
+        for (std::size_t i = 0; i + 1 < raw.size(); i += 2) {
+          seed = seed * 1103515245u + 12345u;
+          const unsigned v = (512u + (seed >> 16) % (unsigned)(amp > 1023 ? 1023 : amp)) & 1023u;
+          raw[i] = (unsigned char)(v >> 2); raw[i + 1] = (unsigned char)((v & 3u) << 6); // 10 bits, MSB justified, big-endian
+        }
+        const vc2hip_coding_params cp = {(int)kernel, waveletDepth, ySlices, xSlices, VC2HIP_HQ_CONSTQ, k < 4 ? 3 : 0, 0, slicePrefix, sliceScalar};
+        std::copy(raw.begin(), raw.end(), enc.inputBuffer((unsigned long long)k, rawBytes));
+        enc.submitEncode((unsigned long long)k, pf, cp, false);
+        raws.push_back(raw); cps.push_back(cp);
+      }
+      enc.close();
+      PictureResult r;
+      while (enc.wait(r)) {
+        EXPECT(r.error.empty());
+        EXPECT(r.qidx.size() == (std::size_t)ySlices * xSlices && r.qidx[0] == cps[(std::size_t)r.seq].q_index);
+        payloads.push_back(r.bytes);
+      }
+    }
+    EXPECT(payloads.size() == 8 && payloads[7].size() > payloads[0].size() + 64);
+    GpuWorkers dec(std::vector<int>(2, 0), payloads.empty() ? 16 : payloads[0].size(), rawBytes); // bound = the FIRST (smallest) picture
+    for (std::size_t k = 0; k < payloads.size(); ++k) {
+      std::copy(payloads[k].begin(), payloads[k].end(), dec.inputBuffer(k, payloads[k].size()));
+      dec.submitDecode(k, payloads[k].size(), pf, cps[k], false);
+    }
+    dec.close();
+    PictureResult r;
+    std::size_t got = 0;
+    while (dec.wait(r)) {
+      EXPECT(r.error.empty() && r.bytes.size() == rawBytes);
+      if (cps[(std::size_t)r.seq].q_index == 0) EXPECT(r.bytes == raws[(std::size_t)r.seq]); // index 0: lossless
+      ++got;
+    }
+    EXPECT(got == payloads.size());
   }
   if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
   std::printf("slicetest ok\n");
