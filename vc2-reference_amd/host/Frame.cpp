@@ -9,6 +9,56 @@ PictureFormat fieldFormat(const PictureFormat &f) {
   return PictureFormat(f.lumaHeight() / 2, f.lumaWidth(), f.chromaFormat());
 }
 
+// ---- Frame: the reference's bodies (Frame.cpp:40-94), expression for expression, on host/Arrays.h
+const Picture Frame::topField() const {
+  // Get parameters of field
+  const int height = format().lumaHeight() / 2;
+  const int width = format().lumaWidth();
+  const ColourFormat chromaFormat = format().chromaFormat();
+  // Construct interlaced field
+  Picture picture(PictureFormat(height, width, chromaFormat));
+  // Set components of interlaced field
+  const int top = 0;
+  const int yBottom = format().lumaHeight();
+  const int uvBottom = format().chromaHeight();
+  picture.y(y()[indices[Range(top, yBottom, 2)][Range()]]);
+  picture.c1(c1()[indices[Range(top, uvBottom, 2)][Range()]]);
+  picture.c2(c2()[indices[Range(top, uvBottom, 2)][Range()]]);
+  return picture;
+}
+
+void Frame::topField(const Picture &f) {
+  const int top = 0;
+  const int yBottom = format().lumaHeight();
+  const int uvBottom = format().chromaHeight();
+  luma[indices[Range(top, yBottom, 2)][Range()]] = f.y();
+  chroma1[indices[Range(top, uvBottom, 2)][Range()]] = f.c1();
+  chroma2[indices[Range(top, uvBottom, 2)][Range()]] = f.c2();
+}
+
+const Picture Frame::bottomField() const {
+  const int height = format().lumaHeight() / 2;
+  const int width = format().lumaWidth();
+  const ColourFormat chromaFormat = format().chromaFormat();
+  Picture picture(PictureFormat(height, width, chromaFormat));
+  const int top = 1;
+  const int yBottom = format().lumaHeight();
+  const int uvBottom = format().chromaHeight();
+  picture.y(y()[indices[Range(top, yBottom, 2)][Range()]]);
+  picture.c1(c1()[indices[Range(top, uvBottom, 2)][Range()]]);
+  picture.c2(c2()[indices[Range(top, uvBottom, 2)][Range()]]);
+  return picture;
+}
+
+void Frame::bottomField(const Picture &f) {
+  const int top = 1;
+  const int yBottom = format().lumaHeight();
+  const int uvBottom = format().chromaHeight();
+  luma[indices[Range(top, yBottom, 2)][Range()]] = f.y();
+  chroma1[indices[Range(top, uvBottom, 2)][Range()]] = f.c1();
+  chroma2[indices[Range(top, uvBottom, 2)][Range()]] = f.c2();
+}
+
 static Array2D rowsOf(const Array2D &a, int first) {
   const Index h = a.shape()[0], w = a.shape()[1];
   Array2D out((h - first + 1) / 2, w);

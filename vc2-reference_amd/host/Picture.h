@@ -38,18 +38,18 @@ class PictureFormat {
 class Picture {
  public:
   Picture() {}
-  explicit Picture(const PictureFormat &f) : fmt(f), luma(f.lumaShape()), c1_(f.chromaShape()), c2_(f.chromaShape()) {}
+  explicit Picture(const PictureFormat &f) : fmt(f), luma(f.lumaShape()), chroma1(f.chromaShape()), chroma2(f.chromaShape()) {}
   const PictureFormat &format() const { return fmt; }
   const Array2D &y() const { return luma; }
-  const Array2D &c1() const { return c1_; }
-  const Array2D &c2() const { return c2_; }
+  const Array2D &c1() const { return chroma1; }
+  const Array2D &c2() const { return chroma2; }
   void y(const Array2D &a) { luma = a; }
-  void c1(const Array2D &a) { c1_ = a; }
-  void c2(const Array2D &a) { c2_ = a; }
+  void c1(const Array2D &a) { chroma1 = a; }
+  void c2(const Array2D &a) { chroma2 = a; }
 
- private:
+ protected: // (Frame writes its fields into them, Frame.cpp:65-74)
   PictureFormat fmt;
-  Array2D luma, c1_, c2_;
+  Array2D luma, chroma1, chroma2;
 };
 
 // ySlices x xSlices pictures (the reference's PictureArray, a 2-D multi_array of Picture)

@@ -5,7 +5,10 @@
 #include <stdexcept>
 #include <string>
 
+#include <algorithm>
+
 #include "Arrays.h"
+#include "Frame.h"
 #include "Picture.h"
 #include "Slices.h"
 #include "WaveletTransform.h"
@@ -15,6 +18,20 @@
 
 static int failures = 0;
 #define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+// quantIndicesConstQ exactly as the reference writes it (/root/reference/src/EncodeStream/EncodeStream.cpp:128-138)
+const Array2D quantIndicesConstQ(const Picture& coefficients,
+                                 const int ySlices, const int xSlices,
+                                 const Array1D& qMatrix,
+                                 const int qIndex) {
+  (void)coefficients; (void)qMatrix;
+  // Create an empty array of indices to fill and return
+  Array2D indices(extents[ySlices][xSlices]);
+
+  std::fill(indices.data(), indices.data()+indices.num_elements(), qIndex);
+
+  return indices;
+}
 
 static std::string thrown(void (*f)()) { try { f(); } catch (const std::logic_error &e) { return e.what(); } return "<no exception>"; }
 
@@ -54,6 +71,51 @@ int main() {
     int sum = 0;
     for (int vv = 0; vv < 3; ++vv) for (int h = 0; h < 2; ++h) sum += slice_bytes(vv, h, 3, 2, 1000, 6);
     EXPECT(sum == 1000 && slice_bytes(0, 0, 3, 2, 1000, 6) == 166 && slice_bytes(2, 1, 3, 2, 1000, 6) == 167);
+  }
+  { // the multi_array idioms of the reference's sources (Arrays.h:17-50): extents, indices, views as l- and r-values, ranges
+    Array2D a(extents[6][8]);
+    EXPECT(a.shape()[0] == 6 && a.shape()[1] == 8 && shape(a)[1] == 8);
+    for (Index y = 0; y < 6; ++y) for (Index x = 0; x < 8; ++x) a[y][x] = (int)(10 * y + x);
+    const Array2D odd = a[indices[Range(1, 6, 2)][Range()]];           // r-value: a dense copy of rows 1, 3, 5
+    EXPECT(odd.shape()[0] == 3 && odd.shape()[1] == 8 && odd[0][0] == 10 && odd[2][7] == 57);
+    Array2D b(a.ranges());                                               // same extents, zero filled
+    EXPECT(b.shape()[0] == 6 && b.shape()[1] == 8 && b[5][7] == 0);
+    b[indices[Range(0, 6, 2)][Range()]] = odd;                           // l-value: rows 0, 2, 4 take them
+    EXPECT(b[0][3] == 13 && b[2][0] == 30 && b[4][7] == 57 && b[1][3] == 0);
+    View2D win = b[indices[Range(2, 6, 2)][Range(1, 8, 3)]];
+    EXPECT(win.shape()[0] == 2 && win.shape()[1] == 3 && win[0][0] == 31 && win[1][2] == 57);
+    win[1][1] = -7;
+    EXPECT(b[4][4] == -7);
+    b.resize(extents[2][3]);
+    EXPECT(b.num_elements() == 6 && b[0][2] == 12);
+    Array1D m(extents[7]);
+    EXPECT(m.size() == 7 && Array1D(m.ranges()).size() == 7);
+    BlockArray blocks(extents[2][3]);
+    blocks[1][2] = odd;
+    EXPECT(shape(blocks)[0] == 2 && shape(blocks)[1] == 3 && blocks[1][2][2][7] == 57);
+    BlockVector bands(extents[4]);
+    EXPECT(bands.size() == 4);
+    const Array2D q = quantIndicesConstQ(Picture(), 3, 5, m, 21);
+    EXPECT(q.shape()[0] == 3 && q.shape()[1] == 5 && q[2][4] == 21 && q[0][0] == 21);
+    // Frame (Frame.cpp:40-94): fields are alternate rows; writing both fields back restores the frame
+    Frame fr(PictureFormat(6, 8, CF420), true, false);
+    Array2D y(extents[6][8]), u(extents[3][4]);
+    for (Index r = 0; r < 6; ++r) for (Index c = 0; c < 8; ++c) y[r][c] = (int)(100 * r + c);
+    for (Index r = 0; r < 3; ++r) for (Index c = 0; c < 4; ++c) u[r][c] = (int)(7 * r - c);
+    Frame even(PictureFormat(6, 8, CF422), true, true);
+    Array2D u2(extents[6][4]);
+    for (Index r = 0; r < 6; ++r) for (Index c = 0; c < 4; ++c) u2[r][c] = (int)(9 * r + c);
+    even.y(y); even.c1(u2); even.c2(u2);
+    const Picture top = even.topField(), bot = even.bottomField();
+    EXPECT(top.y().shape()[0] == 3 && top.y()[1][2] == 202 && bot.y()[1][2] == 302 && bot.c1()[2][3] == 48);
+    EXPECT(even.firstField().y()[0][0] == 0 && even.secondField().y()[0][0] == 100);
+    Frame rebuilt(PictureFormat(6, 8, CF422), true, true);
+    rebuilt.firstField(top); rebuilt.secondField(bot);
+    bool same = true;
+    for (Index r = 0; r < 6; ++r) for (Index c = 0; c < 8; ++c) same = same && rebuilt.y()[r][c] == y[r][c];
+    for (Index r = 0; r < 6; ++r) for (Index c = 0; c < 4; ++c) same = same && rebuilt.c2()[r][c] == u2[r][c];
+    EXPECT(same);
+    (void)fr; (void)u;
   }
   { // tests/Arrays.cpp:6-16
     Array2D a(3, 7);
