@@ -1,14 +1,22 @@
 // EncodeStream -- command-line compatible with /root/reference/src/EncodeStream (EncodeParams.cpp:55-249
 // flags and validation, EncodeStream.cpp:247-788 flow and output modes), with the per-picture body
 // running on MI355X through libvc2hip.  Extension: --gpus N encodes frame k on GPU k mod N.
+#include <cerrno>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <mutex>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
 #include <thread>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "Args.h"
 #include "DataUnit.h"
@@ -223,17 +231,56 @@ int main(int argc, char *argv[]) {
     bool done = false;
 
     if (output == STREAM) {
-      // The fused picture path (EncodeStream.cpp:482-647 on the device), pipelined: this thread reads frames into the
-      // workers' pinned buffers and writes finished pictures in order; picture k is coded by worker k mod N, which keeps
-      // two pictures in flight on its GPU (Pipeline.h).  An interlaced frame is two pictures, first field first
-      // (Frame.cpp:90-104).
+      // The fused picture path (EncodeStream.cpp:482-647 on the device), pipelined (Pipeline.h): picture k is coded by
+      // worker k mod N, which keeps two pictures in flight on its GPU.  I/O runs at the speed of the copies: when the
+      // input is a regular file every worker preads its own frames straight into pinned memory, and every worker
+      // writes its own data unit straight from pinned memory -- the output range is reserved in picture order (parse
+      // offsets and picture numbers chain: DataUnit.cpp:112-123, Utils.cpp:52-63), the pwrite happens outside that
+      // critical section.  Pipes and interlaced frames (a frame is two pictures, first field first: Frame.cpp:90-104)
+      // are read by this thread; pipes are written in order.
+      out->flush();
+      struct stat st;
+      const int ifd = inFileName == "-" ? 0 : ::open(inFileName.c_str(), O_RDONLY);
+      const bool inRegular = ifd >= 0 && fstat(ifd, &st) == 0 && S_ISREG(st.st_mode) && inFileName != "-";
+      const long long inSize = inRegular ? (long long)st.st_size : 0;
+      int ofd = 1;
+      if (outFileName != "-") { outFile.close(); ofd = ::open(outFileName.c_str(), O_WRONLY | O_APPEND); }
+      if (ifd < 0 || ofd < 0) throw std::runtime_error("cannot reopen the input / output file for the pipelined path");
+      const bool outSeekable = outFileName != "-" && fstat(ofd, &st) == 0 && S_ISREG(st.st_mode);
+      if (outSeekable) { ::close(ofd); ofd = ::open(outFileName.c_str(), O_WRONLY); } // (pwrite ignores the offset of O_APPEND descriptors)
+      auto writeAll = [&](const unsigned char *p, std::size_t n, long long at) {
+        while (n) {
+          const ssize_t r = outSeekable ? pwrite(ofd, p, n, (off_t)at) : ::write(ofd, p, n);
+          if (r < 0 && errno == EINTR) continue;
+          if (r <= 0) throw std::runtime_error(string("Failed to write output file \"") + outFileName + "\"");
+          p += r; n -= (std::size_t)r; at += r;
+        }
+      };
       GpuWorkers workers(devices, picBytes, vc2hip_max_payload_bytes(&pf, &cp) + 64);
       const utils::Rational ldRatio = utils::rationalise(pictureBytes, ySlices * xSlices);
-      auto writePicture = [&](const PictureResult &e) { // the ordered writer: parse offsets and picture numbers chain
-        if (!e.error.empty()) throw std::logic_error(e.error);
+      // ---- the ordered part of the writer
+      std::mutex om;
+      std::condition_variable ocv;
+      unsigned long long nextOut = 0;
+      long long outPos = (long long)du.size(); // behind the sequence header
+      string firstError;
+      // VC2_TOOL_STATS=1: the steady-state rate on stderr -- pictures per second between the completion of picture 4 * workers
+      // (contexts created, workspaces allocated, pages touched) and the last one (tools/cli_throughput.sh)
+      const bool stats = getenv("VC2_TOOL_STATS") != nullptr;
+      const unsigned long long warmPics = 4ull * devices.size();
+      std::chrono::steady_clock::time_point tWarm, tStart = std::chrono::steady_clock::now();
+      workers.setSink([&](unsigned long long seq, const unsigned char *data, std::size_t len, const string &err) {
+        const unsigned long picnum = utils::getPictureNumber((int)(seq % framePics), seq / framePics, framePics);
+        std::vector<unsigned char> head; // parse info + picture header (or, fragmented, the whole picture)
+        std::unique_lock<std::mutex> lock(om);
+        ocv.wait(lock, [&]() { return nextOut == seq; });
+        if (!err.empty() || !firstError.empty()) {
+          if (firstError.empty()) firstError = err;
+          ++nextOut; ocv.notify_all();
+          return;
+        }
         if (verbose) clog << "Forward transform" << endl << "Quantise transform coefficients" << endl << "Writing compressed output to file" << endl;
-        const unsigned long picnum = utils::getPictureNumber((int)(e.seq % framePics), e.seq / framePics, framePics);
-        du.clear();
+        bool payloadFollows = true;
         if (fragmented) {
           // DataUnit.cpp:156-232 / :267-342: parameters fragment + fragments of whole slices
           const std::vector<unsigned char> params =
@@ -241,47 +288,92 @@ int main(int argc, char *argv[]) {
                          : writeTransformParams(kernel, waveletDepth, true, xSlices, ySlices, (unsigned)slicePrefix, (unsigned)sliceScalar);
           std::vector<std::size_t> sizes;
           if (mode == LD) for (std::size_t i = 0; i < ldSliceBytes.num_elements(); ++i) sizes.push_back((std::size_t)ldSliceBytes.data()[i]);
-          else sizes = sliceSizesHQ(e.bytes.data(), e.bytes.size(), ySlices * xSlices, slicePrefix, sliceScalar);
-          writeFragmentedPicture(du, mode == LD, picnum, params, e.bytes.data(), sizes, xSlices, fragmentLength, &prev_parse_offset);
-          out->write((const char *)du.data(), (std::streamsize)du.size());
+          else sizes = sliceSizesHQ(data, len, ySlices * xSlices, slicePrefix, sliceScalar);
+          writeFragmentedPicture(head, mode == LD, picnum, params, data, sizes, xSlices, fragmentLength, &prev_parse_offset);
+          payloadFollows = false;
         } else {
           const std::vector<unsigned char> hdr =
               mode == LD ? writePictureHeaderLD(picnum, kernel, waveletDepth, xSlices, ySlices, ldRatio, major_version)
                          : writePictureHeaderHQ(picnum, kernel, waveletDepth, xSlices, ySlices, slicePrefix, sliceScalar, major_version);
-          const unsigned long next = (unsigned long)(hdr.size() + e.bytes.size() + 13);
-          writeParseInfo(du, mode == LD ? LD_PICTURE : HQ_PICTURE, next, prev_parse_offset);
+          const unsigned long next = (unsigned long)(hdr.size() + len + 13);
+          writeParseInfo(head, mode == LD ? LD_PICTURE : HQ_PICTURE, next, prev_parse_offset);
           prev_parse_offset = next;
-          du.insert(du.end(), hdr.begin(), hdr.end());
-          out->write((const char *)du.data(), (std::streamsize)du.size());
-          out->write((const char *)e.bytes.data(), (std::streamsize)e.bytes.size());
+          head.insert(head.end(), hdr.begin(), hdr.end());
         }
-        if (!*out) throw std::runtime_error(string("Failed to write output file \"") + outFileName + "\"");
-      };
-      std::vector<unsigned char> frameBuf; // interlaced: the frame is read here and its fields go to the workers
+        const long long at = outPos;
+        outPos += (long long)head.size() + (payloadFollows ? (long long)len : 0);
+        if (seq == warmPics) tWarm = std::chrono::steady_clock::now();
+        try {
+          if (!outSeekable) { // a pipe: in order, inside the critical section
+            writeAll(head.data(), head.size(), 0);
+            if (payloadFollows) writeAll(data, len, 0);
+          }
+        } catch (const std::exception &ex) { firstError = ex.what(); }
+        ++nextOut;
+        lock.unlock();
+        ocv.notify_all();
+        if (outSeekable) { // the range is ours: write it while the next picture reserves its own
+          try { writeAll(head.data(), head.size(), at); if (payloadFollows) writeAll(data, len, at + (long long)head.size()); }
+          catch (const std::exception &ex) { std::lock_guard<std::mutex> l2(om); if (firstError.empty()) firstError = ex.what(); }
+        }
+      });
+      std::vector<unsigned char> frameBuf; // interlaced / piped input: the frame is read here and goes to the workers from here
       unsigned long long seq = 0;
       PictureResult res;
+      auto drain = [&](bool all) { // completed pictures (their bytes went through the sink): errors surface in order
+        while (all ? workers.wait(res) : workers.poll(res)) if (!res.error.empty()) throw std::logic_error(res.error);
+      };
+      const long long wholeFrames = inRegular ? inSize / (long long)frameBytes : -1;
       for (;; ++frame) {
         if (verbose) clog << "Reading input frame number " << frame;
-        unsigned char *dst;
-        if (interlaced) { frameBuf.resize(frameBytes); dst = frameBuf.data(); }
-        else dst = workers.inputBuffer(seq);
-        in->read((char *)dst, (std::streamsize)frameBytes);
-        if ((std::size_t)in->gcount() < frameBytes) {
+        bool got;
+        if (inRegular && !interlaced) { // the worker reads it
+          got = (long long)frame < wholeFrames;
+          if (got) { (void)workers.inputBuffer(seq); workers.submitEncodeFile(seq, ifd, (long long)frame * (long long)frameBytes, frameBytes, pf, cp, mode == LD); ++seq; }
+        } else {
+          unsigned char *dst;
+          if (interlaced) { frameBuf.resize(frameBytes); dst = frameBuf.data(); }
+          else dst = workers.inputBuffer(seq);
+          std::size_t n = 0;
+          while (n < frameBytes) {
+            const ssize_t r = ::read(ifd, dst + n, frameBytes - n);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            n += (std::size_t)r;
+          }
+          got = n == frameBytes;
+          if (got) {
+            if (interlaced) {
+              for (int pic = 0; pic < framePics; ++pic) {
+                extractFieldRaw(frameBuf.data(), format, bytes, (pic == 0) == topFieldFirst, workers.inputBuffer(seq));
+                workers.submitEncode(seq++, pf, cp, mode == LD);
+              }
+            } else workers.submitEncode(seq++, pf, cp, mode == LD);
+          }
+        }
+        if (!got) {
           if (frame == 0) { cerr << "\rFailed to read input frame number 0" << endl; return EXIT_FAILURE; }
           if (verbose) clog << "\rEnd of input reached after " << frame << " frames" << endl;
-          break; // (the buffer taken for the missing frame is simply never submitted)
+          break; // (a buffer taken for the missing frame is simply never submitted)
         } else if (verbose) clog << endl;
-        if (interlaced) {
-          for (int pic = 0; pic < framePics; ++pic) {
-            extractFieldRaw(frameBuf.data(), format, bytes, (pic == 0) == topFieldFirst, workers.inputBuffer(seq));
-            workers.submitEncode(seq++, pf, cp, mode == LD);
-          }
-        } else workers.submitEncode(seq++, pf, cp, mode == LD);
-        while (workers.poll(res)) writePicture(res);
+        drain(false);
       }
       workers.close();
-      while (workers.wait(res)) writePicture(res);
-      done = true;
+      drain(true);
+      if (!firstError.empty()) throw std::logic_error(firstError);
+      du.clear();
+      writeParseInfo(du, END_OF_SEQUENCE, 0, prev_parse_offset);
+      writeAll(du.data(), du.size(), outPos);
+      if (stats) {
+        const std::chrono::steady_clock::time_point tEnd = std::chrono::steady_clock::now();
+        const double all = std::chrono::duration<double>(tEnd - tStart).count();
+        cerr << "EncodeStream stats: " << seq << " pictures in " << all << " s";
+        if (seq > warmPics + 1) cerr << "; steady state " << (double)(seq - warmPics) / std::chrono::duration<double>(tEnd - tWarm).count() << " pictures/s";
+        cerr << endl;
+      }
+      if (outFileName != "-") ::close(ofd);
+      if (inFileName != "-") ::close(ifd);
+      return EXIT_SUCCESS;
     }
 
     std::vector<std::vector<unsigned char> > raws(1);

@@ -1,7 +1,10 @@
 #include "Pipeline.h"
 
+#include <cerrno>
 #include <cstring>
 #include <stdexcept>
+
+#include <unistd.h>
 
 #include "Hip.h"
 
@@ -21,12 +24,16 @@ GpuWorkers::GpuWorkers(const std::vector<int> &devices, std::size_t in_bytes, st
     }
     workers_.push_back(w);
   }
-  for (Worker *w : workers_) w->th = std::thread([this, w]() { run(*w); });
+  for (Worker *w : workers_) {
+    w->th = std::thread([this, w]() { run(*w); });
+    w->reader = std::thread([this, w]() { runReader(*w); });
+  }
 }
 
 GpuWorkers::~GpuWorkers() {
   close();
   for (Worker *w : workers_) {
+    if (w->reader.joinable()) w->reader.join();
     if (w->th.joinable()) w->th.join();
     for (unsigned char *p : w->in) vc2hip_host_free(p);
     for (unsigned char *p : w->out) vc2hip_host_free(p);
@@ -56,15 +63,49 @@ unsigned char *GpuWorkers::inputBuffer(unsigned long long seq, std::size_t bytes
 }
 
 void GpuWorkers::submitEncode(unsigned long long seq, const vc2hip_picture_format &pf, const vc2hip_coding_params &cp, bool ld) {
-  Job j = {seq, 0, false, ld, 0, pf, cp};
+  Job j = {seq, 0, false, ld, 0, pf, cp, -1, 0};
   { std::lock_guard<std::mutex> rl(rm_); j.slot = slot_of_[seq]; slot_of_.erase(seq); ++submitted_; }
   Worker &w = *workers_[(std::size_t)(seq % workers_.size())];
   { std::lock_guard<std::mutex> lock(w.m); w.queue.push_back(j); }
   w.cv.notify_all();
 }
 
+void GpuWorkers::submitEncodeFile(unsigned long long seq, int fd, long long offset, std::size_t bytes, const vc2hip_picture_format &pf,
+                                  const vc2hip_coding_params &cp, bool ld) {
+  Job j = {seq, 0, false, ld, bytes, pf, cp, fd, offset};
+  { std::lock_guard<std::mutex> rl(rm_); j.slot = slot_of_[seq]; slot_of_.erase(seq); ++submitted_; }
+  Worker &w = *workers_[(std::size_t)(seq % workers_.size())];
+  { std::lock_guard<std::mutex> lock(w.m); w.toread.push_back(j); }
+  w.cv.notify_all();
+}
+
+// a worker's reader: file-sourced pictures, in order, straight into the pinned slot; then over to the GPU thread
+void GpuWorkers::runReader(Worker &w) {
+  for (;;) {
+    Job j;
+    {
+      std::unique_lock<std::mutex> lock(w.m);
+      w.cv.wait(lock, [&]() { return !w.toread.empty() || w.closing; });
+      if (w.toread.empty()) return;
+      j = w.toread.front();
+      w.toread.pop_front();
+      w.reading = true;
+    }
+    std::size_t got = 0;
+    while (got < j.len) {
+      const ssize_t r = pread(j.fd, w.in[(std::size_t)j.slot] + got, j.len - got, (off_t)(j.offset + (long long)got));
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) break;
+      got += (std::size_t)r;
+    }
+    j.fd = got == j.len ? -1 : -2; // -2: the GPU thread reports the short read, in order
+    { std::lock_guard<std::mutex> lock(w.m); w.queue.push_back(j); w.reading = false; }
+    w.cv.notify_all();
+  }
+}
+
 void GpuWorkers::submitDecode(unsigned long long seq, std::size_t len, const vc2hip_picture_format &pf, const vc2hip_coding_params &cp, bool ld) {
-  Job j = {seq, 0, true, ld, len, pf, cp};
+  Job j = {seq, 0, true, ld, len, pf, cp, -1, 0};
   { std::lock_guard<std::mutex> rl(rm_); j.slot = slot_of_[seq]; slot_of_.erase(seq); ++submitted_; }
   Worker &w = *workers_[(std::size_t)(seq % workers_.size())];
   { std::lock_guard<std::mutex> lock(w.m); w.queue.push_back(j); }
@@ -115,21 +156,23 @@ void GpuWorkers::run(Worker &w) {
   struct Open { Job job; int ticket; PictureResult res; };
   std::deque<Open> open;
   auto finish = [&](Open &o) {
+    std::size_t len = 0;
     if (o.res.error.empty()) {
       if (o.job.decode) {
         const int e = vc2hip_decode_picture_end(ctx, o.ticket);
         if (e) o.res.error = vc2hip_last_error(ctx);
-        else o.res.bytes.assign(w.out[(std::size_t)o.job.slot], w.out[(std::size_t)o.job.slot] + vc2hip_raw_picture_bytes(&o.job.pf));
+        else len = vc2hip_raw_picture_bytes(&o.job.pf);
       } else {
-        std::size_t len = 0;
         const int e = vc2hip_encode_picture_end(ctx, o.ticket, &len);
         if (e) o.res.error = vc2hip_last_error(ctx);
-        else {
-          o.res.bytes.assign(w.out[(std::size_t)o.job.slot], w.out[(std::size_t)o.job.slot] + len);
-          if (qidx_ints_) o.res.qidx.assign(w.qidx[(std::size_t)o.job.slot], w.qidx[(std::size_t)o.job.slot] + (std::size_t)o.job.cp.y_slices * o.job.cp.x_slices);
-        }
+        else if (qidx_ints_) o.res.qidx.assign(w.qidx[(std::size_t)o.job.slot], w.qidx[(std::size_t)o.job.slot] + (std::size_t)o.job.cp.y_slices * o.job.cp.x_slices);
       }
     }
+    const unsigned char *data = w.out[(std::size_t)o.job.slot];
+    if (sink_) { // straight from the pinned buffer, on this thread
+      try { sink_(o.job.seq, data, o.res.error.empty() ? len : 0, o.res.error); }
+      catch (const std::exception &ex) { if (o.res.error.empty()) o.res.error = ex.what(); }
+    } else if (o.res.error.empty()) o.res.bytes.assign(data, data + len);
     { std::lock_guard<std::mutex> lock(w.m); w.busy[(std::size_t)o.job.slot] = false; }
     w.cv.notify_all();
     publish(std::move(o.res));
@@ -139,9 +182,9 @@ void GpuWorkers::run(Worker &w) {
     bool have = false;
     {
       std::unique_lock<std::mutex> lock(w.m);
-      if (open.empty()) w.cv.wait(lock, [&]() { return !w.queue.empty() || w.closing; });
+      if (open.empty()) w.cv.wait(lock, [&]() { return !w.queue.empty() || (w.closing && w.toread.empty() && !w.reading); });
       if (!w.queue.empty()) { j = w.queue.front(); w.queue.pop_front(); have = true; }
-      else if (open.empty() && w.closing) break;
+      else if (open.empty() && w.closing && w.toread.empty() && !w.reading) break;
     }
     if (!have) { finish(open.front()); open.pop_front(); continue; } // nothing waiting: hand the oldest picture back
     if ((int)open.size() == VC2HIP_MAX_INFLIGHT) { finish(open.front()); open.pop_front(); }
@@ -150,6 +193,8 @@ void GpuWorkers::run(Worker &w) {
     o.ticket = -1;
     o.res.seq = j.seq;
     if (!w.init_error.empty()) o.res.error = w.init_error;
+    else if (j.fd == -2) o.res.error = "vc2hip: short read of an input picture";
+    if (!o.res.error.empty()) {}
     else if (j.decode) {
       const int e = vc2hip_decode_picture_begin(ctx, w.in[(std::size_t)j.slot], j.len, &j.pf, &j.cp, w.out[(std::size_t)j.slot], &o.ticket);
       if (e) o.res.error = vc2hip_last_error(ctx);

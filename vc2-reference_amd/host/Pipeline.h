@@ -11,6 +11,7 @@
 #define VC2HOST_PIPELINE_H
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -26,8 +27,23 @@ struct PictureResult {
   std::string error;                // the exception text of a failed picture (thrown again by the caller, in order)
 };
 
+// File I/O at the speed of the link (round 3).  The round-2 tools moved every picture through ONE thread twice (istream
+// read into the pinned buffer; a vector::assign copy of the result and an ostream write): 54 / 30 UHD frames per second
+// where the GPU path sustains over a thousand.  Now
+//   * a worker reads its own input: submitEncodeFile hands it (fd, offset, bytes) and the worker thread preads straight
+//     into its pinned slot -- one reader per worker, in parallel;
+//   * a worker delivers its own output: with a sink set, the finished picture is handed over as a pointer into the pinned
+//     output buffer on the worker's thread (no copy); the sinks of the tools reserve the output range in picture order
+//     (a short critical section) and pwrite outside it, so several workers write at once.
 class GpuWorkers {
  public:
+  // (seq, data, len, error): called on the worker thread that finished picture seq, pictures of one worker in order
+  typedef std::function<void(unsigned long long, const unsigned char *, std::size_t, const std::string &)> Sink;
+  void setSink(Sink s) { sink_ = s; }
+  // encode picture seq from `bytes` bytes at `offset` of file descriptor fd (read by the worker into the slot reserved
+  // with inputBuffer(seq))
+  void submitEncodeFile(unsigned long long seq, int fd, long long offset, std::size_t bytes, const vc2hip_picture_format &pf,
+                        const vc2hip_coding_params &cp, bool ld);
   // devices[g]: HIP device of worker g (a device may appear more than once: more pictures in flight on it).
   // in_bytes / out_bytes: upper bounds of one picture's input and output
   // qidx_ints: quantiser indices per picture that encode results carry (0: none wanted -- the stream writer does not use them)
@@ -51,26 +67,32 @@ class GpuWorkers {
     std::size_t len;
     vc2hip_picture_format pf;
     vc2hip_coding_params cp;
+    int fd;            // >= 0: the worker reads the input itself
+    long long offset;
   };
   struct Worker {
     int device = 0;
-    std::thread th;
+    std::thread th, reader;     // the GPU thread; the thread that reads file-sourced input (so that reads overlap the GPU thread's waits and writes)
     std::mutex m;
     std::condition_variable cv;
-    std::deque<Job> queue;
+    std::deque<Job> queue;      // ready for the GPU thread
+    std::deque<Job> toread;     // file-sourced jobs waiting for their bytes
     std::vector<unsigned char *> in, out; // pinned, SLOTS each
     std::vector<std::size_t> in_cap;      // bytes of in[i]
     std::vector<int *> qidx;              // pinned: the quantiser indices of an encoded picture come back here
     std::vector<bool> busy;               // input slot handed out and not yet finished
     int next_slot = 0;
     bool closing = false;
+    bool reading = false;       // the reader holds a job (taken from toread, not yet in queue)
     std::string init_error;
   };
-  static const int SLOTS = VC2HIP_MAX_INFLIGHT + 1;
+  static const int SLOTS = VC2HIP_MAX_INFLIGHT + 2; // two in flight, one being read / filled, one being written out
   void run(Worker &w);
+  void runReader(Worker &w);
   void publish(PictureResult &&r);
   std::vector<Worker *> workers_;
   std::size_t in_bytes_, out_bytes_, qidx_ints_;
+  Sink sink_;
   std::mutex rm_;
   std::condition_variable rcv_;
   std::map<unsigned long long, PictureResult> done_;
