@@ -1055,6 +1055,9 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
 // Anything outside that domain (a coefficient beyond 16 bits, a trial index above 79, a length byte overflow) hands the
 // slice to the general kernel through VC2_CBR_MARK: same answers, found the slow way.
 // Needs the common geometry (components of at most 512 / 256 coefficients, multiples of 8).
+#ifndef CBR_SPW
+#define CBR_SPW 8 // (measured: 4 -> 0.57, 8 -> 0.54, 16 -> 0.53 ms per 16 UHD pictures; one slice, as before: 0.76) consecutive slices per wavefront (the first is bisected, the others start at their predecessor's threshold)
+#endif
 template <class ST>
 __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
   __shared__ __attribute__((aligned(8))) unsigned char band_lds[768];
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
   __shared__ uint4 s_tab[80];  // by quantiser index: (rounded-up 4 / factor as a float, factor, offset + 2, -)
   __shared__ int s_qm[32];     // 16 x the quantisation matrix entry of every subband (byte offsets into s_tab)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x * 4 + wave, pic = blockIdx.y;
+  const int slice0 = (blockIdx.x * 4 + wave) * CBR_SPW, pic = blockIdx.y;
   {
     copy_band_lut(band_y, p.band_lut);
     if (threadIdx.x < 80)
@@ -1070,13 +1073,14 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     if (threadIdx.x < 32) s_qm[threadIdx.x] = threadIdx.x < p.n_bands ? 16 * p.qmatrix[threadIdx.x] : 0;
   }
   __syncthreads();
-  if (slice >= p.n_slices) return; // no workgroup barriers below
-  const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-  const ST *rec = (const ST *)p.store + rec_at;
-  const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
   const int half = lane >> 5, cc = 1 + half; // lanes 0-31 U, lanes 32-63 V
   const int jy = lane * 8, jc = (lane & 31) * 8;
   const bool has_y = jy < p.comp_n[0], has_c = jc < p.comp_n[1];
+  int guess = -1; // the previous slice's threshold (see the search below)
+  for (int slice = slice0; slice < min(slice0 + CBR_SPW, p.n_slices); ++slice) { // no workgroup barriers below
+  const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  const ST *rec = (const ST *)p.store + rec_at;
+  const int32_t *recw = St<ST>::narrow ? p.store_wide + rec_at : nullptr;
   float fy[8], fc[8]; // |coefficient|
   int my[8], mc[8];   // 16 x the matrix entry of its subband: table offset of a trial tq = clamp(16 tq - m, 0, 16 * 79)
   bool out = false;
@@ -1161,15 +1165,49 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     return (long long)__builtin_amdgcn_readlane(lo, 63) + ((long long)__builtin_amdgcn_readlane(hi, 63) << 24) - (64ll << 35);
   };
 
+  // The reference bisects: trial 63, steps 32 .. 1, 0 -- seven measurements of the slice (EncodeStream.cpp:88-104).  The
+  // bytes a slice needs never grow with the index (every factor grows, so every magnitude, code length and
+  // last-non-zero position shrinks or stays), so what the bisection returns is the THRESHOLD T = the smallest index in
+  // 0 .. 126 whose bytes fit (127: none), and it raises an error exactly when the smallest trial it visits -- a function
+  // of T alone -- overflows a length byte.  Neighbouring slices have neighbouring thresholds: a wavefront takes
+  // CBR_SPW consecutive slices, bisects the first like the reference and starts every other one at its predecessor's
+  // T: fits(T) and not fits(T - 1) are two measurements instead of seven (further away: gallop, then bisect the bracket),
+  // plus one at the reference's smallest trial for the error it would have raised there.
   bool bad = __any(out);
   int trial = 63, q = 127, delta = 64;
-  while (delta > 0 && !bad) {
-    delta >>= 1;
-    const int need = need_bytes(trial, bad);
-    bad = __any(bad);
-    if (need <= avail) { if (trial < q) q = trial; trial -= delta; }
-    else trial += delta;
+  if (guess < 0) {
+    while (delta > 0 && !bad) {
+      delta >>= 1;
+      const int need = need_bytes(trial, bad);
+      bad = __any(bad);
+      if (need <= avail) { if (trial < q) q = trial; trial -= delta; }
+      else trial += delta;
+    }
+  } else if (!bad) {
+    int lo = -1, hi = 127, step = 1, lowest = 127; // lo: the largest index known not to fit; hi: the smallest known to fit
+    int t = min(guess, 126);
+    for (;;) {
+      const int need = need_bytes(t, bad);
+      bad = __any(bad);
+      if (bad) break;
+      lowest = min(lowest, t);
+      if (need <= avail) hi = t; else lo = t;
+      if (hi - lo <= 1) break;
+      if (hi == 127) { if (lo >= 126) break; t = min(126, lo + step); step *= 2; }   // nothing fits yet: up
+      else if (lo < 0) { if (hi <= 0) break; t = max(0, hi - step); step *= 2; }      // everything fits so far: down
+      else t = (lo + hi) >> 1;
+    }
+    q = hi;
+    if (!bad) { // the smallest trial of the reference's walk to this threshold
+      int rt = 63, rd = 64, rmin = 127, rmax = 0;
+      while (rd > 0) { rd >>= 1; rmin = min(rmin, rt); rmax = max(rmax, rt); if (rt >= q) rt -= rd; else rt += rd; }
+      // (its largest trial may leave this kernel's domain, or the quantiser table -- the error the reference raises there:
+      // the general kernel walks the reference's own path for such slices, as before)
+      if (rmax - p.qm_min > 79) bad = true;
+      else if (rmin < lowest) { (void)need_bytes(rmin, bad); bad = __any(bad); }
+    }
   }
+  const int q_fit = q; // the threshold (before the refinement below): the next slice's starting point
   if (!bad) {
     trial = q;
     long long prev = yss(trial, bad), d;
@@ -1183,6 +1221,8 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
     q = trial - 1;
   }
   if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = bad ? VC2_CBR_MARK : q;
+  guess = bad ? -1 : q_fit;
+  } // slices of the wavefront
 }
 
 // wavefronts per workgroup so that their LDS (per_wave bytes each) fits: 4 down to 1; 0 if even one does not
@@ -1207,8 +1247,9 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_
                    p.comp_n[0] % 8 == 0 && p.comp_n[1] % 8 == 0 && (p.store_stride % 8) == 0 && (p.slice_coefs % 8) == 0 &&
                    p.comp_off[1] % 8 == 0 && p.comp_off[2] % 8 == 0;
   if (reg) { // the register kernel, then the general one over the slices it handed back (usually none: a small grid)
-    if (p.store16) VC2_LAUNCH(L, k_cbr_search_reg<int16_t>, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), 0, s, p);
-    else VC2_LAUNCH(L, k_cbr_search_reg<int32_t>, dim3((p.n_slices + 3) / 4, n_pictures), dim3(256), 0, s, p);
+    const int per_wg = 4 * CBR_SPW; // slices per workgroup
+    if (p.store16) VC2_LAUNCH(L, k_cbr_search_reg<int16_t>, dim3((p.n_slices + per_wg - 1) / per_wg, n_pictures), dim3(256), 0, s, p);
+    else VC2_LAUNCH(L, k_cbr_search_reg<int32_t>, dim3((p.n_slices + per_wg - 1) / per_wg, n_pictures), dim3(256), 0, s, p);
     p.only_marked = 1;
   }
   if (per_wave + tables > 160 * 1024) { // the slice does not fit in LDS: the search reads it from the store in every trial
