@@ -4,7 +4,7 @@
 A "step" = one pass of the hot path (encode_batch_dev then decode_batch_dev) over one batch of
 synthetic pictures that are already resident in HBM.  Workload at every N: BASELINE.json config 2
 (UHD-1 3840x2160 4:2:2 10-bit, HQ_ConstQ, DD97, 4 levels, slices -u 1 -a 2, q 16, scalar 2);
-each rank/GPU owns its own batch of 16 distinct pictures (frames are independent: weak scaling, no
+each rank/GPU owns its own batch of 32 distinct pictures, cut over two HIP streams (frames are independent: weak scaling, no
 collective on the data path).  Prints ONE JSON line on rank 0:
 
   value            encode+decode, device resident, K timed steps (barrier + synchronize on both sides)
@@ -136,16 +136,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="pictures per GPU per step (all distinct)")
+    ap.add_argument("--batch", type=int, default=32, help="pictures per GPU per step (all distinct)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the per-core CPU run (0: one per core)")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the barrier and the MAX-over-ranks (nccl = RCCL; gloo: CPU tensors, for ranks that share a GPU)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the library cuts each batch over (vc2hip_set_streams); 1 = one launch per kernel and "
-                         "batch, which is what the roofline figures describe")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the library cuts each batch over (vc2hip_set_streams): every kernel is launched once per "
+                         "stream on batch / streams pictures, and the launches of one stream fill the ramps and tails of the other's")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,10 +165,25 @@ def main():
     # synthetic pictures: SURVEY Appendix-B generator.  Rank 0: seed 1234, B distinct frames (frames 0-1 are the pair whose
     # reference digests tests/golden holds).  Every other rank keeps that pair in its slots 0-1 (its own golden check) and
     # fills the rest with frames of its own seed 1234 + rank: the ranks code different pictures.
+    # (numpy makes 0.45 UHD frames per second: at most 16 frames come from the generator, the rest of a larger batch are
+    # those frames with every plane rolled down by 64 rows per repetition -- distinct pictures, coded by the oracle like any other)
+    G = min(B, 16)
     if rank == 0 or B <= 2:
-        frames = synth(W, H, CFMT, BITS, 1234, frames=B)
+        frames = synth(W, H, CFMT, BITS, 1234, frames=G)
     else:
-        frames = synth(W, H, CFMT, BITS, 1234, frames=2) + synth(W, H, CFMT, BITS, 1234 + rank, frames=B - 2)
+        frames = synth(W, H, CFMT, BITS, 1234, frames=2) + synth(W, H, CFMT, BITS, 1234 + rank, frames=G - 2)
+    if B > G:
+        rb0 = len(frames) // G
+        a = np.frombuffer(frames, np.uint8).reshape(G, rb0)
+        ny, nc = W * H * 2, (rb0 - W * H * 2) // 2
+        cw = W if CFMT == "444" else W // 2
+        more = []
+        for k in range(G, B):
+            src, rows = a[k % G], 64 * (k // G)
+            more.append(np.concatenate([np.roll(src[:ny].reshape(-1, W * 2), rows, 0).reshape(-1),
+                                        np.roll(src[ny:ny + nc].reshape(-1, cw * 2), rows, 0).reshape(-1),
+                                        np.roll(src[ny + nc:].reshape(-1, cw * 2), rows, 0).reshape(-1)]))
+        frames = frames + b"".join(m.tobytes() for m in more)
     rb = len(frames) // B
 
     # ---- CPU baseline first: nothing has touched the GPU yet, so forking worker processes is safe
@@ -198,8 +213,6 @@ def main():
 
     import vc2hip_py
     hip = vc2hip_py.Vc2Hip(dev_index)
-    if args.streams > 1:
-        hip.set_streams(args.streams)
     fmt = vc2hip_py.picture_format(W, H, CFMT, BITS)
     cp = vc2hip_py.coding_params(hip.lib, fmt, KERNEL, DEPTH, U, A, q=Q, scalar=SCALAR)
     assert rb == hip.raw_picture_bytes(fmt)
@@ -235,20 +248,35 @@ def main():
         barrier()
         return time.perf_counter() - t0
 
-    # ---- warm-up: W untimed steps, then three more (untimed too) with a HIP event pair on EVERY kernel launch -> the
-    # per-kernel table and the dominant kernel (30 launches per step: paying for all their events inside the timed region
-    # costs 4 % of it)
-    for _ in range(args.warmup):
-        step()
+    # ---- the per-kernel table and the dominant kernel: ONE stream, the pictures of one launch (batch / streams), event pairs on
+    # every launch, untimed.  (Paying for all ~30 event pairs of a step inside the timed region costs 4 % of it; and with
+    # two streams a launch's duration includes what the other stream's kernels take from it -- the table is of kernels alone.)
+    n_launch = max(1, B // max(1, min(args.streams, B)))   # pictures one launch processes
+
+    def step_one_launch():
+        hip.encode_batch_dev(d_raw.data_ptr(), n_launch, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n_launch, fmt, cp, d_out.data_ptr())
+    for _ in range(2):
+        step_one_launch()
     hip.sync()
-    w_steps = 3 if args.warmup > 0 else 0   # (no warm-up asked for: the timed region carries every kernel's events instead)
+    w_steps = 3
     hip.profile_reset()
     hip.profile_enable(True)
     for _ in range(w_steps):
-        step()
+        step_one_launch()
     hip.sync()
+    hip.profile_enable(False)
     warm = {k: v for k, v in hip.profile().items() if v[0] > 0 and k != "fill"}
     dom = max(warm, key=lambda k: warm[k][1]) if warm else None
+    hip.profile_reset()
+
+    # ---- warm-up of the timed configuration: W untimed steps over the whole batch on `streams` streams
+    if args.streams > 1:
+        hip.set_streams(args.streams)
+    for _ in range(max(1, args.warmup)):
+        step()
+    hip.sync()
+    hip.profile_enable(True)
 
     # ---- timed region: exactly K steps; the dominant kernel's launches carry their event pairs (on the library's stream)
     hip.profile_reset()
@@ -335,15 +363,17 @@ def main():
         # algorithmic bytes: encode w*S + C, decode C + w*S per picture
         samples = W * H * 2  # 4:2:2
         alg_dir = 2 * samples + coded
-        if dom is None:   # no warm-up steps: the timed region carried every kernel's events
-            warm, w_steps = {k: v for k, v in prof.items() if v[0] > 0 and k != "fill"}, args.steps
-            dom = max(warm, key=lambda k: warm[k][1])
-        kern_step_ms = {k: v[1] / w_steps for k, v in warm.items()}     # per step, every kernel (warm-up steps)
+        launches_per_step = B / n_launch
+        kern_launch_ms = {k: v[1] / w_steps for k, v in warm.items()}    # one encode + decode of n_launch pictures, kernels alone
+        kern_step_ms = {k: v * launches_per_step for k, v in kern_launch_ms.items()}
         dom_launches, dom_ms = prof[dom]                                  # the dominant kernel, live in the timed region
         dom_avg_s = dom_ms / dom_launches / 1e3
-        per_launch = B / max(1, min(args.streams, B))   # pictures one launch processes
+        per_launch = n_launch
         achieved = alg_dir * per_launch / dom_avg_s / 1e9
-        path_achieved = 2 * alg_dir * B / (sum(kern_step_ms.values()) / 1e3) / 1e9
+        solo_avg_s = warm[dom][1] / warm[dom][0] / 1e3                    # the same kernel with the GPU to itself
+        solo_achieved = alg_dir * per_launch / solo_avg_s / 1e9
+        path_achieved = 2 * alg_dir * B / (dt / args.steps) / 1e9         # the whole step: what the timed region sustained
+        path_solo = 2 * alg_dir * n_launch / (sum(kern_launch_ms.values()) / 1e3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
         # separate runs, gfx950 correction applied).  Only valid for the kernel sources it was measured on.
         traffic, traffic_note, path_traffic = None, "no committed PMC profile", None
@@ -375,7 +405,7 @@ def main():
             "dtype": "int32",
             "dtype_note": "the reference's arithmetic: every transform, quantiser and code value is computed as int32 in registers; "
                           "the coefficient store between kernels holds int16 with an escape to int32 (exact for every input)",
-            "data": f"synthetic (SURVEY Appendix-B generator, seed 1234; {B} distinct pictures per GPU" +
+            "data": f"synthetic (SURVEY Appendix-B generator, seed 1234; {B} distinct pictures per GPU" + (f": {G} generated, the others those rolled by 64 rows per repetition" if B > G else "") +
                     ("" if world == 1 else "; slots 2.. of rank r from seed 1234 + r") + ")",
             "config": {"workload": "BASELINE cfg2: UHD-1 3840x2160 4:2:2 10-bit HQ_ConstQ DD97 depth 4, -u 1 -a 2 -q 16 -S 2",
                        "pictures_per_gpu_per_step": B, "coded_bytes_per_picture": round(coded, 1), "streams": args.streams,
@@ -385,15 +415,22 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": dom, "kernel_avg_ms": round(dom_ms / dom_launches, 4),
+                         "solo_achieved": round(solo_achieved, 1), "solo_frac": round(solo_achieved / HBM_PEAK_GBS, 4),
+                         "solo_kernel_avg_ms": round(solo_avg_s * 1e3, 4),
+                         "solo_note": "the same kernel, same pictures per launch, launched on ONE stream (untimed table pass): with "
+                                      f"{args.streams} streams a launch shares the GPU with the other stream's kernels and `frac` prices that contention in",
                          "algorithmic_bytes_per_launch": int(alg_dir * per_launch),
                          "path_achieved_GBs": round(path_achieved, 1),
                          "path_frac": round(path_achieved / HBM_PEAK_GBS, 4),
+                         "path_frac_note": "algorithmic bytes of a step / measured step time of the timed region",
+                         "path_solo_frac": round(path_solo / HBM_PEAK_GBS, 4),
                          "path_algorithmic_bytes_per_step": int(2 * alg_dir * B),
                          "path_traffic_bytes": path_traffic,
                          "path_traffic_ratio": ({k: round(v / (2 * alg_dir * B), 2) for k, v in path_traffic.items()} if path_traffic else None),
                          "kernel_events": f"the {dom_launches} launches of `{dom}` inside the timed region",
                          "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_step_ms.items())},
-                         "kernel_ms_per_step_source": f"event pairs on every launch of {w_steps} untimed steps between the warm-up and the timed region"},
+                         "kernel_ms_per_step_source": f"event pairs on every launch of {w_steps} untimed one-stream passes over {n_launch} pictures (one launch's worth), "
+                                                      f"times {launches_per_step:g} launches per step: kernels alone, additive"},
             "value_without_kernel_events": round(total_px / dt_noev / 1e6, 1),
             "parity_checked": parity,
             "e2e": e2e,

@@ -131,6 +131,7 @@ struct vc2hip_ctx {
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
   bool allow_planes = true; // decode: band planes for the streaming levels (A/B and test switch VC2HIP_NO_BANDPLANES)
+  bool allow_heads = true;  // record heads for the levels below them (A/B and test switch VC2HIP_NO_HEADS)
   bool allow_cbr_index = true; // decode of HQ_CBR pictures: offsets from the budgets, verified (VC2HIP_NO_CBR_INDEX=1: always the general index)
   bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
@@ -301,6 +302,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_STREAM"); c->allow_stream = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_BANDPLANES"); c->allow_planes = !(e && e[0] == '1'); }
+  { const char *e = getenv("VC2HIP_NO_HEADS"); c->allow_heads = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_CBR_INDEX"); c->allow_cbr_index = !(e && e[0] == '1'); }
 #ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
@@ -635,6 +637,7 @@ static void fill_level(LevelParams &p, const Geom &g, int level, int kernel, con
     p.in_h[c] = cg.ph >> level; p.in_w[c] = cg.pw >> level;
     p.pic_h[c] = cg.h; p.pic_w[c] = cg.w;
     p.coef_off[c] = cg.coef_off;
+    p.rec_stride[c] = g.slice_coefs;
     if (cg.ph == 0) { p.tiles_x[c] = p.tiles_y[c] = 0; p.fh[c] = p.fw[c] = 2; p.tsy[c] = p.tsx[c] = 1; continue; }
     p.fh[c] = cg.sh >> level; p.fw[c] = cg.sw >> level;
     // tile ~64 x 128 samples, whole slices, power-of-two slice counts, LDS <= 64 KiB
@@ -709,12 +712,16 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
                        const int32_t *qm, bool dequant, bool ll_ready, const LLPlanes &ll, void *const dst[3],
                        const long long dst_stride[3], bool dst_raw, const vc2hip_picture_format *f,
                        bool s16 = false, int32_t *store_wide = nullptr, const BandPlanes *bp = nullptr,
-                       long long store_stride = 0, unsigned *stream_mask = nullptr) {
+                       long long store_stride = 0, unsigned *stream_mask = nullptr, const HeadSplit *hs = nullptr, int head_level = 1 << 30,
+                       unsigned *fast_mask = nullptr) {
   if (stream_mask) *stream_mask = 0;
+  if (fast_mask) *fast_mask = 0;
   for (int level = g.depth - 1; level >= 0; --level) {
     LevelParams p;
     memset(&p, 0, sizeof p);
     fill_level(p, g, level, kernel, qm);
+    if (hs && level >= head_level) // the deep levels' coefficients live in the record heads (HeadSplit)
+      for (int k = 0; k < 3; ++k) if (g.c[k].ph) { p.rec_stride[k] = hs->n[k]; p.coef_off[k] = (int)hs->base[k]; }
     p.store = store; p.store_stride = store_stride ? store_stride : (long long)g.ys * g.xs * g.slice_coefs;
     for (int k = 0; k < 3; ++k) p.bp_base[k] = (bp && level < bp->levels && g.c[k].ph) ? bp->base[k][level] : -1;
     p.store_wide = store_wide;
@@ -745,7 +752,7 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
         continue;
       }
     }
-    if (stream_mask) continue;
+    if (stream_mask) { if (fast_mask && !c->force_generic && vc2_fast_level_applicable(pf)) *fast_mask |= 1u << level; continue; }
     if (bp && level < bp->levels) return set_err(c, VC2HIP_EINVAL, "internal: band planes without the streaming kernel");
     if (!c->force_generic && vc2_fast_level_applicable(pf)) {
       int rc = vc2_launch_inverse_fast(c->L, kernel, fin, pf, n, s16, c->stream);
@@ -1521,8 +1528,37 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     }
     if (sstride >= (1ll << 31)) { memset(&bp, 0, sizeof bp); sstride = (long long)ns * g.slice_coefs; } // 32-bit element offsets
   }
+  // Record heads (HeadSplit, vc2hip_internal.h): the levels below the streaming ones, when all of them run on the tile
+  // kernels, read their coefficients from dense per-component arrays behind the records (and band planes)
+  HeadSplit hs;
+  memset(&hs, 0, sizeof hs);
+  int head_level = 1 << 30;
+  if (s16 && !plane_path && c->allow_heads) {
+    unsigned smask = 0, fmask = 0;
+    LLPlanes none;
+    memset(&none, 0, sizeof none);
+    (void)run_inverse(c, g, cp->kernel, n, nullptr, nullptr, qm, true, ld, none, dst, ds, true, f, s16, nullptr, nullptr, 0, &smask, nullptr, 1 << 30, &fmask);
+    int ls = g.depth; // first level of the run of tile-kernel levels that reaches the deepest one
+    while (ls > 0 && !(smask >> (ls - 1) & 1) && (fmask >> (ls - 1) & 1)) --ls;
+    bool ok = ls >= 1 && ls < g.depth && ls >= bp.levels; // (level 0 keeps its bands where the final kernels expect them)
+    for (int k = 0; k < 3 && ok; ++k) {
+      if (!g.c[k].ph) continue;
+      const int hn = (g.c[k].sh >> ls) * (g.c[k].sw >> ls);
+      ok = hn >= 8 && hn % 8 == 0 && hn <= bp.from[k];
+    }
+    if (ok) {
+      long long at = sstride;
+      for (int k = 0; k < 3; ++k) {
+        if (!g.c[k].ph) continue;
+        hs.n[k] = (g.c[k].sh >> ls) * (g.c[k].sw >> ls);
+        hs.base[k] = at;
+        at += ((long long)ns * hs.n[k] + 7) & ~7ll;
+      }
+      if (at < (1ll << 31)) { sstride = at; head_level = ls; } else memset(&hs, 0, sizeof hs);
+    }
+  }
   int32_t *d_store, *d_ll, *d_q, *d_storew = nullptr, *d_llw = nullptr;
-  NEED(c, B_STORE, (size_t)n * ns * g.slice_coefs * 4, d_store); // 16-bit elements: records and band planes fit in it
+  NEED(c, B_STORE, std::max((size_t)n * ns * g.slice_coefs * 4, (size_t)n * (size_t)sstride * 2), d_store); // (16-bit elements: records, band planes and record heads)
   NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
   if (s16) {
     NEED(c, B_STOREW, (size_t)n * sstride * 4, d_storew);
@@ -1560,7 +1596,7 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     int n0[3];
     fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
     p.prefix = cp->prefix; p.scalar = cp->scalar; p.err = c->d_err;
-    p.bp = bp; p.xs = g.xs;
+    p.bp = bp; p.hs = hs; p.xs = g.xs;
     vc2_launch_unpack(c->L, p, n, c->stream);
   } else {
     // DecodeStream.cpp:312, :331-333: per-slice sizes from the picture byte budget
@@ -1592,7 +1628,8 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
                        ll.stride[g.depth][k], n, c->d_err, c->stream);
   }
   if (plane_path) return plane_inverse(c, g, cp->kernel, n, d_store, d_q, qm, dst, ds, f);
-  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew, &bp, sstride);
+  return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew, &bp, sstride, nullptr,
+                     hs.n[0] ? &hs : nullptr, head_level);
 }
 
 extern "C" int vc2hip_decode_batch_dev(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens,

@@ -27,6 +27,15 @@ void vc2_upload_tables_fast(const QuantTables &t, hipStream_t s) {
 #ifndef VC2_FID_NT
 #define VC2_FID_NT 512
 #endif
+#ifdef VC2HIP_STAMPS // diagnostic build only: per-phase times of a tile workgroup
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+__device__ unsigned long long *g_tile_stamps;
+#define TILE_STAMP(k) do { if (threadIdx.x == 0 && g_tile_stamps) g_tile_stamps[16 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) + (k)] = wall_clock64(); } while (0)
+#else
+#define TILE_STAMP(k)
+#endif
 namespace {
 
 constexpr int TY = 32, TX = 128;
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
   const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
   int tile_x, tile_y;
   if (!tile_of_block(p.tiles_x[comp], p.tiles_y[comp], tile_x, tile_y)) return;
+  TILE_STAMP(0);
   constexpr int HY = C::HY, HX = C::HX, WX = C::WX, WY = C::WY, WXP = C::WXP, ACC = WT<K>::accuracy;
   const int in_h = p.in_h[comp], in_w = p.in_w[comp];
   const int y0 = min(tile_y * TY, in_h - TY), x0 = min(tile_x * TX, in_w - TX);
@@ -436,6 +446,7 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
     }
   }
   __syncthreads();
+  TILE_STAMP(1);
 
   // ---- lifting in registers: horizontal over all in-plane window rows, vertical over the core
   {
@@ -453,6 +464,7 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
     }
   }
 
+  TILE_STAMP(2);
   // ---- write the four bands of the core
   const int fh = p.fh[comp], fw = p.fw[comp];
   const int bsh = fh >> 1, bsw = fw >> 1;
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
     const int chunk0 = p.coef_off[comp] + (p.ll_to_store ? 0 : p.band_off[comp]);
     const int chunk_n = (4 - band_first) * band_n, nq = (chunk_n + 3) >> 2;
     const int tsx = TX / fw, nsl = (TY / fh) * tsx;
-    const bool al = ((chunk0 | p.slice_coefs) & 3) == 0;
+    const bool al = ((chunk0 | p.rec_stride[comp]) & 3) == 0;
     for (int id = threadIdx.x; id < nsl * nq; id += NT) {
       const int sidx = id / nq, qd = id - sidx * nq;
       const int si = sidx / tsx, sj = sidx - si * tsx;
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
         const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
         e[k] = core[band * C::PLANE + ((si << (lblk - lbsw)) + (rem >> lbsw)) * WXP + (sj << lbsw) + (rem & (bsw - 1))];
       }
-      const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + chunk0 + 4 * qd;
+      const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.rec_stride[comp] + chunk0 + 4 * qd;
       if (al && 4 * qd + 4 <= chunk_n) S_::store4(store + at, wide + at, e[0], e[1], e[2], e[3]);
       else {
 #pragma unroll
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
         const int si = s >> tsx_l, sj = s & ((1 << tsx_l) - 1);
         const int r = rem >> lbsw, c = rem & (bsw - 1);
         const I4 v = lds_ld4(src + ((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c);
-        const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem;
+        const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.rec_stride[comp] + off + rem;
         S_::store4(store + at, wide + at, v.x, v.y, v.z, v.w);
       }
     } else {
@@ -526,11 +538,12 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
         const int s = e >> lblk, rem = e & ((1 << lblk) - 1);
         const int si = s >> tsx_l, sj = s & ((1 << tsx_l) - 1);
         const int r = rem >> lbsw, c = rem & (bsw - 1);
-        const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.slice_coefs + off + rem;
+        const size_t at = (size_t)((s_y0 + si) * p.xs + s_x0 + sj) * p.rec_stride[comp] + off + rem;
         S_::store1(store + at, wide + at, src[((si << (lblk - lbsw)) + r) * WXP + (sj << lbsw) + c]);
       }
     }
   }
+  TILE_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,6 +560,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
   const int comp = blockIdx.z % 3, pic = blockIdx.z / 3;
   int tile_x, tile_y;
   if (!tile_of_block(p.tiles_x[comp], p.tiles_y[comp], tile_x, tile_y)) return;
+  TILE_STAMP(0);
   constexpr int HY = C::HY, HX = C::HX, WXP = C::WXP, WYP = C::WYP, ACC = WT<K>::accuracy;
   const int out_h = p.in_h[comp], out_w = p.in_w[comp];
   const int y0 = min(tile_y * TY, out_h - TY), x0 = min(tile_x * TX, out_w - TX);
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     qtab[240 + threadIdx.x] = qf > 0 ? (int)((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf) : -1;
   }
   __syncthreads();
+  TILE_STAMP(1);
 
   // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in.
   // Every 16-byte load of the thread (and the slice's quantiser index beside it) is issued before
@@ -605,7 +620,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
         if (from_plane) val[band][it] = ldq(llp + (size_t)by * npx + bx0);
         else {
           const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
-          val[band][it] = ldq(store + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c);
+          val[band][it] = ldq(store + (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + off + (r << lbsw) + c);
           if (p.dequant) qv[band][it] = qidx[sv * p.xs + sh];
         }
       }
@@ -632,7 +647,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
               if (from_plane) wq = llp_w + (size_t)by * npx + bx0;
               else {
                 const int sv = by >> lbsh, r = by & (bsh - 1), sh = bx0 >> lbsw, c = bx0 & (bsw - 1);
-                wq = wide + (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c;
+                wq = wide + (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + off + (r << lbsw) + c;
               }
 #pragma unroll
               for (int k = 0; k < 4; ++k) if (e[k] == VC2_ST_SENTINEL) e[k] = wq[k];
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
           for (int k = 0; k < 4; ++k) {
             const int bx = min(max(bx0 + k, 0), npx - 1);
             const int sh = bx >> lbsw, c = bx & (bsw - 1);
-            const size_t at = (size_t)(sv * p.xs + sh) * p.slice_coefs + off + (r << lbsw) + c;
+            const size_t at = (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + off + (r << lbsw) + c;
             int t = S_::load1(store + at, wide + at);
             if (p.dequant) {
               const int aq = max(qidx[sv * p.xs + sh] - qm, 0);
@@ -686,6 +701,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
       }
     }
   }
+  TILE_STAMP(2);
   if constexpr (SMALL) {
     // Deep levels: the level's bands of one slice and component are ONE short contiguous run of its record
     // ([LL |] HL | LH | HH, a few to a few dozen coefficients), so they are fetched slice by slice -- one 16-byte load
@@ -698,12 +714,12 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     const int sr0 = max(ky_base, 0) >> lbsh, sr1 = min(ky_base + WYP - 1, npy - 1) >> lbsh;
     const int sc0 = max(kx_base, 0) >> lbsw, sc1 = min(kx_base + WXP - 1, npx - 1) >> lbsw;
     const int nsc = sc1 - sc0 + 1, nsl = (sr1 - sr0 + 1) * nsc, nq = (chunk_n + 3) >> 2;
-    const bool al = ((chunk0 | p.slice_coefs) & 3) == 0;
+    const bool al = ((chunk0 | p.rec_stride[comp]) & 3) == 0;
     const int qm0 = p.qmatrix[0], qm1 = p.qmatrix[p.band], qm2 = p.qmatrix[p.band + 1], qm3 = p.qmatrix[p.band + 2];
     for (int id = threadIdx.x; id < nsl * nq && !VC2_SKIP(p, 1); id += NT) {
       const int sidx = id / nq, qd = id - sidx * nq;
       const int sr = sidx / nsc, sv = sr0 + sr, sh = sc0 + (sidx - sr * nsc);
-      const size_t at = (size_t)(sv * p.xs + sh) * p.slice_coefs + chunk0 + 4 * qd;
+      const size_t at = (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + chunk0 + 4 * qd;
       int e[4];
       if (al && 4 * qd + 4 <= chunk_n) S_::load4(store + at, wide + at, e);
       else {
@@ -729,6 +745,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     }
   }
   __syncthreads();
+  TILE_STAMP(3);
 
   // ---- inverse lifting in registers: vertical over every window column, horizontal over the core rows
   {
@@ -750,6 +767,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     }
   }
   if (VC2_SKIP(p, 4)) return;
+  TILE_STAMP(4);
 
   // ---- interleave, round, write (FINAL: clip + offset + justify + big-endian 16-bit words)
   const int lim_h = FINAL ? p.pic_h[comp] : out_h, lim_w = FINAL ? p.pic_w[comp] : out_w;
@@ -793,6 +811,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
       }
     }
   }
+  TILE_STAMP(5);
 }
 
 template <int K, bool EDGE, bool INV, class ST>
@@ -801,6 +820,16 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
   for (int c = 0; c < 3; ++c) { gx = std::max(gx, p.tiles_x[c]); gy = std::max(gy, p.tiles_y[c]); }
   dim3 grid(gx, gy, 3 * n_pictures), block(NTK<K>);
   const size_t lds = INV ? Cfg<K>::LDS_INV : Cfg<K>::LDS;
+#ifdef VC2HIP_STAMPS
+  const char *stamp_file = getenv("VC2HIP_TILE_STAMPS_FILE");
+  const size_t stamp_n = (size_t)gx * gy * 3 * n_pictures * 16;
+  unsigned long long *d_st = nullptr;
+  if (stamp_file) {
+    (void)hipMalloc((void **)&d_st, stamp_n * 8);
+    (void)hipMemsetAsync(d_st, 0, stamp_n * 8, s);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tile_stamps), &d_st, sizeof d_st, 0, hipMemcpyHostToDevice, s);
+  }
+#endif
   if constexpr (INV) {
     // element-wise gather when some component's band blocks are narrower than four coefficients
     bool small = false;
@@ -818,6 +847,22 @@ void launch_fast(Launcher &L, const LevelParams &p, int n_pictures, hipStream_t 
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
     VC2_LAUNCH(L, (k_fwd_fast<K, EDGE, ST>), grid, block, lds, s, p);
   }
+#ifdef VC2HIP_STAMPS
+  if (stamp_file) {
+    std::vector<unsigned long long> h(stamp_n);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), d_st, stamp_n * 8, hipMemcpyDeviceToHost);
+    unsigned long long *none = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), &none, sizeof none);
+    (void)hipFree(d_st);
+    if (FILE *fp = fopen(stamp_file, "ab")) {
+      const int hdr[8] = {INV ? 1 : 0, p.in_w[0], gx, gy, 3 * n_pictures, (int)lds, 0, 0};
+      fwrite(hdr, sizeof hdr, 1, fp);
+      fwrite(h.data(), 8, stamp_n, fp);
+      fclose(fp);
+    }
+  }
+#endif
   vc2_prof_end(L, s);
 }
 

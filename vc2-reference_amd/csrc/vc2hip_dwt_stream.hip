@@ -229,7 +229,6 @@ template <int K, bool INV> struct VEng {
     if constexpr (P < T::N) {
       constexpr int dst = sl(U - T::off(P));
       constexpr int dmin = T::dmin(P), dmax = T::dmax(P);
-      const int c = m - T::off(P);
       if constexpr (MODE == 2 && (D + 1 > T::off(P))) copy<sl(U - T::off(P) - 1), dst>(x[P]); // below the plane: the last pair again
       else {
         Row W[dmax - dmin + 1]; // rows c_P + dmin .. c_P + dmax of what position P reads
@@ -851,7 +850,7 @@ __global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_inv_stream(cons
 template <int K, bool EDGE, bool INV, class ST, bool TAIL>
 void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds, hipStream_t s) {
   const int cols = (p.st_strips[0] + p.st_strips[1] + p.st_strips[2]) * n_pictures;
-  const int gx = ((cols + 7) / 8) * p.st_segmax * 8, gy = 1;
+  const int gx = ((cols + 7) / 8) * p.st_segmax * 8;
   dim3 grid(gx), block(64);
 #ifdef VC2HIP_STAMPS
   const char *stamp_file = getenv("VC2HIP_STAMPS_FILE");
@@ -881,7 +880,7 @@ void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &none, sizeof none);
     (void)hipFree(d_st);
     if (FILE *fp = fopen(stamp_file, "ab")) {
-      const int hdr[8] = {INV ? 1 : 0, EDGE ? 1 : 0, gx, gy, 1, (int)lds, 0, 0};
+      const int hdr[8] = {INV ? 1 : 0, EDGE ? 1 : 0, gx, 1, 1, (int)lds, 0, 0};
       fwrite(hdr, sizeof hdr, 1, fp);
       fwrite(h.data(), 8, stamp_n, fp);
       fclose(fp);

@@ -101,6 +101,8 @@ struct LevelParams {
   int band_n[3];              // coefficients per band block (bsh * bsw)
   int band;                   // band index of HL at this level (for the quant matrix)
   int ys, xs, slice_coefs;
+  int rec_stride[3];          // tile kernels (vc2hip_dwt_fast.hip): elements from one slice's coefficients of a component to the next
+                              // slice's -- slice_coefs in the slice records, HeadSplit::n[c] in the record heads
   int word_bytes, sample_shift, sample_offset; // raw sample format
   int clip_lo, clip_hi;
   int ll_from_store;          // inverse, coarsest level: LL comes from store band 0 (dequantised)
@@ -175,6 +177,17 @@ struct BandPlanes {
   int lbsh[3][VC2_BP_MAX], lbsw[3][VC2_BP_MAX]; // log2 of a slice's block in it
 };
 
+// Record heads: the coefficients of the DEEP levels (those below the streaming kernels: LL and the bands of levels >= Ls) are
+// the first head_n[c] coefficients of every component record -- 8 to 64 bytes per component at slice-record distance, and
+// the tile kernels of those levels fetched (wrote) a whole 128-byte line for each (3.6 - 7 x their bytes, rocprofv3
+// FETCH_SIZE).  With a head split they live in one dense array per component instead: [slice][coefficient]; inside a
+// slice the order is that of the record, so the deep levels see a coefficient store with rec_stride[c] = n[c] and
+// coef_off[c] = base[c].
+struct HeadSplit {
+  int n[3];            // coefficients of a component record that live in the head (0: no split); multiples of 8
+  long long base[3];   // element offset, from the picture's store, of the component's head array: [slice][n[c]]
+};
+
 struct UnpackParams {
   const uint8_t *payload;
   long long payload_stride;
@@ -190,6 +203,7 @@ struct UnpackParams {
   int prefix, scalar;
   unsigned *err;
   BandPlanes bp;
+  HeadSplit hs;
   int xs;                     // slices across
 };
 

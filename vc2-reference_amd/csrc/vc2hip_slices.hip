@@ -451,6 +451,14 @@ __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, in
 // GIMG: the slice images live in the slots in global memory instead of LDS (slices too long for LDS: slice size scalars
 // beyond ~160; VBR and CBR then both go through slots + compaction) -- the same code on flat atomics, an order slower, for
 // command lines the reference accepts and nobody uses.
+#ifdef VC2HIP_STAMPS
+#include <stdio.h>
+#include <vector>
+__device__ unsigned long long *g_pack_stamps;
+#define PACK_STAMP(k) do { if (threadIdx.x == 0 && g_pack_stamps && blockIdx.y == 0) g_pack_stamps[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define PACK_STAMP(k)
+#endif
 template <int W, bool MID, class ST, bool GIMG = false>
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   constexpr int S = 64 / W;
@@ -458,6 +466,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   extern __shared__ unsigned lds_u[];
   __shared__ unsigned long long s_base; // byte offset of this tile inside the picture payload
   __shared__ int s_tile, s_tot[4];
+  PACK_STAMP(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg = lane / W, sl = lane % W; // slice of the wavefront, lane inside the slice
   const int pic = blockIdx.y;
@@ -500,6 +509,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     }
   }
   __syncthreads();
+  PACK_STAMP(1);
 
   int bytes[3] = {0, 0, 0};
   int q = 0;
@@ -537,6 +547,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
         base += 1 + bytes[0];
       }
+      PACK_STAMP(2);
       { // both chroma components in one round: the lower half of the lanes U, the upper half V
         const int n = p.comp_n[1], n0 = p.comp_n0[1];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
@@ -614,7 +625,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   }
   const int total = active ? p.prefix + 4 + bytes[0] + bytes[1] + bytes[2] : 0;
   if (p.lookback && lane == 0) s_tot[wave] = total;
+  PACK_STAMP(3);
   __syncthreads();
+  PACK_STAMP(4);
   if (p.lookback) {
     // decoupled look-back: publish this tile's byte count, add up the predecessors' counts until one
     // of them carries an inclusive prefix, publish ours.  One 8-byte agent-scope word per tile holds
@@ -691,6 +704,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     if (sl == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
     for (int i = sl; i < (total + 3) / 4; i += W) dst[i] = __builtin_bswap32(img[i]);
   }
+  PACK_STAMP(5);
 }
 
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
@@ -752,6 +766,16 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
     vc2_allow_lds((const void *)k_hq_pack<WW, MM, TT>, 144 * 1024);                                   \
     VC2_LAUNCH(L, (k_hq_pack<WW, MM, TT>), dim3(tiles, n_pictures), dim3(256), lds, s, p);            \
   } while (0)
+#ifdef VC2HIP_STAMPS
+  const char *stamp_file = getenv("VC2HIP_PACK_STAMPS_FILE");
+  const size_t stamp_n = (size_t)tiles * 8;
+  unsigned long long *d_st = nullptr;
+  if (stamp_file) {
+    (void)hipMalloc((void **)&d_st, stamp_n * 8);
+    (void)hipMemsetAsync(d_st, 0, stamp_n * 8, s);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pack_stamps), &d_st, sizeof d_st, 0, hipMemcpyHostToDevice, s);
+  }
+#endif
   if (p.store16) {
     if (W == 16) VC2_PACK_LAUNCH(16, false, int16_t);
     else if (W == 32) VC2_PACK_LAUNCH(32, false, int16_t);
@@ -764,6 +788,17 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
     else VC2_PACK_LAUNCH(64, false, int32_t);
   }
 #undef VC2_PACK_LAUNCH
+#ifdef VC2HIP_STAMPS
+  if (stamp_file) {
+    std::vector<unsigned long long> h(stamp_n);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), d_st, stamp_n * 8, hipMemcpyDeviceToHost);
+    unsigned long long *none = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pack_stamps), &none, sizeof none);
+    (void)hipFree(d_st);
+    if (FILE *fp = fopen(stamp_file, "wb")) { fwrite(h.data(), 8, stamp_n, fp); fclose(fp); }
+  }
+#endif
   vc2_prof_end(L, s);
 }
 
@@ -1678,6 +1713,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
     int lw, ow;
     const int at = p.bp.levels ? band_plane_at(p.bp, comp, n, j, sy, sx, lw, ow) : -1;
     if (at >= 0) p.store_wide[(size_t)pic * p.store_stride + (size_t)at] = v;
+    else if (j < p.hs.n[comp]) p.store_wide[(size_t)pic * p.store_stride + (size_t)p.hs.base[comp] + (size_t)(active ? slice : 0) * p.hs.n[comp] + j] = v;
     else wide[j] = v;
   };
   Reader32 br;
@@ -1772,6 +1808,8 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
           const int4 v = *(const int4 *)(sw + r * UNP_PITCH + c);
           const v4i vv = {v.x, v.y, v.z, v.w};
           int16_t *dst = (int16_t *)p.store + rec0 + (size_t)(slice0 + r) * p.slice_coefs + base + c;
+          if (base + c < p.hs.n[comp]) // a piece of the record's head (HeadSplit: the deep levels' coefficients of all slices side by side)
+            dst = (int16_t *)p.store + (size_t)pic * p.store_stride + (size_t)p.hs.base[comp] + (size_t)(slice0 + r) * p.hs.n[comp] + base + c;
           __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
         }
       }
