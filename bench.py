@@ -387,8 +387,18 @@ def main():
                 continue
             if pmc.get("pictures_per_launch") == per_launch and dom in pmc.get("kernels", {}):
                 traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-                # the whole path: every kernel of a step (launches per step x bytes per launch), as counted and with the guide's 2 x FETCH_SIZE
-                path_traffic = pmc.get("path_bytes_per_step")
+                # the whole path: every kernel of a step -- its launches per step (this run's own count) x its bytes per launch
+                # (the PMC file), as counted (FETCH_SIZE + WRITE_SIZE) and with the guide's 2 x FETCH_SIZE
+                path_traffic = {"as_counted": 0, "fetch_x2": 0}
+                for k, v in warm.items():
+                    n_k = v[0] / w_steps * launches_per_step   # launches of kernel k per step
+                    rows = [r for name, r in pmc["kernels"].items() if name == k or name.startswith(k + "(")]
+                    if not rows:
+                        path_traffic = None
+                        break
+                    # (a name with several instantiations per pass, e.g. the levels below the first: the file holds their average)
+                    path_traffic["as_counted"] += int(n_k * sum((r["FETCH_SIZE_KiB"] + r["WRITE_SIZE_KiB"]) * 1024 for r in rows) / len(rows))
+                    path_traffic["fetch_x2"] += int(n_k * sum(r["hbm_bytes_per_launch"] for r in rows) / len(rows))
                 traffic_note = f"committed profile {os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench), not collected by this run"
                 break
         out = {

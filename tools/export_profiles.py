@@ -52,7 +52,7 @@ def main(tag):
             out.setdefault(sn, {})[name + '_KiB'] = tot / cnt
             out[sn]['launches_sampled'] = cnt
     res = {"_comment": "rocprofv3 PMC, two separate passes (--kernel-trace --pmc FETCH_SIZE ; --kernel-trace --pmc WRITE_SIZE) of "
-                       "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (batch 16 UHD cfg-2 pictures per launch), averages "
+                       "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs` (32 UHD cfg-2 pictures per step on two streams: 16 per launch), averages "
                        "per launch. FETCH_SIZE/WRITE_SIZE are in KiB. hbm_bytes_per_launch applies the gfx950 correction of "
                        "MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads): 2*FETCH + WRITE -- an upper bound for "
                        "kernels whose reads are narrower than 16 bytes per lane. Names with several launches per step (dwt_level, "

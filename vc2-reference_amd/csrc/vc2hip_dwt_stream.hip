@@ -1036,7 +1036,7 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
   // work, long ones leave the chip without wavefronts, and a launch whose wavefronts do not fill whole rounds of the
   // chip's wavefront slots idles through its last round (round 2: 8704 equal wavefronts for 4096 slots).  So: the nseg
   // that minimises rounds * (rows of the tallest segment + run-in), rounds = ceil(strips * nseg / slots).
-  static const int force_nseg = [] { const char *e = getenv("VC2HIP_STREAM_NSEG"); return e ? atoi(e) : 0; }();
+  static const int force_nseg = vc2_tune_int("VC2HIP_STREAM_NSEG", 0);
   int cols = 0, bsh_max = 1;
   for (int c = 0; c < 3; ++c) if (p.st_strips[c]) { cols += p.st_strips[c] * n_pictures; bsh_max = std::max(bsh_max, p.fh[c] / 2); }
   const int slots = stream_slots(kernel, edge, inverse, store16, p.st_tail != 0, lds);
@@ -1055,7 +1055,7 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
   for (int c = 0; c < 3; ++c) if (p.st_strips[c]) p.st_segs[c] = nseg;
   p.st_segmax = nseg;
   p.st_npic = n_pictures;
-  static const int prio = [] { const char *e = getenv("VC2HIP_STREAM_PRIO"); return e ? atoi(e) : 2; }();
+  static const int prio = vc2_tune_int("VC2HIP_STREAM_PRIO", 2);
   p.st_prio = prio; // a new turn at the highest priority every four row pairs (measured: 2, 3 and 4 alike; off: inverse level 0 9 % slower)
   return lds;
 }

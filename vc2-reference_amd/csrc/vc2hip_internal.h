@@ -123,6 +123,15 @@ struct LevelParams {
   long long bp_base[3];
 };
 
+// Tuning knobs (lanes per slice, wavefronts per workgroup, segments per strip ...) are compile-time decisions of the
+// release library; the environment can override them only in the -DVC2HIP_ABLATE build (A/B measurements on one box).
+#include <stdlib.h>
+#ifdef VC2HIP_ABLATE
+static inline int vc2_tune_int(const char *name, int def) { const char *e = getenv(name); return e ? atoi(e) : def; }
+#else
+static inline int vc2_tune_int(const char *, int def) { return def; }
+#endif
+
 // Work-skipping switches for the timing experiments of tools/ablate_*.py exist only in a library built with
 // -DVC2HIP_ABLATE (the tools build their own); the release kernels carry no such test.
 #ifdef VC2HIP_ABLATE

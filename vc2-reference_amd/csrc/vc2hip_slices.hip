@@ -439,6 +439,27 @@ __device__ __forceinline__ void write8(unsigned *img, int pos, int limit, const 
   }
   if (acc) atomicOr(&img[wi], (unsigned)(acc >> 32));
 }
+// The same for a wavefront none of whose lanes has more than 64 bits of codes (what quantised pictures look like: 36 bits per
+// eight coefficients at the bench's index): the lane's eight codes become ONE string in a register pair -- a shift and an
+// OR per code, no test per code whether a word is full -- which is cut at the limit (what lies beyond it are the '1's of
+// trailing zeros) and OR-ed into the three words it can touch.  write8 above remains for every other wavefront.
+__device__ __forceinline__ void write8_short(unsigned *img, int pos, int limit, const Coef8 &c) {
+  unsigned long long acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc = (acc << c.nb[k]) | (c.nb[k] ? c.code[k] : 0u);
+  int n = c.sum;
+  if (pos + n > limit) { const int keep = max(limit - pos, 0); acc >>= (n - keep); n = keep; }
+  if (n <= 0) return;
+  const int wi = pos >> 5, bo = pos & 31;
+  const unsigned long long v = acc << (64 - n); // left aligned
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned w0 = hi >> bo;
+  const unsigned w1 = bo ? (hi << (32 - bo)) | (lo >> bo) : lo;
+  const unsigned w2 = bo ? lo << (32 - bo) : 0u;
+  if (w0) atomicOr(&img[wi], w0);
+  if (w1) atomicOr(&img[wi + 1], w1);
+  if (w2) atomicOr(&img[wi + 2], w2);
+}
 __device__ __forceinline__ void put_byte(unsigned *img, int off, unsigned b) { atomicOr(&img[off >> 2], b << (24 - 8 * (off & 3))); }
 
 
@@ -543,7 +564,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int incl = seg_incl_scan<W>(c.sum, sl);
         const int count = seg_max<W>(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
-        write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, VC2_SKIP(p, 1));
+        if (!__any(c.sum > 64)) { if (!VC2_SKIP(p, 1)) write8_short(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c); }
+        else write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, VC2_SKIP(p, 1));
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
         base += 1 + bytes[0];
       }
@@ -561,7 +583,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         bytes[1] = comp_len(__shfl(cnt, seg * W));
         bytes[2] = cbr_v(comp_len(__shfl(cnt, seg * W + W / 2)));
         const int base_c = half ? base + 1 + bytes[1] : base;
-        write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, VC2_SKIP(p, 1));
+        if (!__any(c.sum > 64)) { if (!VC2_SKIP(p, 1)) write8_short(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c); }
+        else write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, VC2_SKIP(p, 1));
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
         if (sl == W / 2) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
       }
@@ -731,7 +754,7 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
   // lanes per slice: as few as still hold the slice (8 luma / 4 chroma coefficients and one subband constant per lane)
   int W = 64;
   const bool same_c = p.comp_n[1] == p.comp_n[2];
-  static const int force_w = [] { const char *e = getenv("VC2HIP_PACK_LANES"); return e ? atoi(e) : 0; }();
+  static const int force_w = vc2_tune_int("VC2HIP_PACK_LANES", 0);
   if (!p.lookback && same_c && force_w != 64) {
     const int bands = 3 * p.depth + 1;
     if (p.comp_n[0] <= 128 && p.comp_n[1] <= 64 && bands <= 16 && pack_lds(p.prefix, p.scalar, 4) <= 144 * 1024) W = 16;
@@ -865,7 +888,7 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
                         int n_slices, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "slice_compact", s);
   // lanes per slice from the slot size (an upper bound of the slice size; typical slices are far shorter)
-  static const int force = [] { const char *e = getenv("VC2HIP_COMPACT_LANES"); return e ? atoi(e) : 0; }();
+  static const int force = vc2_tune_int("VC2HIP_COMPACT_LANES", 0);
   const int W = force ? force : (slot_bytes <= 800 ? 16 : (slot_bytes <= 1600 ? 32 : 64));
   const int per_wg = 256 / W;
   const dim3 grid((n_slices + per_wg - 1) / per_wg, n_pictures);
@@ -1880,8 +1903,8 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipS
   }
   // A/B on MI355X, 16 UHD pictures: whole 128-byte lines (32 coefficients per round) 0.48 ms, 64-byte runs 0.52 ms (the other
   // half of every line is fetched back: FETCH_SIZE ~1 GB for 0.15 GB of payload), plain instead of non-temporal stores 0.69 ms
-  static const int wide = [] { const char *e = getenv("VC2HIP_UNPACK_WIDE"); return e ? atoi(e) : 1; }();
-  static const int nt = [] { const char *e = getenv("VC2HIP_UNPACK_NT"); return e ? atoi(e) : 1; }();
+  static const int wide = vc2_tune_int("VC2HIP_UNPACK_WIDE", 1);
+  static const int nt = vc2_tune_int("VC2HIP_UNPACK_NT", 1);
   if (!nt) VC2_LAUNCH(L, (k_hq_unpack<16, false>), dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   else if (wide) VC2_LAUNCH(L, k_hq_unpack<32>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
   else VC2_LAUNCH(L, k_hq_unpack<16>, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
@@ -2260,7 +2283,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   vc2_prof_begin(L, "slice_index_tables", s);
   {
     // merged walks (see the kernel): entry regions of up to 4096 bytes whose landing region lies inside the chunk
-    static const bool no_merge = [] { const char *e = getenv("VC2HIP_IDX_NO_MERGE"); return e && e[0] == '1'; }();
+    static const bool no_merge = vc2_tune_int("VC2HIP_IDX_NO_MERGE", 0) != 0;
     const int merge = !no_merge && E <= 4096 && 2 * E <= ch;
     const size_t lds = stage_bytes + (size_t)ch * 2 + (merge ? (size_t)E * 6 + ((size_t)(E + 31) / 32) * 4 + 16 : 0);
 #define VC2_IDX_TABLES(CH)                                                                                                    \
@@ -2280,7 +2303,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   vc2_prof_begin(L, "slice_index_chain", s);
   {
     // (exit offsets are below E and fit 16 bits up to IDX_MAX_E; the dedupe tables need 14 bytes of LDS per entry)
-    static const bool no_dedupe = [] { const char *e = getenv("VC2HIP_IDX_NO_DEDUPE"); return e && e[0] == '1'; }();
+    static const bool no_dedupe = vc2_tune_int("VC2HIP_IDX_NO_DEDUPE", 0) != 0;
     const int dedupe = !no_dedupe && E <= 8192;
     const size_t glds = dedupe ? ((size_t)((E + 1) & ~1) * 4 + (size_t)E * 8 + (size_t)E * 2 + 16) : 0;
     if (glds) vc2_allow_lds((const void *)k_index_group, glds);
@@ -3189,7 +3212,7 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
 #endif
     if (rows && p.search && !vc2_ld_rows_disabled()) {
       // 3 wavefronts (LL chains + 2 x subbands) measured fastest: 3.2 ms per 16 HD pictures, 4 wavefronts 3.6, one launch per anti-diagonal 3.7-3.9
-      static const int nwr = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : v > 4 ? 4 : v; }();
+      static const int nwr = std::min(4, std::max(2, vc2_tune_int("VC2HIP_LD_WAVES", 3)));
       (void)hipMemsetAsync(p.qidx, 0xFF, (size_t)n_pictures * p.n_slices * sizeof(int32_t), s); // progress flags: -1 = not final
       const dim3 grid(p.ys * ((n_pictures + 7) & ~7)), blk(64 * nwr);
       if (small && dual) VC2_LAUNCH(L, (k_ld_search_rows<4, true>), grid, blk, lds, s, p, n_pictures, rs_pad);
@@ -3202,7 +3225,7 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     for (int d = 0; d < p.ys + p.xs - 1; ++d) {
       const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
       const dim3 grid(cnt, n_pictures);
-      static const int nwv = [] { const char *e = getenv("VC2HIP_LD_WAVES"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > 4 ? 4 : v; }();
+      static const int nwv = std::min(4, std::max(2, vc2_tune_int("VC2HIP_LD_WAVES", 4)));
       const dim3 blk(64 * nwv);
       if (small && dual) VC2_LAUNCH(L, (k_ld_quantise_diag_fast<4, true>), grid, blk, lds, s, p, d, rs_pad); // 75 registers: forcing 64 for full residency of a 16-picture diagonal spills and measured slower
       else if (small) VC2_LAUNCH(L, (k_ld_quantise_diag_fast<4, false>), grid, blk, lds, s, p, d, rs_pad);
