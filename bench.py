@@ -674,6 +674,48 @@ def run_e2e(torch, vc2hip_py, dev, frames, rb, fmt, cp, stride, lens, B, d_out):
     td = run(decode_chunk, None)
     for h in ctx:
         h.sync()
+    # ---- both directions at once: the link is full duplex (raw pictures go in for the encoder while decoded ones come out).
+    # A second pair of streams / contexts / buffers decodes the chunks coded above while the first pair encodes.
+    streams2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    ctx2 = [vc2hip_py.Vc2Hip(dev.index or 0, stream=s.cuda_stream) for s in streams2]
+    bufs2 = []
+    for i in range(2):
+        b = bufs[i]
+        bufs2.append(dict(d_pay=torch.zeros(CH * stride, dtype=torch.uint8, device=dev), d_len=torch.zeros(CH, dtype=torch.int64, device=dev),
+                          d_out=torch.empty(CH * rb, dtype=torch.uint8, device=dev), h_len=b["h_len"].clone().pin_memory(),
+                          h_pay=b["h_pay"].clone().pin_memory(), h_out=torch.empty(CH * rb, dtype=torch.uint8).pin_memory()))
+
+    def decode_chunk2(i):
+        b, s, h = bufs2[i], streams2[i], ctx2[i]
+        with torch.cuda.stream(s):
+            for j in range(CH):
+                n = int(b["h_len"][j])
+                b["d_pay"][j * stride:j * stride + n].copy_(b["h_pay"][j * span:j * span + n], non_blocking=True)
+            b["d_len"].copy_(b["h_len"], non_blocking=True)
+            h.decode_batch_dev(b["d_pay"].data_ptr(), stride, b["d_len"].data_ptr(), CH, fmt, cp, b["d_out"].data_ptr())
+            b["h_out"].copy_(b["d_out"], non_blocking=True)
+
+    def run_both():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in range(NCH):
+            i = c & 1
+            if c >= 2:
+                streams2[i].synchronize()
+            encode_chunk(i, c)
+            decode_chunk2(i)
+            if c >= 1:
+                encode_finish(1 - i)
+        encode_finish((NCH - 1) & 1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run_both()
+    tb = run_both()
+    for h in ctx + ctx2:
+        h.sync()
+    both_ok = all(torch.equal(bufs2[i]["h_out"], bufs[i]["h_out"]) for i in range(2))   # the same chunks decode to the same pictures
+    if not both_ok:
+        raise SystemExit("end-to-end pipeline: concurrent decode returned other pictures")
     for i in range(2):   # what came back on each stream is the decode of the chunk it encoded last
         k0 = ((NCH - 2 + i) % nchunks_batch) * CH
         if not torch.equal(bufs[i]["h_out"], d_out[k0 * rb:(k0 + CH) * rb].cpu()):
@@ -682,6 +724,8 @@ def run_e2e(torch, vc2hip_py, dev, frames, rb, fmt, cp, stride, lens, B, d_out):
     return {"encode": {"value": round(px / te / 1e6, 1), "unit": "Mpixels/s"},
             "decode": {"value": round(px / td / 1e6, 1), "unit": "Mpixels/s"},
             "encode+decode": {"value": round(px / (te + td) / 1e6, 1), "unit": "Mpixels/s"},
+            "encode||decode": {"value": round(px / tb / 1e6, 1), "unit": "Mpixels/s (pictures encoded AND as many decoded in that time, both directions of the link at once)",
+                               "host_link_GBs_each_way": round((rb + maxlen) * CH * NCH / tb / 1e9, 1)},
             "host_link_GBs": {"encode_in": round(rb * CH * NCH / te / 1e9, 1), "decode_out": round(rb * CH * NCH / td / 1e9, 1)},
             "method": f"pinned host buffers, 2 HIP streams x chunks of {CH} pictures, H2D / kernels / D2H of consecutive chunks overlapped; "
                       f"{CH * NCH} pictures per direction; bound by the PCIe Gen5 x16 link (33.2 MB in + ~9.4 MB out per picture)"}

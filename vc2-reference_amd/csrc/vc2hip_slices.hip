@@ -721,7 +721,18 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   } else if (p.cbr_bytes) {
     if (bad_cbr) return;
     uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
-    for (int i = sl; i < total; i += W) dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3)));
+    // dword stores for the 4-byte aligned middle of the destination (the budgets put a slice at any byte), byte stores for
+    // its ragged head and tail (byte stores for all of it: cfg 3's pack 0.43 ms against 0.385 ms in VBR mode)
+    const int head = min((int)((4 - ((size_t)dst & 3)) & 3), total);
+    const int nw = (total - head) >> 2, tail0 = head + 4 * nw;
+    if (sl < head) dst[sl] = (uint8_t)(img[sl >> 2] >> (24 - 8 * (sl & 3)));
+    if (sl < total - tail0) { const int i = tail0 + sl; dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3))); }
+    unsigned *d4 = (unsigned *)(dst + head);
+    for (int w = sl; w < nw; w += W) {
+      const int i0 = head + 4 * w;
+      const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
+      d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
+    }
   } else {
     unsigned *dst = (unsigned *)(p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes);
     if (sl == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
