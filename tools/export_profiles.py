@@ -32,6 +32,9 @@ def main(tag):
     shutil.copy(f'{d}/stats/run_kernel_stats.csv', f'profiles/{tag}_rocprofv3_kernel_stats.csv')
     if os.path.exists(f'{d}/bench_under_rocprof.json'):
         shutil.copy(f'{d}/bench_under_rocprof.json', f'profiles/{tag}_bench_under_rocprof.json')
+    if os.path.exists(f'{d}/stats1/run_kernel_stats.csv'):   # the one-stream run: every kernel alone on the GPU
+        shutil.copy(f'{d}/stats1/run_kernel_stats.csv', f'profiles/{tag}_rocprofv3_kernel_stats_one_stream.csv')
+        shutil.copy(f'{d}/bench_under_rocprof_one_stream.json', f'profiles/{tag}_bench_under_rocprof_one_stream.json')
     with open(f'profiles/{tag}_pmc_instruction_mix.txt', 'w') as f:
         f.write('# rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/prof_kernels.sh); '
                 'SQ_WAVE_CYCLES and the WAIT / ACTIVE counters are in 4-cycle units\n')

@@ -2070,29 +2070,40 @@ __global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8
   }
 }
 
-// The chain through the chunk functions is followed in two levels so that only n_chunks / IDX_GROUP +
-// IDX_GROUP dependent table reads are serial instead of n_chunks:
-//   group  : compose the functions of IDX_GROUP consecutive chunks, for every entry offset (parallel)
-//   chain  : per picture, follow entry -> exit through the group functions, then expand every group
+// The chain through the chunk functions is followed in three levels so that only n_chunks / IDX_GROUP^2 + 2 IDX_GROUP
+// dependent table reads are serial instead of n_chunks (each one a trip to L2 or beyond, ~0.8 us: a UHD-2 picture of 2400
+// chunks took 0.16 ms with two levels):
+//   group  : compose the functions of IDX_GROUP consecutive chunks, for every entry offset (parallel); then the functions
+//            of IDX_GROUP consecutive groups the same way (super-groups)
+//   chain  : per picture, follow entry -> exit through the super-groups, expand every super-group into its groups and
+//            every group into its chunks
 static constexpr int IDX_GROUP = 16;
 
-__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const unsigned *tables,
-                                                     uint2 *groups, int n_chunks, int n_groups, int E, int IDX_CH, const unsigned *skip,
+// an entry of a function table: (exit offset, slices).  WORD: the chunk tables' packed form exit << 16 | slices
+template <bool WORD> __device__ __forceinline__ uint2 idx_entry(const void *tab, size_t i) {
+  if constexpr (WORD) { const unsigned t = ((const unsigned *)tab)[i]; return make_uint2(t >> 16, t & 0xFFFFu); }
+  else return ((const uint2 *)tab)[i];
+}
+
+// out[g] = in[16 g + 15] o ... o in[16 g]; `span` = payload bytes one input function covers
+template <bool WORD>
+__global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const void *tables,
+                                                     uint2 *groups, int n_chunks, int n_groups, int E, long long span, const unsigned *skip,
                                                      int dedupe) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(8))) unsigned lds_g[];
   const int g = blockIdx.x, pic = blockIdx.y;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
-  if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) return;
+  if ((unsigned long long)g * IDX_GROUP * (unsigned long long)span >= plen) return;
   if (!dedupe) {
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
       unsigned x = (unsigned)e, cnt = 0;
       for (int k = 0; k < IDX_GROUP; ++k) {
         const int c = g * IDX_GROUP + k;
-        if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
-        const unsigned t = tables[((size_t)pic * n_chunks + c) * E + x];
-        x = t >> 16;
-        cnt += t & 0xFFFFu;
+        if (c >= n_chunks || (unsigned long long)c * (unsigned long long)span >= plen) break;
+        const uint2 t = idx_entry<WORD>(tables, ((size_t)pic * n_chunks + c) * E + x);
+        x = t.x;
+        cnt += t.y;
       }
       groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(x, cnt);
     }
@@ -2108,9 +2119,9 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int c0 = g * IDX_GROUP;
-  const unsigned *t0 = tables + ((size_t)pic * n_chunks + c0) * E;
+  const size_t t0 = ((size_t)pic * n_chunks + c0) * E;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    const unsigned x = t0[e] >> 16;
+    const unsigned x = idx_entry<WORD>(tables, t0 + e).x;
     if (atomicExch(&need[x], 1u) == 0u) list[atomicAdd(&s_count, 1u)] = (unsigned short)x;
   }
   __syncthreads();
@@ -2119,41 +2130,67 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
     const unsigned x0 = x;
     for (int k = 1; k < IDX_GROUP; ++k) {
       const int c = c0 + k;
-      if (c >= n_chunks || (unsigned long long)c * IDX_CH >= plen) break;
-      const unsigned t = tables[((size_t)pic * n_chunks + c) * E + x];
-      x = t >> 16;
-      cnt += t & 0xFFFFu;
+      if (c >= n_chunks || (unsigned long long)c * (unsigned long long)span >= plen) break;
+      const uint2 t = idx_entry<WORD>(tables, ((size_t)pic * n_chunks + c) * E + x);
+      x = t.x;
+      cnt += t.y;
     }
     res[x0] = make_uint2(x, cnt);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    const unsigned t = t0[e];
-    const uint2 r = res[t >> 16];
-    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(r.x, (t & 0xFFFFu) + r.y);
+    const uint2 t = idx_entry<WORD>(tables, t0 + e);
+    const uint2 r = res[t.x];
+    groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(r.x, t.y + r.y);
   }
 }
 
 constexpr int IDX_MAX_GROUPS = 1024;
 __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *lens, long long stride, const unsigned *tables,
-                                                    const uint2 *groups, uint2 *entries, int n_chunks,
-                                                    int n_groups, int E, int IDX_CH, const unsigned *skip) {
+                                                    const uint2 *groups, const uint2 *supers, uint2 *entries, int n_chunks,
+                                                    int n_groups, int n_supers, int E, int IDX_CH, const unsigned *skip) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
-  __shared__ uint2 g_entry[IDX_MAX_GROUPS]; // the launcher keeps n_groups within it (larger chunks for larger slots)
+  __shared__ uint2 g_entry[IDX_MAX_GROUPS];              // the launcher keeps n_groups within it (larger chunks for larger slots)
+  __shared__ uint2 s_entry[IDX_MAX_GROUPS / IDX_GROUP];
   const int pic = blockIdx.x;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride);
-  if (threadIdx.x == 0) {
+  const unsigned long long gspan = (unsigned long long)IDX_GROUP * IDX_CH, sspan = gspan * IDX_GROUP;
+  if (n_supers == 0) { // few groups (the launcher's choice): they are followed directly
+    if (threadIdx.x == 0) {
+      unsigned entry = 0, base = 0;
+      for (int g = 0; g < n_groups; ++g) {
+        g_entry[g] = make_uint2(entry, base);
+        if ((unsigned long long)g * gspan >= plen) continue;
+        const uint2 t = groups[((size_t)pic * n_groups + g) * E + entry];
+        entry = t.x;
+        base += t.y;
+      }
+    }
+  } else if (threadIdx.x == 0) { // the only serial part: one read per super-group
     unsigned entry = 0, base = 0;
-    for (int g = 0; g < n_groups; ++g) {
+    for (int sg = 0; sg < n_supers; ++sg) {
+      s_entry[sg] = make_uint2(entry, base);
+      if ((unsigned long long)sg * sspan >= plen) continue;
+      const uint2 t = supers[((size_t)pic * n_supers + sg) * E + entry];
+      entry = t.x;
+      base += t.y;
+    }
+  }
+  __syncthreads();
+  for (int sg = threadIdx.x; sg < n_supers; sg += blockDim.x) { // every super-group into its groups
+    unsigned entry = s_entry[sg].x, base = s_entry[sg].y;
+    for (int k = 0; k < IDX_GROUP; ++k) {
+      const int g = sg * IDX_GROUP + k;
+      if (g >= n_groups) break;
       g_entry[g] = make_uint2(entry, base);
-      if ((unsigned long long)g * IDX_GROUP * IDX_CH >= plen) continue;
+      if ((unsigned long long)g * gspan >= plen) continue;
       const uint2 t = groups[((size_t)pic * n_groups + g) * E + entry];
       entry = t.x;
       base += t.y;
     }
   }
   __syncthreads();
-  for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+  for (int g = threadIdx.x; g < n_groups; g += blockDim.x) { // every group into its chunks
     unsigned entry = g_entry[g].x, base = g_entry[g].y;
     for (int k = 0; k < IDX_GROUP; ++k) {
       const int c = g * IDX_GROUP + k;
@@ -2265,7 +2302,8 @@ size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix,
   const size_t n_chunks = (max_payload + ch - 1) / ch + 1;
   if (n_chunks > (size_t)1024 * 16) return 256; // serial walk (see vc2_launch_slice_index)
   const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
-  return (size_t)n_pictures * (n_chunks * E * sizeof(unsigned) + (n_chunks + n_groups * E) * sizeof(uint2)) + 512;
+  const size_t n_supers = (n_groups + IDX_GROUP - 1) / IDX_GROUP;
+  return (size_t)n_pictures * (n_chunks * E * sizeof(unsigned) + (n_chunks + (n_groups + n_supers) * E) * sizeof(uint2)) + 512;
 }
 
 void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
@@ -2309,19 +2347,23 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
 #undef VC2_IDX_TABLES
   }
   vc2_prof_end(L, s);
-  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry): payload slots up to 128 MiB
+  const int n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP; // <= 1024 (g_entry)
+  // (the third level costs a launch: 5 us; it pays from a few hundred groups on -- UHD-2 pictures: 0.163 -> 0.132 ms)
+  const int n_supers = n_groups > 128 ? (n_groups + IDX_GROUP - 1) / IDX_GROUP : 0;
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
+  uint2 *supers = groups + (size_t)n_pictures * n_groups * E;
   vc2_prof_begin(L, "slice_index_chain", s);
   {
     // (exit offsets are below E and fit 16 bits up to IDX_MAX_E; the dedupe tables need 14 bytes of LDS per entry)
     static const bool no_dedupe = vc2_tune_int("VC2HIP_IDX_NO_DEDUPE", 0) != 0;
     const int dedupe = !no_dedupe && E <= 8192;
     const size_t glds = dedupe ? ((size_t)((E + 1) & ~1) * 4 + (size_t)E * 8 + (size_t)E * 2 + 16) : 0;
-    if (glds) vc2_allow_lds((const void *)k_index_group, glds);
-    VC2_LAUNCH(L, k_index_group, dim3(n_groups, n_pictures), dim3(256), glds, s, lens, payload_stride, tables, groups, n_chunks, n_groups, E, ch, skip, dedupe);
+    if (glds) { vc2_allow_lds((const void *)k_index_group<true>, glds); vc2_allow_lds((const void *)k_index_group<false>, glds); }
+    VC2_LAUNCH(L, k_index_group<true>, dim3(n_groups, n_pictures), dim3(256), glds, s, lens, payload_stride, (const void *)tables, groups, n_chunks, n_groups, E, (long long)ch, skip, dedupe);
+    if (n_supers) VC2_LAUNCH(L, k_index_group<false>, dim3(n_supers, n_pictures), dim3(256), glds, s, lens, payload_stride, (const void *)groups, supers, n_groups, n_supers, E, (long long)ch * IDX_GROUP, skip, dedupe);
   }
-  // (one lane follows the groups of a picture; then a thread per group expands it: sixteen dependent reads, all groups at once)
-  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(std::min(1024, (n_groups + 63) / 64 * 64)), 0, s, lens, payload_stride, tables, groups, entries, n_chunks, n_groups, E, ch, skip);
+  // (one lane follows the super-groups of a picture; then a thread per super-group / group expands it: sixteen dependent reads each, all at once)
+  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(std::min(1024, (n_groups + 63) / 64 * 64)), 0, s, lens, payload_stride, tables, groups, supers, entries, n_chunks, n_groups, n_supers, E, ch, skip);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
   VC2_LAUNCH(L, k_index_emit, dim3((n_chunks + 63) / 64, n_pictures), dim3(64), 0, s, payload,
