@@ -315,3 +315,42 @@ def test_streaming_levels_with_odd_pair_counts_and_narrow_planes(variants, oracl
     _check(variants, oracle, raw, w, h, "444", 10, kernel, depth, 1, 8, q=9, scalar=8)
     raw = synth(w, h, "444", 10, 92)
     _check(variants, oracle, raw, w, h, "444", 10, kernel, depth, 1, 8, q=0, scalar=8)
+
+
+def test_ld_decode_of_slices_beyond_any_lds_tile(hip, oracle):
+    """LD pictures whose slices do not fit an LDS tile of the level kernels (the reference's only limit is sliceSizeIsValid,
+    WaveletTransform.cpp:116-136): the decoder takes the whole-plane transform that HQ pictures of such slices take, with the
+    DC-predicted LL reconstruction put into the plane's LL band.  512 x 512 4:4:4, four slices of 256 x 256."""
+    from test_gpu_parity import _fmt_cp
+    w, h, depth, nbytes = 512, 512, 2, 90000
+    raw = synth(w, h, "444", 8, 321, word_bytes=1)
+    p = make_params(w, h, "444", 8, "LeGall", depth, 64, 64, mode="LD", s=nbytes, word_bytes=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, n = oracle.decode_stream(p, stream, 1)
+    assert n == 1
+    fmt, cp = _fmt_cp(hip, w, h, "444", 8, "LeGall", depth, 64, 64, mode="LD", s=nbytes, word_bytes=1)
+    assert cp.y_slices == 2 and cp.x_slices == 2
+    payload = stream[-13 - nbytes:-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+def test_ld_encode_of_slices_beyond_lds(hip, oracle):
+    """... and the LD encoder for such slices: the index search and the DC-predicted quantiser read the coefficients from
+    the store (k_ld_quantise_diag<GLOBAL>), the transform runs on whole planes.  Payload against the oracle's stream."""
+    from test_gpu_parity import _fmt_cp
+    w, h, depth, nbytes = 512, 512, 2, 90000
+    raw = synth(w, h, "444", 8, 322, word_bytes=1)
+    p = make_params(w, h, "444", 8, "LeGall", depth, 64, 64, mode="LD", s=nbytes, word_bytes=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "444", 8, "LeGall", depth, 64, 64, mode="LD", s=nbytes, word_bytes=1)
+    got, qidx = hip.encode_picture_hq(raw, fmt, cp)
+    assert got == stream[-13 - nbytes:-13]
+    # a slice size between the LDS tile of the level kernels and the LD coder's LDS budget: 128 x 256 (98 K coefficients)
+    w, h, nbytes = 512, 256, 50000
+    raw = synth(w, h, "444", 10, 323)
+    p = make_params(w, h, "444", 10, "DD97", 2, 32, 64, mode="LD", s=nbytes)
+    stream = oracle.encode_stream(p, raw, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "444", 10, "DD97", 2, 32, 64, mode="LD", s=nbytes)
+    got, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert got == stream[-13 - nbytes:-13]
+    assert hip.decode_picture(got, fmt, cp) == oracle.decode_stream(p, stream, 1)[0]

@@ -36,6 +36,8 @@ void vc2_launch_plane_ingest(Launcher &L, const void *raw, long long raw_stride,
                              int32_t *plane, long long plane_stride, int ph, int pw, int n, hipStream_t s);
 void vc2_launch_plane_emit(Launcher &L, const int32_t *plane, long long plane_stride, int pw, void *raw, long long raw_stride, int pic_h,
                            int pic_w, int word_bytes, int bit_depth, int n, hipStream_t s);
+void vc2_launch_ll_into_plane(Launcher &L, const int32_t *ll, long long ll_stride, int llh, int llw, int32_t *plane, long long plane_stride,
+                              int pw, int depth, int n, hipStream_t s);
 void vc2_launch_fill_i32(Launcher &L, int32_t *p, int32_t v, size_t n, hipStream_t s);
 void vc2_launch_fill_u64(Launcher &L, unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 
@@ -131,6 +133,7 @@ struct vc2hip_ctx {
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
   bool allow_planes = true; // decode: band planes for the streaming levels (A/B and test switch VC2HIP_NO_BANDPLANES)
+  int ld_batch = 1;         // pictures of the LD batch being encoded (fill_ld_enc sizes the scratch array with it)
   bool allow_heads = true;  // record heads for the levels below them (A/B and test switch VC2HIP_NO_HEADS)
   bool allow_cbr_index = true; // decode of HQ_CBR pictures: offsets from the budgets, verified (VC2HIP_NO_CBR_INDEX=1: always the general index)
   bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
@@ -826,8 +829,9 @@ static int plane_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const 
   return VC2HIP_OK;
 }
 // store (quantised) -> raw pictures (inverse), general geometry
+// ll (LD pictures): the DC-predicted LL reconstruction of every component, which replaces the plane's LL band
 static int plane_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, const int32_t *d_store, const int32_t *d_q, const int32_t *qm,
-                         void *const dst[3], const long long ds[3], const vc2hip_picture_format *f) {
+                         void *const dst[3], const long long ds[3], const vc2hip_picture_format *f, const LLPlanes *ll = nullptr) {
   int32_t *d_plane;
   int *d_qm;
   NEED(c, B_PLANE, plane_elems(g) * n * 4, d_plane);
@@ -845,6 +849,8 @@ static int plane_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, const 
     for (int p = 0; p < n; ++p)
       vc2_launch_store_to_plane(c->L, d_store + (size_t)p * ns * g.slice_coefs, g.slice_coefs, cg.coef_off, pl + (size_t)p * ps, cg.ph,
                                 cg.pw, g.depth, g.ys, g.xs, d_q + (size_t)p * ns, d_qm, 1, c->d_err, c->stream);
+    if (ll) vc2_launch_ll_into_plane(c->L, (const int32_t *)ll->p[g.depth][k], ll->stride[g.depth][k], cg.ph >> g.depth, cg.pw >> g.depth, pl, ps,
+                                     cg.pw, g.depth, n, c->stream);
     const int rc = vc2_launch_plane_transform(c->L, kernel, pl, ps, cg.ph, cg.pw, g.depth, true, n, c->stream);
     if (rc) return set_err(c, rc, "invalid wavelet kernel");
     vc2_launch_plane_emit(c->L, pl, ps, cg.pw, dst[k], ds[k], cg.h, cg.w, f->word_bytes, f->bit_depth, n, c->stream);
@@ -1271,8 +1277,13 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
   p.img_words = (max_slice + 3) / 4 + 2;
   p.payload = d_pay; p.payload_stride = stride; p.err = c->d_err;
   p.tab = (int *)((char *)c->d_err + 256);
-  if ((size_t)g.slice_coefs * 8 + 512 + (size_t)p.rs_ints * 4 > 160 * 1024 || (size_t)p.img_words * 4 > 160 * 1024)
+  // what has to fit in LDS whatever the slice's size: the LL blocks with their halo (search) and one slice's bytes (writer)
+  if (512 + (size_t)p.rs_ints * 4 > 160 * 1024 || (size_t)p.img_words * 4 > 160 * 1024)
     return set_err(c, VC2HIP_EINVAL, "slice too large for the LD encode kernels");
+  if ((size_t)g.slice_coefs * 8 + 512 + (size_t)p.rs_ints * 4 > 160 * 1024) { // the coefficients do not: the search reads the store, its trials write a scratch array
+    NEED(c, B_PLANE2, (size_t)((p.store_stride ? p.store_stride : 1)) * 4 * (size_t)std::max(1, c->ld_batch), p.scratch);
+  }
+  c->ld_batch = 1;
   return VC2HIP_OK;
 }
 
@@ -1419,7 +1430,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
   ll_layout(g, n, d_ll, s16 ? 2 : 4, d_llw, ll);
   const void *src[3]; long long ss[3];
   raw_planes(f, d_raw, src, ss);
-  if (cp->mode != VC2HIP_LD && needs_plane_path(c, g, cp->kernel)) {
+  if (needs_plane_path(c, g, cp->kernel)) { // (a slice beyond any LDS tile: HQ and LD alike -- the store is int32 then)
     if ((rc = plane_forward(c, g, cp->kernel, n, src, ss, f, d_store))) return rc;
   } else if ((rc = run_forward(c, g, cp->kernel, n, src, ss, true, f, d_store, ll, s16, d_storew))) return rc;
   int32_t *d_cb = nullptr; uint32_t *d_co = nullptr; uint64_t total = 0;
@@ -1436,6 +1447,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     d_cb = (int32_t *)c->buf[B_CBRB].p; d_co = (uint32_t *)c->buf[B_CBRO].p; total = c->cbr_total;
     if (total > payload_stride) return set_err(c, VC2HIP_ECAP);
     LdEncParams p;
+    c->ld_batch = n;
     if ((rc = fill_ld_enc(c, p, g, d_store, d_q, qm, ll, d_cb, d_co, cp->compressed_bytes / ns + 5, (uint8_t *)d_payload,
                           (long long)payload_stride))) return rc;
     p.search = 1;
@@ -1491,7 +1503,7 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
   const void *dstc[3]; long long ds[3];
   raw_planes(f, d_raw_out, dstc, ds);
   void *dst[3] = {(void *)dstc[0], (void *)dstc[1], (void *)dstc[2]};
-  const bool plane_path = !ld && needs_plane_path(c, g, cp->kernel);
+  const bool plane_path = needs_plane_path(c, g, cp->kernel);
   // Band planes (vc2hip_internal.h): the finest levels, as long as they go through the streaming inverse kernel, a
   // slice's block row in them is at least 4 coefficients (8: rows that keep 16-byte pieces aligned) and they are not
   // the level whose LL comes from the store.  16-bit store only (the int32 store is the fallback decoder's).
@@ -1627,7 +1639,7 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
                        g.c[k].ph >> g.depth, g.c[k].pw >> g.depth, g.ys, g.xs, d_q, qm[0], (int32_t *)ll.p[g.depth][k],
                        ll.stride[g.depth][k], n, c->d_err, c->stream);
   }
-  if (plane_path) return plane_inverse(c, g, cp->kernel, n, d_store, d_q, qm, dst, ds, f);
+  if (plane_path) return plane_inverse(c, g, cp->kernel, n, d_store, d_q, qm, dst, ds, f, ld ? &ll : nullptr);
   return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew, &bp, sstride, nullptr,
                      hs.n[0] ? &hs : nullptr, head_level);
 }

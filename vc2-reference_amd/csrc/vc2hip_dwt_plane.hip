@@ -116,6 +116,20 @@ int vc2_launch_plane_transform(Launcher &L, int kernel, int32_t *plane, long lon
   vc2_prof_end(L, s);
   return rc;
 }
+// LD pictures on the whole-plane path: the LL band of the interleaved plane is not the dequantised residuals that
+// store_to_plane put there but the DC-predicted reconstruction (inverse_quantise_LLSubband, Quantisation.cpp:287-306),
+// which the LL kernels of vc2hip_slices.hip left in the compact LL plane
+__global__ void k_ll_into_plane(const int32_t *ll, long long ll_stride, int llh, int llw, int32_t *plane, long long plane_stride, int pw, int depth) {
+  const int x = blockIdx.x * 128 + threadIdx.x, y = blockIdx.y, pic = blockIdx.z;
+  if (x >= llw || y >= llh) return;
+  plane[(size_t)pic * plane_stride + ((size_t)y << depth) * pw + ((size_t)x << depth)] = ll[(size_t)pic * ll_stride + (size_t)y * llw + x];
+}
+void vc2_launch_ll_into_plane(Launcher &L, const int32_t *ll, long long ll_stride, int llh, int llw, int32_t *plane, long long plane_stride,
+                              int pw, int depth, int n, hipStream_t s) {
+  vc2_prof_begin(L, "ld_ll_into_plane", s);
+  VC2_LAUNCH(L, k_ll_into_plane, dim3((llw + 127) / 128, llh, n), dim3(128), 0, s, ll, ll_stride, llh, llw, plane, plane_stride, pw, depth);
+  vc2_prof_end(L, s);
+}
 void vc2_launch_plane_ingest(Launcher &L, const void *raw, long long raw_stride, int pic_h, int pic_w, int word_bytes, int bit_depth,
                              int32_t *plane, long long plane_stride, int ph, int pw, int n, hipStream_t s) {
   vc2_prof_begin(L, "plane_ingest", s);

@@ -323,6 +323,7 @@ void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, 
 // the slice writer
 struct LdEncParams {
   int32_t *store;             // in: transform coefficients; out: quantised (LL as prediction residuals)
+  int32_t *scratch;           // slices too large for LDS: the trials' quantised values, same shape as the store (null: such slices are refused)
   long long store_stride;
   int32_t *qidx;              // n_pictures * n_slices; written when search != 0
   const int32_t *slice_bytes; // per slice

@@ -2650,6 +2650,10 @@ void vc2_launch_ld_ll(Launcher &L, const int32_t *store, long long store_stride,
 // one wavefront per slice.  The last pass of a slice (at its chosen index) leaves the quantised
 // coefficients -- LL band as prediction residuals -- in the coefficient store, in coding order.
 // ------------------------------------------------------------------------------------------
+// GLOBAL: a slice too large for LDS (the reference's only limit is sliceSizeIsValid: slices up to the whole picture) -- the
+// coefficients are read from the store in every trial and the trial's quantised values go to a scratch array of the
+// store's shape; the lanes of the wavefront hand them to each other through memory (workgroup-scope fences: one CU).
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, int d) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2657,18 +2661,28 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
   const int sv = max(0, d - (p.xs - 1)) + (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
   if (sv > min(p.ys - 1, d)) return; // no workgroup barriers below
   const int sh = d - sv, slice = sv * p.xs + sh;
-  int *co = lds_i + wave * 2 * p.slice_coefs, *qv = co + p.slice_coefs;
   int32_t *rec = p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
-  for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
+  const int staged = GLOBAL ? 0 : 2 * p.slice_coefs; // LDS ints per wavefront for the two copies
+  int *co = GLOBAL ? rec : lds_i + wave * staged;
+  int *qv = GLOBAL ? p.scratch + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs : co + p.slice_coefs;
+  auto wave_sync = [&]() {
+    if constexpr (GLOBAL) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else wave_lds_sync();
+  };
+#define wave_lds_sync wave_sync
+  if constexpr (!GLOBAL) for (int i = lane; i < p.slice_coefs; i += 64) co[i] = rec[i];
   wave_lds_sync();
 
   // quantise the whole slice at index tq into qv; true if an adjusted index leaves the table
   const int wpw = blockDim.x >> 6;
-  uint4 *qtab = (uint4 *)(lds_i + wpw * 2 * p.slice_coefs) + wave * 32; // per subband: magic, shift, factor
+  uint4 *qtab = (uint4 *)(lds_i + wpw * staged) + wave * 32; // per subband: magic, shift, factor
   const int n_bands = 3 * p.depth + 1;
   // reconstructed LL samples of the slice's blocks with one row above and one column to the left (the neighbours'
   // final values, loaded once): the trials then run without touching memory
-  int *rs = lds_i + wpw * (2 * p.slice_coefs + 32 * 4) + wave * p.rs_ints;
+  int *rs = lds_i + wpw * (staged + 32 * 4) + wave * p.rs_ints;
   {
     int *r0 = rs;
     for (int c = 0; c < 3; ++c) {
@@ -2773,6 +2787,7 @@ __global__ __launch_bounds__(256) void k_ld_quantise_diag(const LdEncParams p, i
       r0 += (bh + 1) * pitch;
     }
   }
+#undef wave_lds_sync
 }
 
 // Tables of the fast anti-diagonal step, built once per batch: subband of every luma / interleaved chroma index
@@ -3288,12 +3303,16 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     vc2_prof_end(L, s);
     return;
   }
-  const size_t per_wave = (size_t)2 * p.slice_coefs * 4 + 32 * 16 + (size_t)p.rs_ints * 4; // coefficients, quantised copy, subband table, LL blocks + halo
-  const int wpw = vc2_waves_for_lds(per_wave);
-  vc2_allow_lds((const void *)k_ld_quantise_diag, 160 * 1024);
+  size_t per_wave = (size_t)2 * p.slice_coefs * 4 + 32 * 16 + (size_t)p.rs_ints * 4; // coefficients, quantised copy, subband table, LL blocks + halo
+  const bool global = per_wave > 160 * 1024 && p.scratch; // the slice stays in the store (the launcher's caller provided the scratch array)
+  if (global) per_wave = 32 * 16 + (size_t)p.rs_ints * 4;
+  const int wpw = std::max(1, vc2_waves_for_lds(per_wave));
+  vc2_allow_lds((const void *)k_ld_quantise_diag<false>, 160 * 1024);
+  vc2_allow_lds((const void *)k_ld_quantise_diag<true>, 160 * 1024);
   for (int d = 0; d < p.ys + p.xs - 1; ++d) {
     const int cnt = min(p.ys - 1, d) - max(0, d - (p.xs - 1)) + 1;
-    VC2_LAUNCH(L, k_ld_quantise_diag, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
+    if (global) VC2_LAUNCH(L, k_ld_quantise_diag<true>, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
+    else VC2_LAUNCH(L, k_ld_quantise_diag<false>, dim3((cnt + wpw - 1) / wpw, n_pictures), dim3(64 * wpw), wpw * per_wave, s, p, d);
   }
   vc2_prof_end(L, s);
 }
