@@ -142,8 +142,10 @@ int vc2hip_cbr_qindices(vc2hip_ctx *ctx, const int32_t *y, const int32_t *u, con
 typedef struct {
   int width, height; /* luma picture size (unpadded)                       */
   int chroma_format; /* VC2HIP_CF*                                          */
-  int bit_depth;     /* luma == chroma depth (EncodeStream -l)              */
+  int bit_depth;     /* luma depth (EncodeStream -l); the decoder's one depth (sequence header, DecodeStream.cpp:268) */
   int word_bytes;    /* bytes per sample in the raw planar file (-n), 1..4  */
+  int chroma_bit_depth; /* encoder input only: depth of the chroma words (EncodeStream -c, pictureio::bitDepth(luma, chroma),
+                           EncodeStream.cpp:322); 0 = bit_depth.  Ignored by the decode calls, as the reference's decoder does. */
 } vc2hip_picture_format;
 
 typedef struct {

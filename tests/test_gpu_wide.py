@@ -354,3 +354,29 @@ def test_ld_encode_of_slices_beyond_lds(hip, oracle):
     got, _ = hip.encode_picture_hq(raw, fmt, cp)
     assert got == stream[-13 - nbytes:-13]
     assert hip.decode_picture(got, fmt, cp) == oracle.decode_stream(p, stream, 1)[0]
+
+
+@pytest.mark.parametrize("variant", ["default", "tiles"])
+def test_separate_luma_and_chroma_bit_depths(variants, oracle, variant):
+    """EncodeStream -l 10 -c 8 (pictureio::bitDepth(lumaDepth, chromaDepth), EncodeStream.cpp:322): the chroma words carry their
+    own depth on the encoder's input.  Expected payload: the oracle's fine-grained functions plane by plane (ingest with
+    the component's depth, transform, quantise, HQ slice coding); the picture is wide enough for the streaming kernels."""
+    import vc2hip_py
+    hip = variants[variant]
+    w, h, depth, kernel, q, scalar = 1024, 64, 2, "DD97", 16, 2
+    rng = np.random.default_rng(77)
+    ywords = (rng.integers(0, 1024, size=(h, w)).astype(np.uint16) << 6).astype(">u2").tobytes()
+    cwords = [(rng.integers(0, 256, size=(h, w // 2)).astype(np.uint16) << 8).astype(">u2").tobytes() for _ in range(2)]
+    raw = ywords + cwords[0] + cwords[1]
+    fmt = vc2hip_py.picture_format(w, h, "422", 10, 2, chroma_bits=8)
+    cp = vc2hip_py.coding_params(hip.lib, fmt, kernel, depth, 2, 4, q=q, scalar=scalar)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    k = KERNELS[kernel]
+    y = oracle.dwt_forward(oracle.ingest(ywords, 2, 10, (h, w)), k, depth)
+    u = oracle.dwt_forward(oracle.ingest(cwords[0], 2, 8, (h, w // 2)), k, depth)
+    v = oracle.dwt_forward(oracle.ingest(cwords[1], 2, 8, (h, w // 2)), k, depth)
+    qm = oracle.quant_matrix(k, depth)
+    qidx = np.full((cp.y_slices, cp.x_slices), q, np.int32)
+    want = oracle.hq_pack(oracle.quantise_np(y, depth, qidx, qm), oracle.quantise_np(u, depth, qidx, qm), oracle.quantise_np(v, depth, qidx, qm),
+                          depth, qidx, 0, scalar)
+    assert payload == bytes(want)

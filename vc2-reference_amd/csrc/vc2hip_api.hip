@@ -572,7 +572,8 @@ static void chroma_dims(int h, int w, int cf, int *ch, int *cw) {
 // (DecodeStream.cpp:483-498: chroma derived from the padded luma size)
 static int picture_geom(Geom &g, const vc2hip_picture_format *f, const vc2hip_coding_params *cp, bool decoder) {
   if (!f || !cp || f->width < 1 || f->height < 1 || f->word_bytes < 1 || f->word_bytes > 4 ||
-      f->bit_depth < 1 || f->bit_depth > 8 * f->word_bytes || f->chroma_format < 0 || f->chroma_format > 2)
+      f->bit_depth < 1 || f->bit_depth > 8 * f->word_bytes || f->chroma_format < 0 || f->chroma_format > 2 ||
+      f->chroma_bit_depth < 0 || f->chroma_bit_depth > 8 * f->word_bytes)
     return VC2HIP_EINVAL;
   int ch, cw;
   chroma_dims(f->height, f->width, f->chroma_format, &ch, &cw);
@@ -682,6 +683,9 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
       p.word_bytes = f->word_bytes;
       p.sample_shift = 8 * f->word_bytes - f->bit_depth;
       p.sample_offset = 1 << (f->bit_depth - 1);
+      const int cd = f->chroma_bit_depth ? f->chroma_bit_depth : f->bit_depth;
+      p.sample_shift_c = 8 * f->word_bytes - cd;
+      p.sample_offset_c = 1 << (cd - 1);
     }
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;
@@ -819,7 +823,8 @@ static int plane_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const 
     const long long ps = (long long)cg.ph * cg.pw;
     int32_t *pl = d_plane + off;
     off += (size_t)ps * n;
-    vc2_launch_plane_ingest(c->L, src[k], ss[k], cg.h, cg.w, f->word_bytes, f->bit_depth, pl, ps, cg.ph, cg.pw, n, c->stream);
+    vc2_launch_plane_ingest(c->L, src[k], ss[k], cg.h, cg.w, f->word_bytes, k && f->chroma_bit_depth ? f->chroma_bit_depth : f->bit_depth, pl, ps,
+                            cg.ph, cg.pw, n, c->stream);
     const int rc = vc2_launch_plane_transform(c->L, kernel, pl, ps, cg.ph, cg.pw, g.depth, false, n, c->stream);
     if (rc) return set_err(c, rc, "invalid wavelet kernel");
     for (int p = 0; p < n; ++p)

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_fwd_level(const LevelParams p) {
           u = 0;
           for (int b = 0; b < p.word_bytes; ++b) u = (u << 8) | src[b];
         }
-        v = (int)(u >> p.sample_shift) - p.sample_offset;
+        v = (int)(u >> (comp ? p.sample_shift_c : p.sample_shift)) - (comp ? p.sample_offset_c : p.sample_offset);
       } else {
         v = ((const int32_t *)p.plane[comp])[(size_t)pic * p.plane_stride[comp] + (size_t)gy * in_w + gx];
       }

@@ -422,7 +422,8 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
           }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] = (int)((unsigned)((int)((unsigned)s[k] >> p.sample_shift) - p.sample_offset) << ACC);
+        for (int k = 0; k < 8; ++k)
+          s[k] = (int)((unsigned)((int)((unsigned)s[k] >> (comp ? p.sample_shift_c : p.sample_shift)) - (comp ? p.sample_offset_c : p.sample_offset)) << ACC);
       } else {
         if (kind[it] == 1) {
           if constexpr (S_::narrow) S_::unpack8(va[it], lvl_w + (size_t)gy * in_w + gx0, s);

@@ -377,12 +377,13 @@ __global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_fwd_stream(cons
   auto convert = [&](int m, int slot, int h, Row &r) __attribute__((always_inline)) {
     if constexpr (FIRST) {
       const unsigned w[4] = {pf[slot][h][0].x, pf[slot][h][0].y, pf[slot][h][0].z, pf[slot][h][0].w};
-      const int bias = -(p.sample_offset << ACC);
+      const int sshift = comp ? p.sample_shift_c : p.sample_shift; // (wave-uniform: chroma words may have their own depth)
+      const int bias = -((comp ? p.sample_offset_c : p.sample_offset) << ACC);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned b = __builtin_amdgcn_perm(w[k], w[k], 0x02030001u); // both big-endian 16-bit words to host order
-        r[k] = (int)(((b & 0xFFFFu) >> p.sample_shift) << ACC) + bias;
-        r[4 + k] = (int)((b >> (16 + p.sample_shift)) << ACC) + bias;
+        r[k] = (int)(((b & 0xFFFFu) >> sshift) << ACC) + bias;
+        r[4 + k] = (int)((b >> (16 + sshift)) << ACC) + bias;
       }
     } else {
       int s[8];

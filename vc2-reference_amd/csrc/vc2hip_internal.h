@@ -103,7 +103,8 @@ struct LevelParams {
   int ys, xs, slice_coefs;
   int rec_stride[3];          // tile kernels (vc2hip_dwt_fast.hip): elements from one slice's coefficients of a component to the next
                               // slice's -- slice_coefs in the slice records, HeadSplit::n[c] in the record heads
-  int word_bytes, sample_shift, sample_offset; // raw sample format
+  int word_bytes, sample_shift, sample_offset; // raw sample format (luma; the decoder's one format)
+  int sample_shift_c, sample_offset_c;         // FIRST: the chroma words' (EncodeStream -c: its own depth)
   int clip_lo, clip_hi;
   int ll_from_store;          // inverse, coarsest level: LL comes from store band 0 (dequantised)
   int ll_to_store;            // forward, last level: LL goes to store band 0

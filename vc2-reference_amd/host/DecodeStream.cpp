@@ -210,7 +210,7 @@ int main(int argc, char *argv[]) {
       const int pictureHeight = interlaced ? height / 2 : height;
       if (output == DECODED) {
         (void)owned;
-        vc2hip_picture_format pf = {width, pictureHeight, (int)chromaFormat, depthBits, bytes};
+        vc2hip_picture_format pf = {width, pictureHeight, (int)chromaFormat, depthBits, bytes, 0};
         vc2hip_coding_params cp = {(int)pre.wavelet_kernel, pre.depth, pre.slices_y, pre.slices_x, ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0,
                                    compressedBytes, pre.slice_prefix, pre.slice_size_scalar};
         if (!workers) {

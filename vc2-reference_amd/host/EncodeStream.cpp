@@ -160,7 +160,6 @@ int main(int argc, char *argv[]) {
       cerr << "Command line error: " << e.what() << endl;
       return EXIT_FAILURE;
     }
-    if (lumaDepth != chromaDepth) throw std::logic_error("luma and chroma bit depths must be equal in the MI355X tools");
 
     // ---- streams ----
     std::ifstream inFile; std::ofstream outFile;
@@ -204,7 +203,7 @@ int main(int argc, char *argv[]) {
       clog << endl;
     }
 
-    vc2hip_picture_format pf = {width, picFormat.lumaHeight(), (int)chromaFormat, lumaDepth, bytes};
+    vc2hip_picture_format pf = {width, picFormat.lumaHeight(), (int)chromaFormat, lumaDepth, bytes, chromaDepth};
     vc2hip_coding_params cp = {(int)kernel, waveletDepth, ySlices, xSlices,
                                mode == HQ_CBR ? VC2HIP_HQ_CBR : (mode == LD ? VC2HIP_LD : VC2HIP_HQ_CONSTQ),
                                qIndex, pictureBytes, slicePrefix, sliceScalar};

@@ -90,7 +90,7 @@ int main() {
     // variable-size stream does to DecodeStream (the bound comes from the largest data unit, a picture is the sum of its
     // fragments): the slot's pinned buffer must grow, not overflow.  Eight pictures of growing payload through two workers
     // on device 0; the encoder side returns the quantiser indices through its pinned per-slot buffer.
-    const vc2hip_picture_format pf = {width, height, (int)CF422, 10, 2};
+    const vc2hip_picture_format pf = {width, height, (int)CF422, 10, 2, 0};
     const std::size_t rawBytes = vc2hip_raw_picture_bytes(&pf);
     std::vector<std::vector<unsigned char> > raws, payloads;
     std::vector<vc2hip_coding_params> cps;

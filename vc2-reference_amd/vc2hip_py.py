@@ -26,7 +26,7 @@ class Geom(C.Structure):
 
 class PictureFormat(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("chroma_format", C.c_int),
-                ("bit_depth", C.c_int), ("word_bytes", C.c_int)]
+                ("bit_depth", C.c_int), ("word_bytes", C.c_int), ("chroma_bit_depth", C.c_int)]
 
 
 class CodingParams(C.Structure):
@@ -127,8 +127,8 @@ def load_library():
     return lib
 
 
-def picture_format(width, height, cf, bits, word_bytes=2):
-    return PictureFormat(width, height, CF[cf], bits, word_bytes)
+def picture_format(width, height, cf, bits, word_bytes=2, chroma_bits=0):
+    return PictureFormat(width, height, CF[cf], bits, word_bytes, chroma_bits)
 
 
 def coding_params(lib, fmt, kernel, depth, u, a, mode="HQ_ConstQ", q=0, s=0, prefix=0, scalar=1):
