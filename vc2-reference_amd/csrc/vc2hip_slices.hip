@@ -359,14 +359,17 @@ __device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, u
 // coefficient index comes from a per-workgroup byte table, the quantiser constants of every subband
 // from a per-slice table, both in LDS -- no per-coefficient band arithmetic, no divergence between
 // lanes whose eight coefficients straddle subbands and lanes whose do not.
-template <class ST>
+// PRE: the eight 16-bit elements were fetched earlier (`pre`, valid when j0 + 8 <= n) -- the packer issues the luma round's
+// loads before its table set-up, so that their latency and the tables' run side by side.
+template <class ST, bool PRE = false>
 __device__ __forceinline__ void load8_tab(Coef8 &c, const ST *src, const int32_t *wide, int j0, int n, const unsigned char *band_lut,
-                                          const uint4 *qtab, unsigned *err, const unsigned *lut) {
+                                          const uint4 *qtab, unsigned *err, const unsigned *lut, const uint4 pre = make_uint4(0u, 0u, 0u, 0u)) {
   c.sum = 0;
   c.last_end = 0;
   int raw[8];
   if (j0 + 8 <= n) {
-    St<ST>::load8(src + j0, wide + j0, raw);
+    if constexpr (PRE && St<ST>::narrow) St<int16_t>::unpack8(pre, wide + j0, raw);
+    else St<ST>::load8(src + j0, wide + j0, raw);
     const uint2 bands = *(const uint2 *)(band_lut + j0);
     // quant(), Quantisation.cpp:69-76, eight at a time: floor(4|v| / factor) as the truncated float product of |v| and
     // the rounded-up 4 / factor (exact for |v| < 2^20, see k_cbr_search_reg), then ONE test whether any left that domain
@@ -508,6 +511,13 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   // slices of up to 2048 coefficients per component (more than one round of 512): the same tables, longer (launcher: big_lut)
   unsigned char *big_y = (unsigned char *)((uint4 *)(band_c + 256) + nwv * S * 32), *big_c = big_y + 2048;
   const bool fast = p.comp_n[0] <= 8 * W && p.comp_n[1] <= 4 * W && p.comp_n[1] == p.comp_n[2];
+  // the luma round's loads go out before the tables: their latency and the tables' side by side (0.383 -> 0.372 ms; the
+  // chroma round's as well: 81 registers, a wavefront per SIMD fewer, 0.40 ms)
+  uint4 pre_y = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (St<ST>::narrow && !GIMG) {
+    if (fast && p.quantise && active && sl * 8 + 8 <= p.comp_n[0])
+      pre_y = *(const uint4 *)((const ST *)p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs + p.comp_off[0] + sl * 8);
+  }
   if (!GIMG || active) for (int i = sl; i < img_words; i += W) img[i] = 0;
   if (GIMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the zeros are in place before the first atomic OR
   build_vlc_lut(lut);
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       { // luma: one round
         const int n = p.comp_n[0], n0 = p.comp_n0[0];
         const int n0s = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
-        if (p.quantise) load8_tab(c, rec + p.comp_off[0], recw + p.comp_off[0], sl * 8, n, band_y, qtab, p.err, lut);
+        if (p.quantise) load8_tab<ST, !GIMG>(c, rec + p.comp_off[0], recw + p.comp_off[0], sl * 8, n, band_y, qtab, p.err, lut, pre_y);
         else load8<false>(c, rec + p.comp_off[0], recw + p.comp_off[0], sl * 8, n, n0, n0s, qtab, p.err, lut);
         const int incl = seg_incl_scan<W>(c.sum, sl);
         const int count = seg_max<W>(c.last_end ? incl - c.sum + c.last_end : 0);
@@ -1602,8 +1612,11 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 // per lane happens on almost every turn somewhere, and a step the wavefront executes for one lane costs all of them.
 // The bit reader keeps 33..64 unread bits in a register pair and appends one pre-fetched 32-bit word when it runs low
 // (one short conditional block per turn instead of the 64-bit window assembly and refill of WordReader).
-// Rows hold 64 coefficients plus 8 of slack: a table entry is applied whole, coefficients that spill over the end of a
-// round are carried into the next one.
+// Rows hold 32 coefficients plus 8 of slack: a table entry is applied whole, coefficients that spill over the end of a
+// round are carried into the next one.  (Rows of 64 make every flush a whole 128-byte line of the store, but the rows of
+// a workgroup then take 37 KB of LDS and three wavefronts per SIMD is all a CU holds; with 32 it holds six.  16 UHD-1 / 32
+// HD / 4 UHD-2 pictures: 0.310 / 0.285 / 0.39 ms with rows of 64, 0.302 / 0.226 / 0.343 ms with rows of 32 and the
+// second request in flight below; rows of 16: 0.32 / 0.215 / 0.37.)
 // ------------------------------------------------------------------------------------------
 // entry: bits [3:0] consumed (1..10), [7:4] coefficients (1..8), [11:8] / [15:12] positions of the two values,
 // [23:16] / [31:24] the values (int8).  No non-zero value: both slots store 0 at position 0 (a zero anyway); one: both
@@ -1612,7 +1625,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 #define UNP_LOOKS 3
 #endif
 #ifndef VC2_UNP16_N
-#define VC2_UNP16_N 64
+#define VC2_UNP16_N 32
 #endif
 #ifndef UNP_LONG_EVERY
 #define UNP_LONG_EVERY 3
@@ -1660,6 +1673,9 @@ void vc2_upload_unpack_lut(hipStream_t s) {
 // put two to five words of distance between a request and its use.  Words are dword-aligned (a wave-uniform base + a
 // 32-bit offset per lane); bits past the bounded data read as 1 (VLC.cpp:182-185) and no word without a data bit is
 // ever loaded.
+#ifndef VC2_UNP_DEEP
+#define VC2_UNP_DEEP 1
+#endif
 struct __attribute__((aligned(4))) Dword4 { unsigned x, y, z, w; };
 struct Reader32 {
   unsigned long long acc;
@@ -1667,6 +1683,9 @@ struct Reader32 {
   unsigned q0, q1, q2, q3; // the words after those in acc (q0 first); qn of them are valid, 1..4 between turns
   int qn;
   unsigned n0, n1, n2, n3; // the four words after the queue
+#if VC2_UNP_DEEP
+  unsigned m0, m1, m2, m3; // and the four after those: two requests in flight (eight to twelve words between a request and its use)
+#endif
   unsigned off;            // byte offset (from the payload base) of the word after those
   int left;                // data bits from that word on (<= 0: none)
   __device__ __forceinline__ unsigned fetch1(const uint8_t *pay) {
@@ -1679,14 +1698,15 @@ struct Reader32 {
     left -= 32;
     return v;
   }
-  __device__ __forceinline__ void fetch4(const uint8_t *pay) {
+  __device__ __forceinline__ void fetch4(const uint8_t *pay, unsigned &a, unsigned &b, unsigned &c, unsigned &d) {
     if (left >= 128) { // sixteen bytes of data: one load
       const Dword4 v = *(const Dword4 *)(pay + off);
-      n0 = __builtin_bswap32(v.x); n1 = __builtin_bswap32(v.y); n2 = __builtin_bswap32(v.z); n3 = __builtin_bswap32(v.w);
+      a = __builtin_bswap32(v.x); b = __builtin_bswap32(v.y); c = __builtin_bswap32(v.z); d = __builtin_bswap32(v.w);
       off += 16;
       left -= 128;
-    } else { n0 = fetch1(pay); n1 = fetch1(pay); n2 = fetch1(pay); n3 = fetch1(pay); } // the stream's end: word by word
+    } else { a = fetch1(pay); b = fetch1(pay); c = fetch1(pay); d = fetch1(pay); } // the stream's end: word by word
   }
+  __device__ __forceinline__ void fetch4(const uint8_t *pay) { fetch4(pay, n0, n1, n2, n3); }
   // nbytes of data at byte offset pos of the payload
   __device__ __forceinline__ void init(const uint8_t *pay, unsigned pos, int nbytes) {
     const int lead = 8 * (int)(pos & 3u);
@@ -1697,6 +1717,9 @@ struct Reader32 {
     have = 64 - lead;
     q0 = n2; q1 = n3; q2 = ~0u; q3 = ~0u; qn = 2;
     fetch4(pay);
+#if VC2_UNP_DEEP
+    fetch4(pay, m0, m1, m2, m3);
+#endif
   }
   __device__ __forceinline__ unsigned top() const { return (unsigned)(acc >> 32); }
   __device__ __forceinline__ void skip(const uint8_t *pay, int n) { // n <= 32
@@ -1706,7 +1729,11 @@ struct Reader32 {
       acc |= (unsigned long long)q0 << (32 - have);
       have += 32;
       q0 = q1; q1 = q2; q2 = q3;
+#if VC2_UNP_DEEP
+      if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; n0 = m0; n1 = m1; n2 = m2; n3 = m3; fetch4(pay, m0, m1, m2, m3); }
+#else
       if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; fetch4(pay); }
+#endif
     }
   }
 };
@@ -1725,14 +1752,17 @@ __device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int
   return (int)bp.base[comp][l] + (b * bp.np[comp][l] + (sy << lh) + r) * ow + (sx << lw) + c; // (a picture's store is < 2^31 elements)
 }
 
-__global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
+#ifndef VC2_UNP16_WAVES
+#define VC2_UNP16_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const UnpackParams p) {
   constexpr int UNP_N = VC2_UNP16_N, UNP_PITCH = UNP_N + 8, PR = UNP_N / 8; // shorts per staging row (8 of slack), 16-byte aligned rows; pieces per row
-  __shared__ __attribute__((aligned(16))) short stage[4][64 * UNP_PITCH];
+  __shared__ __attribute__((aligned(16))) short stage[VC2_UNP16_WAVES][64 * UNP_PITCH];
   __shared__ unsigned lut[UNP_LUT_N];
   for (int i = threadIdx.x * 4; i < UNP_LUT_N; i += blockDim.x * 4) *(uint4 *)(lut + i) = *(const uint4 *)(g_unp_lut + i);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pic = blockIdx.y, comp = blockIdx.z;
-  const int slice0 = blockIdx.x * 256 + wave * 64, slice = slice0 + lane;
+  const int slice0 = blockIdx.x * (64 * VC2_UNP16_WAVES) + wave * 64, slice = slice0 + lane;
   const bool active = slice < p.n_slices;
   const int n = p.comp_n[comp];
   short *st = stage[wave] + lane * UNP_PITCH;
@@ -1826,7 +1856,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack16(const UnpackParams p) {
       }
       br.skip(pay, used);
     }
-    // flush: eight lanes x 16 bytes per row (one 128-byte line of the store).  The staging rows are private to the
+    // flush: UNP_N / 8 lanes x 16 bytes per row (half a 128-byte line of the store).  The staging rows are private to the
     // wavefront, so only its own lanes have to agree (LDS operations of one wavefront execute in order): no workgroup
     // barrier, the four wavefronts of the workgroup drift apart freely.
     wave_lds_sync();
@@ -1908,7 +1938,8 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipS
   if (p.xs < 1) p.xs = 1;
   vc2_prof_begin(L, "hq_unpack", s);
   if (p.store16) {
-    VC2_LAUNCH(L, k_hq_unpack16, dim3((p.n_slices + 255) / 256, n_pictures, 3), dim3(256), 0, s, p);
+    constexpr int T = 64 * VC2_UNP16_WAVES;
+    VC2_LAUNCH(L, k_hq_unpack16, dim3((p.n_slices + T - 1) / T, n_pictures, 3), dim3(T), 0, s, p);
     vc2_prof_end(L, s);
     return;
   }
