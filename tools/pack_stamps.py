@@ -20,8 +20,10 @@ for _ in range(2):
     hip.sync()
 a = np.fromfile(f, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
 t = a[a[:, 0] > 0]
-names = ["set-up (tables, zero, barrier)", "luma round", "chroma round", "wait for the workgroup", "copy-out"]
 print(f"{len(t)} workgroups of picture 0; life median {np.median(t[:, 5] - t[:, 0]) / 100:.2f} us")
+order = [0, 1, 6, 7, 2, 3, 4, 5]   # stamps in program order (6, 7: inside the luma round)
+names = ["set-up (tables, zero, barrier)", "luma: load, quantise, codes", "luma: scan, lengths", "luma: code writes", "chroma round",
+         "(end of the slice)", "copy-out"]
 for i, nm in enumerate(names):
-    d = (t[:, i + 1] - t[:, i]) / 100.0
+    d = (t[:, order[i + 1]] - t[:, order[i]]) / 100.0
     print(f"   {nm:32s} median {np.median(d):6.2f} us  p90 {np.percentile(d, 90):6.2f}")

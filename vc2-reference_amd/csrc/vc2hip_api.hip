@@ -903,7 +903,7 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const void *store, cons
   // (images kept in the slots themselves: room for the two guard words of an image)
   const int slot = (int)((max_slice_bytes(prefix, scalar) + (gimg ? 8 : 0) + 15) & ~(size_t)15);
   uint8_t *slots; uint32_t *sizes, *offs;
-  NEED(c, B_SLOTS, (size_t)n * ns * slot, slots);
+  NEED(c, B_SLOTS, (size_t)n * ns * slot + 32, slots); // (+32: the compaction reads whole 16-byte pieces and the dword behind them)
   NEED(c, B_SIZES, (size_t)n * ns * 4, sizes);
   NEED(c, B_OFFS, (size_t)n * ns * 4, offs);
   p.slots = slots; p.slot_bytes = slot; p.sizes = sizes;
