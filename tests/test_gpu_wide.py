@@ -380,3 +380,22 @@ def test_separate_luma_and_chroma_bit_depths(variants, oracle, variant):
     want = oracle.hq_pack(oracle.quantise_np(y, depth, qidx, qm), oracle.quantise_np(u, depth, qidx, qm), oracle.quantise_np(v, depth, qidx, qm),
                           depth, qidx, 0, scalar)
     assert payload == bytes(want)
+
+
+@pytest.mark.parametrize("h,cf", [(24, "420"), (200, "422"), (400, "422"), (512, "444"), (600, "422")])
+def test_ld_decode_dc_prediction_by_one_wavefront(hip, oracle, h, cf):
+    """The DC-predicted LL band (Quantisation.cpp:191-234) of planes of up to 256 rows is reconstructed by one wavefront
+    whose lanes own 1, 2, 3 or 4 consecutive rows (ld_ll_wave<R>); taller planes take the anti-diagonal sweep.  Depth 1:
+    LL planes of 12 / 6, 100, 200, 256 and 300 rows (a partial last lane, every R, the limit, the fallback); noise, so that
+    the residuals are large and of both signs."""
+    from test_gpu_parity import _fmt_cp
+    w, depth = 96, 1
+    nbytes = w * h * 3 // 4
+    raw = noise_frame(w, h, cf, 8, 1000 + h, word_bytes=1)
+    p = make_params(w, h, cf, 8, "Haar0", depth, 2, 4, mode="LD", s=nbytes, word_bytes=1)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, n = oracle.decode_stream(p, stream, 1)
+    assert n == 1
+    fmt, cp = _fmt_cp(hip, w, h, cf, 8, "Haar0", depth, 2, 4, mode="LD", s=nbytes, word_bytes=1)
+    payload = stream[-13 - nbytes:-13]
+    assert hip.decode_picture(payload, fmt, cp) == dec

@@ -2579,6 +2579,69 @@ __global__ __launch_bounds__(1024) void k_ld_ll(const int32_t *store, long long 
   }
 }
 
+// DC prediction of a plane of up to 64 R rows in LDS by ONE wavefront, no barrier.  A lane owns R consecutive rows and
+// walks the columns one step behind the lane above it; what it needs from there -- the row above its first row, at this
+// column and the one before -- arrives by DPP (wave_shr:1) from that lane's last two steps, its own left and upper-left
+// neighbours are the previous step's registers, the residuals are fetched a step ahead.  The anti-diagonal sweep over
+// 2 x 2 blocks it replaces paid a workgroup barrier and an LDS round trip per diagonal (16 HD pictures: 0.148 ms, of
+// which 0.053 are the gather of the residuals and the plane's way out).  A lone wavefront waits ~8 cycles for every
+// dependent result and ~20 for every branch, so a step is straight-line code and the chain per sample is four
+// instructions (first version, a test per row and the literal formula: 0.138 ms; straight-line: 0.108):
+//   * predictDC (Quantisation.cpp:191-208), s >= 0 ? (s + 1) / 3 : (s - 1) / 3 for s = upper-left + up + left, is
+//     floor((s + 1) / 3) for either sign; with a bias B = 0x7FFFFFFE (a multiple of 3) the dividend is non-negative as an
+//     unsigned word for every s > INT_MIN, and floor(u / 3) = umulhi(u, 0xAAAAAAAB) >> 1 for every 32-bit u.  The bias
+//     goes into the upper-left term and B / 3 comes off the residual, both known a step early: add3, mul_hi, shift, add.
+//     (s = INT_MIN, where this differs, and s = INT_MAX, where the reference's s + 1 overflows, need |samples| ~ 2^30.)
+//   * column 0 (prediction = the sample above) is a prefix sum down the column, done first; row 0 (prediction = the
+//     sample to the left) is the formula with left standing in for up and upper-left: floor((3 l + 1) / 3) = l.
+template <int R> __device__ __forceinline__ void ld_ll_wave(int *rs, int llh, int llw) {
+  constexpr unsigned BIAS = 0x7FFFFFFEu, BIAS3 = BIAS / 3u;
+  const int lane = threadIdx.x, y0 = lane * R, nl = (llh + R - 1) / R;
+  int row[R]; // LDS offsets of the own rows (rows past the plane: the last row, never stored)
+  bool ok[R];
+  unsigned left[R], res[R]; // the own rows at column x - 1; their residuals at column x, less BIAS3
+  unsigned run = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    ok[r] = y0 + r < llh;
+    row[r] = min(y0 + r, llh - 1) * llw;
+    run += ok[r] ? (unsigned)rs[row[r]] : 0u;
+    left[r] = run; // column 0, still without the rows of the lanes above
+  }
+  const unsigned above = (unsigned)wave_incl_scan((int)run, lane) - run; // column 0 of the row above the own first row
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    left[r] += above;
+    if (ok[r]) rs[row[r]] = (int)left[r];
+    res[r] = (unsigned)rs[row[r] + min(1, llw - 1)] - BIAS3;
+  }
+  unsigned bottom = left[R - 1]; // the own last row at the column of the latest step
+  unsigned prev_up = above;      // the row above the own first row at column x - 1
+  const bool top = y0 == 0;
+  for (int t = 0; t < llw - 1 + nl - 1; ++t) {
+    const unsigned up_in = (unsigned)dpp0<0x138, 0xf>((int)bottom); // the lane above finished this column in the previous step
+    const int x = t - lane + 1;
+    if (x >= 1 && x < llw && ok[0]) {
+      unsigned nres[R];
+      const int xn = min(x + 1, llw - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) nres[r] = (unsigned)rs[row[r] + xn] - BIAS3; // (column x + 1 is the next step's: not yet overwritten)
+      unsigned ul = (top ? left[0] : prev_up) + (BIAS + 1u), up = top ? left[0] : up_in;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const unsigned a = res[r] + (__umulhi(ul + up + left[r], 0xAAAAAAABu) >> 1);
+        if (ok[r]) rs[row[r] + x] = (int)a;
+        ul = left[r] + (BIAS + 1u);
+        left[r] = a;
+        up = a;
+        res[r] = nres[r];
+      }
+      bottom = up; // (a partial last lane hands nothing on: no lane below it has rows)
+      prev_up = up_in;
+    }
+  }
+}
+
 // The same with the whole LL plane in LDS (it fits for HD pictures: 135 x 240 x 4 bytes): the residuals are dequantised
 // into LDS in one parallel sweep, the anti-diagonal wavefront then only touches LDS (a barrier per diagonal costs
 // tenths of a microsecond instead of a round trip to memory), and the plane is written out once.
@@ -2651,8 +2714,24 @@ __device__ __forceinline__ void ld_ll_lds_body(int pic, const int32_t *store, lo
       if (x > 0) return lf;
       return 0;
     };
-    const int nby = (llh + 1) / 2, nbx = (llw + 1) / 2;
-    for (int d = 0; d < nby + nbx - 1; ++d) {
+    // Planes of up to 256 rows (HD: 135): ONE wavefront, no barrier at all.  A lane owns R = ceil(rows / 64) consecutive
+    // rows and walks the columns one step behind the lane above it; what it needs from there -- the row above its first
+    // row, at this column and the one before -- arrives by DPP (wave_shr:1) from that lane's last two steps, its own
+    // left and upper-left neighbours are the previous step's registers.  A step is R dependent predictions (~12
+    // instructions each) instead of a workgroup barrier and an LDS round trip per anti-diagonal of blocks:
+    // 16 HD pictures 0.148 -> ... ms.
+    const int R = (llh + 63) / 64;
+    if (R <= 4) {
+      if (threadIdx.x < 64) {
+        if (R == 1) ld_ll_wave<1>(rs, llh, llw);
+        else if (R == 2) ld_ll_wave<2>(rs, llh, llw);
+        else if (R == 3) ld_ll_wave<3>(rs, llh, llw);
+        else ld_ll_wave<4>(rs, llh, llw);
+      }
+      __syncthreads();
+    } else
+    for (int d = 0; d < (llh + 1) / 2 + (llw + 1) / 2 - 1; ++d) {
+      const int nby = (llh + 1) / 2, nbx = (llw + 1) / 2;
       const int blo = max(0, d - (nbx - 1)), bhi = min(nby - 1, d);
       for (int by = blo + (int)threadIdx.x; by <= bhi; by += blockDim.x) {
         const int y0 = 2 * by, x0 = 2 * (d - by);
@@ -2699,8 +2778,13 @@ bool vc2_launch_ld_ll3(Launcher &L, const LdLl3Params &p, int n_pictures, hipStr
   if (bytes > 150 * 1024) return false;
   vc2_prof_begin(L, "ld_ll_predict", s);
   vc2_allow_lds((const void *)k_ld_ll_lds3, 150 * 1024);
-  const int blocks = (reach + 1) / 2; // 2 x 2 blocks on the longest anti-diagonal: never more are busy in a step
-  const int threads = blocks <= 256 ? 256 : 512; // measured for 1080p (68 blocks): 128 threads 0.167 ms, 256 0.148, 512 0.153 (barriers cost more)
+  // planes of up to 256 rows: the prediction is one wavefront's work (ld_ll_wave), the other wavefronts only gather the
+  // residuals and write the plane out (16 HD pictures: 256 threads 0.094 ms, 512 0.099, 1024 0.100).  Taller planes: 2 x 2
+  // blocks on the longest anti-diagonal, never more are busy in a step (measured for 68 blocks: 128 threads 0.167 ms,
+  // 256 0.148, 512 0.153: barriers cost more)
+  const int blocks = (reach + 1) / 2;
+  static const int tune_threads = vc2_tune_int("VC2HIP_LD_LL_THREADS", 0);
+  const int threads = tune_threads ? tune_threads : blocks <= 256 ? 256 : 512;
   VC2_LAUNCH(L, k_ld_ll_lds3, dim3(n_pictures, 3), dim3(threads), bytes, s, p);
   vc2_prof_end(L, s);
   return true;
