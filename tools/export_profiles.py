@@ -32,9 +32,9 @@ def main(tag):
     shutil.copy(f'{d}/stats/run_kernel_stats.csv', f'profiles/{tag}_rocprofv3_kernel_stats.csv')
     if os.path.exists(f'{d}/bench_under_rocprof.json'):
         shutil.copy(f'{d}/bench_under_rocprof.json', f'profiles/{tag}_bench_under_rocprof.json')
-    if os.path.exists(f'{d}/stats1/run_kernel_stats.csv'):   # the one-stream run: every kernel alone on the GPU
-        shutil.copy(f'{d}/stats1/run_kernel_stats.csv', f'profiles/{tag}_rocprofv3_kernel_stats_one_stream.csv')
-        shutil.copy(f'{d}/bench_under_rocprof_one_stream.json', f'profiles/{tag}_bench_under_rocprof_one_stream.json')
+    if os.path.exists(f'{d}/stats2/run_kernel_stats.csv'):   # the batch cut over two streams: kernels of the two halves overlap
+        shutil.copy(f'{d}/stats2/run_kernel_stats.csv', f'profiles/{tag}_rocprofv3_kernel_stats_two_streams.csv')
+        shutil.copy(f'{d}/bench_under_rocprof_two_streams.json', f'profiles/{tag}_bench_under_rocprof_two_streams.json')
     with open(f'profiles/{tag}_pmc_instruction_mix.txt', 'w') as f:
         f.write('# rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/prof_kernels.sh); '
                 'SQ_WAVE_CYCLES and the WAIT / ACTIVE counters are in 4-cycle units\n')
@@ -54,14 +54,16 @@ def main(tag):
         for sn, (cnt, tot) in acc.items():
             out.setdefault(sn, {})[name + '_KiB'] = tot / cnt
             out[sn]['launches_sampled'] = cnt
+    cfg = json.loads(open(f'{d}/bench_under_rocprof.json').read().strip().splitlines()[-1])["config"]   # the same command line as the PMC passes
+    per_launch = cfg["pictures_per_gpu_per_step"] // max(1, cfg["streams"])
     res = {"_comment": "rocprofv3 PMC, two separate passes (--kernel-trace --pmc FETCH_SIZE ; --kernel-trace --pmc WRITE_SIZE) of "
-                       "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs` (32 UHD cfg-2 pictures per step on two streams: 16 per launch), averages "
+                       f"`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs` ({cfg['pictures_per_gpu_per_step']} UHD cfg-2 pictures per step on {cfg['streams']} stream(s): {per_launch} per launch), averages "
                        "per launch. FETCH_SIZE/WRITE_SIZE are in KiB. hbm_bytes_per_launch applies the gfx950 correction of "
                        "MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads): 2*FETCH + WRITE -- an upper bound for "
                        "kernels whose reads are narrower than 16 bytes per lane. Names with several launches per step (dwt_level, "
                        "idwt_level: the levels below the first) are averages over those launches. Made by tools/export_profiles.py "
                        "from the " + tag + " runs.",
-           "csrc_digest": bench.csrc_digest(), "pictures_per_launch": 16, "kernels": {}}
+           "csrc_digest": bench.csrc_digest(), "pictures_per_launch": per_launch, "kernels": {}}
     for k, v in sorted(out.items()):
         f, w = v.get('FETCH_SIZE_KiB', 0) * 1024, v.get('WRITE_SIZE_KiB', 0) * 1024
         res['kernels'][k] = {"launches_sampled": v['launches_sampled'], "FETCH_SIZE_KiB": round(v.get('FETCH_SIZE_KiB', 0), 1),

@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAF
 out=gpurun_out/prof_$tag
 mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs "$@" > $out/bench_under_rocprof.json 2> $out/stats.err
-# the same with ONE stream: every kernel alone on the GPU (the durations the per-kernel table of bench.py is made of)
-rocprofv3 --kernel-trace --stats -d $out/stats1 -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs --streams 1 "$@" > $out/bench_under_rocprof_one_stream.json 2> $out/stats1.err
+# the same with the batch cut over TWO streams (vc2hip_set_streams: 16 pictures per launch, the kernels of the two halves overlap)
+rocprofv3 --kernel-trace --stats -d $out/stats2 -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs --streams 2 "$@" > $out/bench_under_rocprof_two_streams.json 2> $out/stats2.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD -d $out/mix -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs "$@" > /dev/null 2> $out/mix.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $out/mix2 -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs "$@" > /dev/null 2> $out/mix2.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs "$@" > /dev/null 2> $out/fetch.err
