@@ -59,7 +59,7 @@ def test_dwt_large_plane_all_tiles(hip, oracle):
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
 def test_dwt_fast_path_all_kernels(hip, oracle, kernel):
-    # planes larger than the 64 x 128 register-blocked tile (ragged: 200 x 264, 136 x 392), every
+    # planes larger than the 32 x 128 register-blocked tile (ragged: 200 x 264, 136 x 392), every
     # wavelet, both directions; deeper levels fall back to the generic kernel (mixed pipeline)
     rng = np.random.default_rng(15)
     for shape, depth in (((200, 264), 3), ((136, 392), 2), ((64, 128), 1)):

@@ -644,7 +644,7 @@ static void fill_level(LevelParams &p, const Geom &g, int level, int kernel, con
     p.rec_stride[c] = g.slice_coefs;
     if (cg.ph == 0) { p.tiles_x[c] = p.tiles_y[c] = 0; p.fh[c] = p.fw[c] = 2; p.tsy[c] = p.tsx[c] = 1; continue; }
     p.fh[c] = cg.sh >> level; p.fw[c] = cg.sw >> level;
-    // tile ~64 x 128 samples, whole slices, power-of-two slice counts, LDS <= 64 KiB
+    // tile 32 x 128 samples, whole slices, power-of-two slice counts, LDS <= 64 KiB
     int tsy = 1, tsx = 1;
     while (tsy * 2 * p.fh[c] <= 64 && tsy * 2 <= g.ys) tsy *= 2;
     while (tsx * 2 * p.fw[c] <= 128 && tsx * 2 <= g.xs) tsx *= 2;

@@ -1,7 +1,7 @@
 // Register-blocked DWT / IDWT level kernels (the hot configuration of the generic kernels in
 // vc2hip_dwt.hip; same reference semantics, same LevelParams).
 //
-// Tile = 64 x 128 samples of whole slices, anchored inside the plane (the last tile of a row /
+// Tile = 32 x 128 samples (TY x TX below) of whole slices, anchored inside the plane (the last tile of a row /
 // column is shifted back so its core never crosses the plane edge; overlapping cores write
 // identical values).  Differences from the generic kernel:
 //   * all tile geometry is compile-time (no integer divisions in the inner loops)
@@ -891,7 +891,7 @@ bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 } // namespace
 
 // The fast kernels apply when every active component has power-of-two slice footprints that divide
-// the 64 x 128 tile and a plane at least one tile large.  Rewrites the tiling fields of p.
+// the 32 x 128 tile and a plane at least one tile large.  Rewrites the tiling fields of p.
 bool vc2_fast_level_applicable(LevelParams &p) {
   for (int c = 0; c < 3; ++c) {
     if (p.tiles_x[c] == 0 || p.tiles_y[c] == 0) continue;
