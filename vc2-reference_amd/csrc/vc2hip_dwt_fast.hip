@@ -717,31 +717,68 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     const int nsc = sc1 - sc0 + 1, nsl = (sr1 - sr0 + 1) * nsc, nq = (chunk_n + 3) >> 2;
     const bool al = ((chunk0 | p.rec_stride[comp]) & 3) == 0;
     const int qm0 = p.qmatrix[0], qm1 = p.qmatrix[p.band], qm2 = p.qmatrix[p.band + 1], qm3 = p.qmatrix[p.band + 2];
-    for (int id = threadIdx.x; id < nsl * nq && !VC2_SKIP(p, 1); id += NT) {
-      const int sidx = id / nq, qd = id - sidx * nq;
-      const int sr = sidx / nsc, sv = sr0 + sr, sh = sc0 + (sidx - sr * nsc);
-      const size_t at = (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + chunk0 + 4 * qd;
-      int e[4];
-      if (al && 4 * qd + 4 <= chunk_n) S_::load4(store + at, wide + at, e);
-      else {
+    // Four pieces per thread and turn, all their loads (16 bytes of coefficients, the slice's index) issued before the
+    // first is consumed: a turn that loads and consumes one piece at a time waits out a trip to memory per piece -- the
+    // phase took 15 us of a workgroup's 22 at the deepest level of UHD, 11 of 17 at the level above (phase stamps).  The
+    // two divisions by run-time constants per piece are multiplications (exact for the < 2^16 pieces of a tile).
+    constexpr int GB = 4;
+    const int total = VC2_SKIP(p, 1) ? 0 : nsl * nq;
+    const unsigned mg_nq = 0xFFFFFFFFu / (unsigned)nq + 1u, mg_nsc = 0xFFFFFFFFu / (unsigned)nsc + 1u;
+    for (int id0 = threadIdx.x; id0 < total; id0 += NT * GB) {
+      int e[GB][4], q[GB], sv_[GB], sh_[GB], qd_[GB];
+      bool vecl[GB]; // the piece came as one aligned load (else: element by element, when it is consumed)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = 4 * qd + k < chunk_n ? S_::load1(store + at + k, wide + at + k) : 0;
-      }
-      const int q = p.dequant ? qidx[sv * p.xs + sh] : 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int idx = 4 * qd + k;
-        if (idx >= chunk_n) continue;
-        const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
-        const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
-        if (i < 0 || i >= WYP || j < 0 || j >= WXP) continue;
-        int v = e[k];
-        if (p.dequant && !VC2_SKIP(p, 8)) {
-          const int aq = max(q - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
-          if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
-          v = dequant_f(v, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
+      for (int g = 0; g < GB; ++g) {
+        const int id = id0 + g * NT;
+        vecl[g] = false; q[g] = 0; sv_[g] = sh_[g] = qd_[g] = 0;
+        e[g][0] = e[g][1] = e[g][2] = e[g][3] = 0;
+        if (id >= total) continue;
+        const int sidx = nq == 1 ? id : (int)__umulhi((unsigned)id, mg_nq), qd = id - sidx * nq; // (the multiplier of 1 does not fit 32 bits)
+        const int sr = nsc == 1 ? sidx : (int)__umulhi((unsigned)sidx, mg_nsc), sv = sr0 + sr, sh = sc0 + (sidx - sr * nsc);
+        sv_[g] = sv; sh_[g] = sh; qd_[g] = qd;
+        const size_t at = (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + chunk0 + 4 * qd;
+        if (al && 4 * qd + 4 <= chunk_n) {
+          vecl[g] = true;
+          if constexpr (S_::narrow) { const uint2 v = *(const uint2 *)(store + at); e[g][0] = (int)v.x; e[g][1] = (int)v.y; }
+          else { const int4 v = *(const int4 *)(store + at); e[g][0] = v.x; e[g][1] = v.y; e[g][2] = v.z; e[g][3] = v.w; }
         }
-        lds[band * C::PLANE + i * WXP + j] = v;
+        if (p.dequant) q[g] = qidx[sv * p.xs + sh];
+      }
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const int id = id0 + g * NT;
+        if (id >= total) continue;
+        const int sv = sv_[g], sh = sh_[g], qd = qd_[g];
+        const size_t at = (size_t)(sv * p.xs + sh) * p.rec_stride[comp] + chunk0 + 4 * qd;
+        int v4[4];
+        if (vecl[g]) {
+          if constexpr (S_::narrow) {
+            const unsigned w0 = (unsigned)e[g][0], w1 = (unsigned)e[g][1];
+            v4[0] = vc2_lo16(w0); v4[1] = vc2_hi16(w0); v4[2] = vc2_lo16(w1); v4[3] = vc2_hi16(w1);
+            if (min(min(v4[0], v4[1]), min(v4[2], v4[3])) == VC2_ST_SENTINEL) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) if (v4[k] == VC2_ST_SENTINEL) v4[k] = wide[at + k];
+            }
+          } else { v4[0] = e[g][0]; v4[1] = e[g][1]; v4[2] = e[g][2]; v4[3] = e[g][3]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v4[k] = 4 * qd + k < chunk_n ? S_::load1(store + at + k, wide + at + k) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = 4 * qd + k;
+          if (idx >= chunk_n) continue;
+          const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
+          const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
+          if (i < 0 || i >= WYP || j < 0 || j >= WXP) continue;
+          int v = v4[k];
+          if (p.dequant && !VC2_SKIP(p, 8)) {
+            const int aq = max(q[g] - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
+            if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+            v = dequant_f(v, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
+          }
+          lds[band * C::PLANE + i * WXP + j] = v;
+        }
       }
     }
   }
