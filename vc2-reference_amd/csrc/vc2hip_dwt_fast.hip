@@ -722,6 +722,7 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     // phase took 15 us of a workgroup's 22 at the deepest level of UHD, 11 of 17 at the level above (phase stamps).  The
     // two divisions by run-time constants per piece are multiplications (exact for the < 2^16 pieces of a tile).
     constexpr int GB = 4;
+    const bool pairs = lbn >= 1 && lbsw >= 1 && (chunk_n & 1) == 0;
     const int total = VC2_SKIP(p, 1) ? 0 : nsl * nq;
     const unsigned mg_nq = 0xFFFFFFFFu / (unsigned)nq + 1u, mg_nsc = 0xFFFFFFFFu / (unsigned)nsc + 1u;
     for (int id0 = threadIdx.x; id0 < total; id0 += NT * GB) {
@@ -764,20 +765,49 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v4[k] = 4 * qd + k < chunk_n ? S_::load1(store + at + k, wide + at + k) : 0;
         }
+        if (pairs) {
+          // an aligned pair of the piece lies in one band and one block row (bands and block rows of two or more
+          // coefficients): band, row, quantiser constants and the row test once per pair, and scale() as the multiply-add
+          // of the vector path above (one magnitude test for the pair, the literal sequence outside its domain)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int idx = 4 * qd + k;
-          if (idx >= chunk_n) continue;
-          const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
-          const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
-          if (i < 0 || i >= WYP || j < 0 || j >= WXP) continue;
-          int v = v4[k];
-          if (p.dequant && !VC2_SKIP(p, 8)) {
-            const int aq = max(q[g] - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
-            if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
-            v = dequant_f(v, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
+          for (int h = 0; h < 2; ++h) {
+            const int idx = 4 * qd + 2 * h;
+            if (idx >= chunk_n) continue;
+            const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
+            const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
+            if (i < 0 || i >= WYP) continue;
+            int a = v4[2 * h], b = v4[2 * h + 1];
+            if (p.dequant && !VC2_SKIP(p, 8)) {
+              const int aq = max(q[g] - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
+              if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+              const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)], lim = qtab[240 + min(aq, 119)];
+              const unsigned ma = a < 0 ? 0u - (unsigned)a : (unsigned)a, mb = b < 0 ? 0u - (unsigned)b : (unsigned)b;
+              if ((int)(ma | mb) >= 0 && (int)(ma | mb) <= lim) {
+                const unsigned ra = ma ? (ma * (unsigned)qf + (unsigned)(qo + 2)) >> 2 : 0u, rb = mb ? (mb * (unsigned)qf + (unsigned)(qo + 2)) >> 2 : 0u;
+                a = a < 0 ? (int)(0u - ra) : (int)ra;
+                b = b < 0 ? (int)(0u - rb) : (int)rb;
+              } else { a = dequant_f(a, qf, qo); b = dequant_f(b, qf, qo); }
+            }
+            int *d = lds + band * C::PLANE + i * WXP + j;
+            if (j >= 0 && j < WXP) d[0] = a;
+            if (j + 1 >= 0 && j + 1 < WXP) d[1] = b;
           }
-          lds[band * C::PLANE + i * WXP + j] = v;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int idx = 4 * qd + k;
+            if (idx >= chunk_n) continue;
+            const int band = band_first + (idx >> lbn), rem = idx & (band_n - 1);
+            const int i = (sv << lbsh) + (rem >> lbsw) - ky_base, j = (sh << lbsw) + (rem & (bsw - 1)) - kx_base;
+            if (i < 0 || i >= WYP || j < 0 || j >= WXP) continue;
+            int v = v4[k];
+            if (p.dequant && !VC2_SKIP(p, 8)) {
+              const int aq = max(q[g] - (band == 0 ? qm0 : band == 1 ? qm1 : band == 2 ? qm2 : qm3), 0);
+              if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+              v = dequant_f(v, qtab[min(aq, 119)], qtab[120 + min(aq, 119)]);
+            }
+            lds[band * C::PLANE + i * WXP + j] = v;
+          }
         }
       }
     }
