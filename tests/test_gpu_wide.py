@@ -399,3 +399,14 @@ def test_ld_decode_dc_prediction_by_one_wavefront(hip, oracle, h, cf):
     fmt, cp = _fmt_cp(hip, w, h, cf, 8, "Haar0", depth, 2, 4, mode="LD", s=nbytes, word_bytes=1)
     payload = stream[-13 - nbytes:-13]
     assert hip.decode_picture(payload, fmt, cp) == dec
+
+
+@pytest.mark.parametrize("w,h,n_slices", [(512, 256, 32768), (640, 256, 40960), (1024, 512, 131072)])
+def test_many_small_slices(variants, oracle, w, h, n_slices):
+    """Slices of 2 x 2 samples (depth 1, -u 1 -a 1, 4:4:4): 32768 slices (the size scan's two coalesced variants end here),
+    40960 and 131072 (its any-size variant; the slice index with hundreds of groups per picture)."""
+    raw = synth(w, h, "444", 8, 9000 + w, word_bytes=1)
+    hip = variants["default"]
+    fmt, cp = _fmt_cp(hip, w, h, "444", 8, "Haar0", 1, 1, 1, q=3, word_bytes=1)
+    assert cp.y_slices * cp.x_slices == n_slices
+    _check({"default": hip}, oracle, raw, w, h, "444", 8, "Haar0", 1, 1, 1, q=3, word_bytes=1)
