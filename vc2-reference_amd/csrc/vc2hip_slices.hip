@@ -1660,8 +1660,11 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 // table of "what these bits decode to": bits consumed, coefficients produced (zeros included, at most 8), and up to
 // two non-zero values with their positions -- a few coefficients per look-up for ~20 instructions, where the
 // code-by-code decoder above spends ~150 per turn of two codes.  What the table cannot hold (a code longer than 10 bits:
-// |value| > 30) takes a separate step that runs on every fourth turn only: with 64 lanes per wavefront something rare
-// per lane happens on almost every turn somewhere, and a step the wavefront executes for one lane costs all of them.
+// |value| > 30) takes a separate step after the look-ups.  (While three wavefronts shared a SIMD that step ran on every
+// fourth turn only -- with 64 lanes per wavefront something rare per lane happens on almost every turn somewhere, and a
+// step the wavefront executes for one lane costs all of them; at six wavefronts per SIMD a stalled lane's waiting costs
+// more than the step: every turn, 16 UHD pictures 0.300 -> 0.295 ms, 32 HD pictures 0.225 -> 0.190.  UNP_LONG_EVERY = 2^k - 1
+// brings the cadence back.)
 // The bit reader keeps 33..64 unread bits in a register pair and appends one pre-fetched 32-bit word when it runs low
 // (one short conditional block per turn instead of the 64-bit window assembly and refill of WordReader).
 // Rows hold 32 coefficients plus 8 of slack: a table entry is applied whole, coefficients that spill over the end of a
@@ -1680,7 +1683,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 #define VC2_UNP16_N 32
 #endif
 #ifndef UNP_LONG_EVERY
-#define UNP_LONG_EVERY 3
+#define UNP_LONG_EVERY 0
 #endif
 constexpr int UNP_LUT_BITS = 10, UNP_LUT_N = 1 << UNP_LUT_BITS;
 __device__ unsigned g_unp_lut[UNP_LUT_N];
@@ -1871,7 +1874,7 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
           used += (int)(e & 15u);
         }
       }
-      // every fourth turn: lanes stopped at a code the table does not hold decode that one code
+      // lanes stopped at a code the table does not hold decode that one code
       if ((turn & UNP_LONG_EVERY) == UNP_LONG_EVERY) {
         if (used == 0 && cnt < room) {
           const unsigned hi = br.top();                   // starts with a 0: a code
