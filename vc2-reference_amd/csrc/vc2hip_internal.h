@@ -155,7 +155,8 @@ struct PackParams {
   // VBR: fixed-stride slots + sizes; CBR: direct
   uint8_t *slots;             // n_pictures * n_slices * slot_bytes
   int slot_bytes;
-  uint32_t *sizes;            // n_pictures * n_slices
+  uint32_t *sizes;            // n_pictures * n_slices (tile_slices: n_pictures * workgroups per picture)
+  int tile_slices;            // > 0: the slices of a pack workgroup (that many) share a slot of tile_slices * slot_bytes, back to back
   const int32_t *cbr_bytes;   // per slice (one picture's worth, shared), NULL => VBR
   const uint32_t *cbr_offsets;
   uint8_t *payload;
@@ -264,6 +265,7 @@ int vc2_launch_inverse_level(Launcher &L, int kernel, bool final_level, const Le
 size_t vc2_level_lds_bytes(int kernel, const LevelParams &p);
 
 void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s);
+int vc2_pack_slices_per_tile(const PackParams &p);
 void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets,
                            unsigned long long *totals, int n_slices, int n_pictures, hipStream_t s);
 void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const uint32_t *sizes,

@@ -662,10 +662,21 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     if (sl == 0) put_byte(img, p.prefix, (unsigned)q & 0xFF);
   }
   const int total = active ? p.prefix + 4 + bytes[0] + bytes[1] + bytes[2] : 0;
-  if (p.lookback && lane == 0) s_tot[wave] = total;
+  // tile_slices: the slices of the workgroup go into its slot back to back (the wavefronts exchange their byte counts over
+  // the barrier below), one size per workgroup: the compaction then moves one run of ~1.2 KB per workgroup instead of
+  // four of ~290 bytes
+  int wave_total = 0, seg_off = 0; // bytes of the wavefront's slices; of those before this lane's slice
+#pragma unroll
+  for (int s2 = 0; s2 < S; ++s2) { const int t = __shfl(total, s2 * W); wave_total += t; if (s2 < seg) seg_off += t; }
+  if ((p.lookback || p.tile_slices) && lane == 0) s_tot[wave] = wave_total;
   PACK_STAMP(3);
   __syncthreads();
   PACK_STAMP(4);
+  if (p.tile_slices && threadIdx.x == 0) {
+    unsigned all = 0;
+    for (int w2 = 0; w2 < nwv; ++w2) all += (unsigned)s_tot[w2];
+    p.sizes[(size_t)pic * gridDim.x + tile] = all;
+  }
   if (p.lookback) {
     // decoupled look-back: publish this tile's byte count, add up the predecessors' counts until one
     // of them carries an inclusive prefix, publish ours.  One 8-byte agent-scope word per tile holds
@@ -748,6 +759,20 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
       d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
     }
+  } else if (p.tile_slices) {
+    int off = seg_off;
+    for (int w2 = 0; w2 < wave; ++w2) off += s_tot[w2];
+    uint8_t *dst = p.slots + ((size_t)pic * gridDim.x + tile) * ((size_t)p.tile_slices * p.slot_bytes) + off;
+    const int head = min((int)((4 - ((size_t)dst & 3)) & 3), total);
+    const int nw = (total - head) >> 2, tail0 = head + 4 * nw;
+    if (sl < head) dst[sl] = (uint8_t)(img[sl >> 2] >> (24 - 8 * (sl & 3)));
+    if (sl < total - tail0) { const int i = tail0 + sl; dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3))); }
+    unsigned *d4 = (unsigned *)(dst + head);
+    for (int w = sl; w < nw; w += W) {
+      const int i0 = head + 4 * w;
+      const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
+      d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
+    }
   } else {
     unsigned *dst = (unsigned *)(p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes);
     if (sl == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
@@ -769,15 +794,8 @@ int vc2_pack_image_mode(int prefix, int scalar) {
   return -1;
 }
 size_t vc2_pack_lds_bytes(int prefix, int scalar) { return pack_lds(prefix, scalar, 1); }
-void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
-  PackParams p = p0;
-  fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
-  p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
-  if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
-#ifdef VC2HIP_ABLATE
-  { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
-#endif
-  // lanes per slice: as few as still hold the slice (8 luma / 4 chroma coefficients and one subband constant per lane)
+// lanes per slice: as few as still hold the slice (8 luma / 4 chroma coefficients and one subband constant per lane)
+static int pack_lanes(const PackParams &p) {
   int W = 64;
   const bool same_c = p.comp_n[1] == p.comp_n[2];
   static const int force_w = vc2_tune_int("VC2HIP_PACK_LANES", 0);
@@ -786,6 +804,25 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
     if (p.comp_n[0] <= 128 && p.comp_n[1] <= 64 && bands <= 16 && pack_lds(p.prefix, p.scalar, 4) <= 144 * 1024) W = 16;
     else if (p.comp_n[0] <= 256 && p.comp_n[1] <= 128 && bands <= 32 && pack_lds(p.prefix, p.scalar, 2) <= 144 * 1024) W = 32;
   }
+  return W;
+}
+// the consecutive slices of a pack workgroup that share a slot (PackParams::tile_slices), 0: one slot per slice -- the
+// choice of the caller's comment (vc2hip_api.hip): shared slots where a wavefront packs two or four slices
+int vc2_pack_slices_per_tile(const PackParams &p) {
+  if (vc2_pack_image_mode(p.prefix, p.scalar) != 0) return 0;
+  const int W = pack_lanes(p);
+  return W == 64 ? 0 : 4 * (64 / W);
+}
+void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
+  PackParams p = p0;
+  fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
+  p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
+  if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
+#ifdef VC2HIP_ABLATE
+  { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
+#endif
+  const int W = pack_lanes(p);
+  const bool same_c = p.comp_n[1] == p.comp_n[2];
   const int S = 64 / W;
   const bool one_round = p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && same_c;
   p.big_lut = W == 64 && !one_round && same_c && p.comp_n[0] <= 2048 && p.comp_n[1] <= 2048 && 3 * p.depth + 1 <= 32 &&
@@ -962,7 +999,7 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
   vc2_prof_begin(L, "slice_compact", s);
   // lanes per slice from the slot size (an upper bound of the slice size; typical slices are far shorter)
   static const int force = vc2_tune_int("VC2HIP_COMPACT_LANES", 0);
-  const int W = force ? force : (slot_bytes <= 800 ? 16 : (slot_bytes <= 1600 ? 32 : 64));
+  const int W = force ? force : (slot_bytes <= 800 ? 16 : (slot_bytes <= 8192 ? 32 : 64)); // (slots of four UHD slices, 6 KiB: 32 lanes 0.062 ms, 64 0.067; of sixteen HD slices, 12 KiB: 0.047 / 0.044)
   const int per_wg = 256 / W;
   const dim3 grid((n_slices + per_wg - 1) / per_wg, n_pictures);
   if (W == 16) VC2_LAUNCH(L, k_compact<16>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
