@@ -665,14 +665,19 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   // tile_slices: the slices of the workgroup go into its slot back to back (the wavefronts exchange their byte counts over
   // the barrier below), one size per workgroup: the compaction then moves one run of ~1.2 KB per workgroup instead of
   // four of ~290 bytes
-  int wave_total = 0, seg_off = 0; // bytes of the wavefront's slices; of those before this lane's slice
+  // (only the instantiations with several slices per wavefront: the caller shares slots only there, vc2hip_api.hip)
+  const bool tiled = S > 1 && p.tile_slices;
+  int wave_total = total, seg_off = 0; // bytes of the wavefront's slices; of those before this lane's slice
+  if constexpr (S > 1) {
+    wave_total = 0;
 #pragma unroll
-  for (int s2 = 0; s2 < S; ++s2) { const int t = __shfl(total, s2 * W); wave_total += t; if (s2 < seg) seg_off += t; }
-  if ((p.lookback || p.tile_slices) && lane == 0) s_tot[wave] = wave_total;
+    for (int s2 = 0; s2 < S; ++s2) { const int t = __shfl(total, s2 * W); wave_total += t; if (s2 < seg) seg_off += t; }
+  }
+  if ((p.lookback || tiled) && lane == 0) s_tot[wave] = wave_total;
   PACK_STAMP(3);
   __syncthreads();
   PACK_STAMP(4);
-  if (p.tile_slices && threadIdx.x == 0) {
+  if (tiled && threadIdx.x == 0) {
     unsigned all = 0;
     for (int w2 = 0; w2 < nwv; ++w2) all += (unsigned)s_tot[w2];
     p.sizes[(size_t)pic * gridDim.x + tile] = all;
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
       const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
       d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
     }
-  } else if (p.tile_slices) {
+  } else if (tiled) {
     int off = seg_off;
     for (int w2 = 0; w2 < wave; ++w2) off += s_tot[w2];
     uint8_t *dst = p.slots + ((size_t)pic * gridDim.x + tile) * ((size_t)p.tile_slices * p.slot_bytes) + off;
