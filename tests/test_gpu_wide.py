@@ -410,3 +410,31 @@ def test_many_small_slices(variants, oracle, w, h, n_slices):
     fmt, cp = _fmt_cp(hip, w, h, "444", 8, "Haar0", 1, 1, 1, q=3, word_bytes=1)
     assert cp.y_slices * cp.x_slices == n_slices
     _check({"default": hip}, oracle, raw, w, h, "444", 8, "Haar0", 1, 1, 1, q=3, word_bytes=1)
+
+
+def test_cbr_search_trial_with_a_code_beyond_32_bits(hip, oracle):
+    """A picture found by tools/fuzz_geometry.py (seed 1101, wide): 16-bit noise, slices of 2 x 2 samples, HQ_CBR.  With ~28
+    bytes per slice every slice ends at an index of 12 or more and no quantised value exceeds 22214 -- but the trials of
+    quantIndicesCBR (EncodeStream.cpp:73-125) on the way there (15, then 7) quantise LL coefficients of up to 94456 with
+    factor 1, beyond 65534, whose code has more than 32 bits.  The reference only MEASURES it there
+    (SignedVLC::numOfBits in luma_slice_bits, Slices.cpp:51-70): the trial does not fit and the search goes up again.  The
+    GPU's search counted such a code as one bit (and raised the 32-bit-domain error): too small an index, a failure in the
+    slice coder.  (With the fuzz case's own 37 bytes per slice the reference's final indices code values beyond 65534:
+    outside its domain, refused here with the documented error.)"""
+    from test_gpu_parity import _fmt_cp
+    import vc2hip_py
+    w, h = 768, 4
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "cbr_oversize_trial_768x4_444_16bit.raw"), "rb").read()
+    kw = dict(mode="HQ_CBR", s=26000, scalar=2, prefix=0)
+    p = make_params(w, h, "444", 16, "Haar1", 1, 1, 1, word_bytes=2, **kw)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, n = oracle.decode_stream(p, stream, 1)
+    assert n == 1
+    fmt, cp = _fmt_cp(hip, w, h, "444", 16, "Haar1", 1, 1, 1, **kw)   # (the register search hands such slices to the general kernel)
+    payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+    assert stream[:-13].endswith(payload)
+    assert hip.decode_picture(payload, fmt, cp) == dec
+    kw["s"] = 31418
+    fmt, cp = _fmt_cp(hip, w, h, "444", 16, "Haar1", 1, 1, 1, **kw)
+    with pytest.raises(vc2hip_py.Vc2HipError, match="exceeds 65534"):
+        hip.encode_picture_hq(raw, fmt, cp)

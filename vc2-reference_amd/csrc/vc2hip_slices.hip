@@ -187,7 +187,10 @@ __device__ __forceinline__ int component_bits(Src src, int n, int n0, int q, con
           else c = quant_dev(c, aq);
         }
         nb[k] = svlc_bits(c);
-        if (nb[k] > 32) { atomicOr(err, VC2_DEVERR_CODE32); c = 0; nb[k] = 1; }
+        // a code of more than 32 bits (|c| > 65534, VLC.h:27) cannot be written; MEASURED it has its length, as
+        // SignedVLC::numOfBits has in luma_slice_bits (Slices.cpp:51-70): the trials of a quantiser search that meet one
+        // simply do not fit (found by tools/fuzz_geometry.py: 16-bit noise, 2 x 2 slices, HQ_CBR)
+        if (WRITE && nb[k] > 32) { atomicOr(err, VC2_DEVERR_CODE32); c = 0; nb[k] = 1; }
       } else {
         nb[k] = 0;
       }
@@ -237,8 +240,7 @@ __device__ __forceinline__ int component_bits_lds(const int *src, int n, int n0,
         int c = 0;
         if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX);
         else c = quant_dev(v[k], aq);
-        nb = svlc_bits(c);
-        if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); c = 0; nb = 1; }
+        nb = svlc_bits(c); // (measured only: more than 32 bits is a length like any other, see component_bits)
         sum += nb;
         if (c != 0) last_end = sum;
       }
@@ -466,7 +468,7 @@ __device__ __forceinline__ void write8_short(unsigned *img, int pos, int limit, 
 __device__ __forceinline__ void put_byte(unsigned *img, int off, unsigned b) { atomicOr(&img[off >> 2], b << (24 - 8 * (off & 3))); }
 
 
-template <class ST>
+template <class ST, bool TRIAL = false>
 __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, int j0, int n, const unsigned char *band_lut,
                                           const uint4 *qtab, unsigned *err, int &sum, int &last_end);
 
@@ -1014,7 +1016,8 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
 }
 
 // bits of eight coefficients of one component, quantised through the tables: total and end of the last non-zero code
-template <class ST>
+// (TRIAL: a quantiser search's measurement -- a code of more than 32 bits has its length and raises nothing, see component_bits)
+template <class ST, bool TRIAL>
 __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, int j0, int n, const unsigned char *band_lut,
                                           const uint4 *qtab, unsigned *err, int &sum, int &last_end) {
   sum = 0; last_end = 0;
@@ -1043,7 +1046,7 @@ __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, in
     for (int k = 0; k < 8; ++k) { // only the length matters: the sign of the quantised value does not change it
       const unsigned m1 = (unsigned)(qq[k] < 0 ? -qq[k] : qq[k]) + 1u;
       int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2;
-      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
+      if (!TRIAL && nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
       sum += nb;
       if (qq[k] != 0) last_end = sum;
     }
@@ -1052,7 +1055,7 @@ __device__ __forceinline__ void bits8_tab(const ST *src, const int32_t *wide, in
       const uint4 t = qtab[band_lut[j0 + k]];
       const int c = quant_core(St<ST>::load1(src + j0 + k, wide + j0 + k), (int)t.z, t.x, (int)t.y);
       int nb = svlc_bits(c);
-      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
+      if (!TRIAL && nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); nb = 1; }
       sum += nb;
       if (c != 0) last_end = sum;
     }
@@ -1126,11 +1129,11 @@ __global__ __launch_bounds__(256) void k_cbr_search(const CbrParams p) {
     if (fast) {
       if (!set_q(tq)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_QINDEX); }
       int sum, last_end;
-      bits8_tab<int32_t>(co + p.comp_off[0], nullptr, lane * 8, p.comp_n[0], band_y, qtab, p.err, sum, last_end); // luma: one round
+      bits8_tab<int32_t, true>(co + p.comp_off[0], nullptr, lane * 8, p.comp_n[0], band_y, qtab, p.err, sum, last_end); // luma: one round
       int incl = wave_incl_scan(sum, lane);
       need += comp_bytes(wave_max(last_end ? incl - sum + last_end : 0), bad);
       const int half = lane >> 5;                                               // lanes 0-31 U, lanes 32-63 V
-      bits8_tab<int32_t>(co + p.comp_off[1 + half], nullptr, (lane & 31) * 8, p.comp_n[1], band_c, qtab, p.err, sum, last_end);
+      bits8_tab<int32_t, true>(co + p.comp_off[1 + half], nullptr, (lane & 31) * 8, p.comp_n[1], band_c, qtab, p.err, sum, last_end);
       incl = wave_incl_scan(sum, lane);
       const int total_u = __shfl(incl, 31); // every lane takes part in the shuffle
       const int rel = incl - sum - (half ? total_u : 0);
@@ -3174,8 +3177,7 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
         else if (x > 0) pred = up[pitch];
         else pred = 0;
         int qq = quant_core((int)((unsigned)llv[ll0 + i * step] - (unsigned)pred), (int)t.z, t.x, (int)t.y);
-        int nb = svlc_bits(qq);
-        if (nb > 32) { atomicOr(p.err, VC2_DEVERR_CODE32); nb = 1; qq = 0; }
+        const int nb = svlc_bits(qq); // (beyond 32 bits: measured like any other, see component_bits; the slice writer raises the error if such an index is chosen)
         // scale(), Quantisation.cpp:86-95, with the table's factor and offset
         const unsigned mag = qq < 0 ? 0u - (unsigned)qq : (unsigned)qq;
         int r = (int)(mag * t.z);
@@ -3212,19 +3214,15 @@ __device__ __forceinline__ void ld_diag_body(const LdEncParams &p, int d, int rs
       for (int k = 0; k < CPL; ++k)
         if ((int)(a8[k] | (qf8[k] - 2u)) < 0) qq[k] = (int)a8[k] / (int)qf8[k];
     }
-    unsigned big = 0;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) { // only the length matters: the sign of the quantised value does not change it
       const unsigned m1 = (unsigned)(qq[k] < 0 ? -qq[k] : qq[k]) + 1u;
-      int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2;
-      big |= (unsigned)(nb > 32);
-      if (nb > 32) { nb = 1; qq[k] = 0; }
+      const int nb = qq[k] == 0 ? 1 : 2 * (31 - __clz((int)m1)) + 2; // (beyond 32 bits: a length like any other, see component_bits)
       if (j0 + k < n && j0 + k >= n_ll) {
         sum += nb;
         if (qq[k] != 0) le = sum;
       }
     }
-    if (big) atomicOr(p.err, VC2_DEVERR_CODE32);
   };
   // the subbands of candidate slot sl at index tq: coded bits of each stream behind its LL block, up to the last
   // non-zero coefficient
