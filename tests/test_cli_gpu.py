@@ -301,3 +301,36 @@ def test_separate_luma_and_chroma_depths_through_the_tool(tools, oracle, tmp_pat
     run("EncodeStream", *base, tmp_path / "in.raw", tmp_path / "s.vc2")
     stream = (tmp_path / "s.vc2").read_bytes()
     assert stream[-13 - len(want):-13] == want
+
+
+def test_slices_that_run_past_their_data_unit(tools, oracle, tmp_path):
+    # A corrupt stream: the last length byte of a picture's only slice claims two bytes more than the data unit holds.  The
+    # reference parses slices straight from the input stream (DecodeStream.cpp:513), so it reads on into the next parse info
+    # and then resynchronises; the tool does the same (the decoder sees one slice's worth of bytes behind the unit).
+    w, h, frames = 16, 8, 2
+    raw = synth(w, h, "444", 8, 77, frames=frames, word_bytes=1)
+    p = make_params(w, h, "444", 8, "Haar0", 1, 4, 8, q=0, word_bytes=1)
+    stream = bytearray(oracle.encode_stream(p, raw, frames))
+    # first picture: parse info (13) + sequence header, then parse info + picture header + payload [q][ly][Y..][lu][U..][lv][V..]
+    at = 13
+    while stream[at:at + 4] != b"BBCD" or stream[at + 4] != 0xE8:
+        at += 1
+    nxt = int.from_bytes(stream[at + 5:at + 9], "big")
+    pay_end = at + nxt
+    # find the payload start: the slice fills the unit's tail exactly, so walk back from the candidates
+    for start in range(at + 13, pay_end):
+        ly = stream[start + 1]
+        lu_at = start + 2 + ly
+        if lu_at >= pay_end: continue
+        lv_at = lu_at + 1 + stream[lu_at]
+        if lv_at < pay_end and lv_at + 1 + stream[lv_at] == pay_end and stream[start] == 0:
+            break
+    else:
+        raise AssertionError("payload not found")
+    stream[lv_at] += 2
+    stream = bytes(stream)
+    want, n = oracle.decode_stream(p, stream, frames)
+    assert n == frames
+    (tmp_path / "in.vc2").write_bytes(stream)
+    run("DecodeStream", tmp_path / "in.vc2", tmp_path / "dec.raw")
+    assert (tmp_path / "dec.raw").read_bytes() == want

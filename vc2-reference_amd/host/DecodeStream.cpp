@@ -337,7 +337,13 @@ int main(int argc, char *argv[]) {
             if (interlaced) clog << "Reading compressed input field " << pic << " of frame " << frame << endl;
             else clog << "Reading compressed input frame number " << frame << endl;
           }
-          handlePicture(ld, pre, ld ? ldPictureBytes(pre) : 0, body + hdr, dlen < avail - hdr ? dlen : avail - hdr, nullptr);
+          // The reference parses the slices straight from the input stream (DecodeStream.cpp:513): in a corrupt stream
+          // whose length bytes run the last slices past their data unit it reads on into the bytes that follow (and then
+          // looks for the next parse info).  The decoder therefore sees up to one more slice's worth of the input behind
+          // the unit; a valid picture ends where its unit ends and never looks at them.
+          std::size_t visible = dlen;
+          if (!ld) visible += (std::size_t)pre.slice_prefix + 4 + 3 * 255 * (std::size_t)pre.slice_size_scalar;
+          handlePicture(ld, pre, ld ? ldPictureBytes(pre) : 0, body + hdr, visible < avail - hdr ? visible : avail - hdr, nullptr);
           if (output != DECODED) ++frame;
           used = unit;
           break;
