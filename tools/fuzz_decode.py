@@ -1,5 +1,6 @@
-"""Mutation fuzz of the picture decoder (GPU box): valid HQ payloads made by the oracle, a few bytes overwritten at random
-(anywhere: slice headers, length bytes, coefficient data), decoded by the GPU's picture path and by the oracle.  Both must
+"""Mutation fuzz of the picture decoder (GPU box): valid payloads made by the oracle, a few bytes overwritten at random
+(anywhere: slice headers, length bytes, coefficient data), decoded by the GPU's picture path and by the oracle (HQ_ConstQ,
+HQ_CBR -- the decoder's byte-budget short cut and its fall-back -- and LD).  Both must
 either refuse the payload or return the same picture.
 
   python tools/fuzz_decode.py <seed> <cases>"""
@@ -28,7 +29,11 @@ for case in range(count):
     h, w = ys * u * unit, xs * a * unit
     scalar, prefix, q = rnd.choice([1, 2, 4]), rnd.choice([0, 0, 2]), rnd.choice([0, 8, 20])
     raw = (noise_frame if rnd.random() < 0.3 else synth)(w, h, cf, 10, rnd.randrange(1 << 30))
-    kw = dict(q=q, scalar=scalar, prefix=prefix)
+    mode = rnd.choice(["HQ_ConstQ", "HQ_ConstQ", "HQ_CBR", "LD"])
+    ns = ys * xs
+    sbytes = ns * rnd.choice([30, 60, 150]) + rnd.randrange(0, ns)
+    kw = dict(q=q, scalar=scalar, prefix=prefix) if mode == "HQ_ConstQ" else (
+        dict(mode="HQ_CBR", s=sbytes, scalar=rnd.choice([1, 2]), prefix=prefix) if mode == "HQ_CBR" else dict(mode="LD", s=sbytes))
     p = make_params(w, h, cf, 10, kernel, depth, u, a, **kw)
     try:
         stream = oracle.encode_stream(p, raw, 1)
@@ -36,7 +41,14 @@ for case in range(count):
         continue
     fmt = vc2hip_py.picture_format(w, h, cf, 10, 2)
     cp = vc2hip_py.coding_params(hip.lib, fmt, kernel, depth, u, a, **kw)
-    payload0, _ = hip.encode_picture_hq(raw, fmt, cp)
+    try:
+        payload0, _ = hip.encode_picture_hq(raw, fmt, cp)
+    except Exception as e:
+        print("ENCODE", f"{w}x{h} {cf} {kernel} d{depth} u{u} a{a} {kw}", str(e)[:80]); bad += 1
+        continue
+    if not stream[:-13].endswith(payload0):
+        print("ENCODE MISMATCH", f"{w}x{h} {cf} {kernel} d{depth} u{u} a{a} {kw}"); bad += 1
+        continue
     head = stream[:len(stream) - 13 - len(payload0)]
     for m in range(4):
         pay = bytearray(payload0)
