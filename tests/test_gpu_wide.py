@@ -438,3 +438,33 @@ def test_cbr_search_trial_with_a_code_beyond_32_bits(hip, oracle):
     fmt, cp = _fmt_cp(hip, w, h, "444", 16, "Haar1", 1, 1, 1, **kw)
     with pytest.raises(vc2hip_py.Vc2HipError, match="exceeds 65534"):
         hip.encode_picture_hq(raw, fmt, cp)
+
+
+@pytest.mark.parametrize("what", ["luma length beyond the slice", "huge quantiser index in the top row", "both"])
+def test_ld_corrupt_slice_headers_like_the_reference(hip, oracle, what):
+    """Corrupt LD slice headers (tools/fuzz_decode.py).  A luma length field beyond its slice: the reference reads that many
+    bits from the stream (LDSliceIO, Slices.cpp:246-303), so every later slice starts late -- flag, serial walk, second pass
+    in the decoder.  A quantiser index near 127: dequantised LL samples around 2^31, sums of three wrap, and the top row's
+    prediction (the left neighbour) must not go through the three-term formula."""
+    from test_gpu_parity import _fmt_cp
+    w, h, depth, nbytes = 256, 16, 1, 4000
+    raw = synth(w, h, "422", 10, 4242)
+    kw = dict(mode="LD", s=nbytes)
+    p = make_params(w, h, "422", 10, "Haar1", depth, 2, 4, **kw)
+    stream = oracle.encode_stream(p, raw, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "Haar1", depth, 2, 4, **kw)
+    sb = oracle.slice_bytes(cp.y_slices, cp.x_slices, nbytes, 1).ravel()
+    off = np.concatenate([[0], np.cumsum(sb)])
+    pay = bytearray(stream[-13 - nbytes:-13])
+    if what != "huge quantiser index in the top row":
+        for sl in (5, 40):   # luma length 255: beyond the 8 * 31 - 7 - 8 bits a slice has
+            pay[off[sl]] |= 1
+            pay[off[sl] + 1] = 0xFF
+    if what != "luma length beyond the slice":
+        for sl in (9, 17, 18, 70):
+            pay[off[sl]] = (115 << 1) | (pay[off[sl]] & 1)
+    pay = bytes(pay)
+    head, tail = stream[:-13 - nbytes], stream[-13:]
+    want, n = oracle.decode_stream(p, head + pay + tail, 1)
+    assert n == 1
+    assert hip.decode_picture(pay + tail, fmt, cp) == want   # (the reference's reader sees what follows the data unit too)

@@ -66,6 +66,10 @@ for case in range(count):
         if gerr and werr: both_err += 1
         elif gerr or werr or got != want:
             bad += 1
+            if os.environ.get("FUZZ_DUMP") and bad == 1:
+                import pickle
+                pickle.dump(dict(w=w, h=h, cf=cf, kernel=kernel, depth=depth, u=u, a=a, kw=kw, pay=pay, pay0=payload0, head=head, tail=stream[-13:],
+                                 got=got, want=want), open(os.environ["FUZZ_DUMP"], "wb"))
             print("MISMATCH", f"{w}x{h} {cf} {kernel} d{depth} u{u} a{a} {kw} mutation {m}: hip {'err ' + gerr[:60] if gerr else 'ok'} / oracle {'err ' + werr[:60] if werr else 'ok'}")
         else: same += 1
 print(f"seed {seed}: {same} same pictures, {both_err} refused by both, {bad} bad")

@@ -1644,6 +1644,20 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     if (total > payload_stride) return set_err(c, VC2HIP_ESTREAM);
     LdUnpackParams p;
     fill_ld_unpack(p, g, (const uint8_t *)d_payload, (long long)payload_stride, d_sb, d_so, d_store, d_q, c->d_err);
+    // slices whose luma length exceeds the slice (corrupt pictures): flag, serial walk, second pass (LdUnpackParams)
+    unsigned *d_shifted; uint32_t *d_starts;
+    NEED(c, B_SIZES, (size_t)n * 4, d_shifted);
+    NEED(c, B_OFFS, (size_t)n * ns * 4, d_starts);
+    int flag_fill = 0;
+#ifdef VC2HIP_ABLATE
+    if (getenv("VC2HIP_DEBUG_LD_REDO")) flag_fill = 1; // every picture takes the walk and the second pass (tests of that path on valid streams)
+#endif
+    HIPCHK(c, hipMemsetAsync(d_shifted, flag_fill, (size_t)n * 4, c->stream));
+    vc2_prof_break(c->L);
+    p.lens = (const unsigned long long *)d_lens; p.shifted = d_shifted; p.starts = d_starts;
+    vc2_launch_ld_unpack(c->L, p, n, c->stream);
+    vc2_launch_ld_walk(c->L, p, n, c->stream);
+    p.redo = 1;
     vc2_launch_ld_unpack(c->L, p, n, c->stream);
     LdLl3Params lp;
     lp.store = d_store; lp.store_stride = (long long)ns * g.slice_coefs; lp.slice_coefs = g.slice_coefs;

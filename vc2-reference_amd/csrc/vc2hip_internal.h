@@ -319,8 +319,18 @@ struct LdUnpackParams {
   int n_slices, slice_coefs;
   int comp_n[3], comp_off[3];
   unsigned *err;
+  // A slice whose luma length field exceeds the slice (corrupt data; also what the reference's decoder makes of its own
+  // interlaced LD streams, DecodeStream.cpp:331): the reference reads that many bits from the stream (Slices.cpp:246-303),
+  // so every later slice of the picture starts late.  The first pass decodes at the nominal offsets and raises the
+  // picture's flag when it meets such a slice; a serial walk then finds the true starts of a flagged picture and a second
+  // pass decodes it again from those (both return at once for pictures without the flag).
+  const unsigned long long *lens; // per picture: payload bytes the decoder may look at (null: payload_stride)
+  unsigned *shifted;              // per picture: flag (null: no such handling, slices stay at their nominal offsets)
+  uint32_t *starts;               // per picture x slice: true start offsets of a flagged picture
+  int redo;                       // the second pass
 };
 void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s);
+void vc2_launch_ld_walk(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s);
 
 // LD encode: quantiser search / DC-predicted quantisation (one launch per slice anti-diagonal) and
 // the slice writer

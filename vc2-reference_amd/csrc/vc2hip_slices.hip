@@ -2512,32 +2512,40 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
   __shared__ __attribute__((aligned(16))) int stage[4][64 * UNP_PITCH];
   __shared__ unsigned long long outp[4][64];
   __shared__ unsigned short vlut[1024];
+  const int pic = blockIdx.y;
+  if (p.redo && !p.shifted[pic]) return; // (the second pass: only pictures with a slice whose luma length exceeds the slice)
   vlut_init(vlut);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x * 256 + threadIdx.x, pic = blockIdx.y;
+  const int slice = blockIdx.x * 256 + threadIdx.x;
   const bool chroma = blockIdx.z != 0; // the two streams of a slice are independent once the header is read: a lane each
   const bool active = slice < p.n_slices;
   int *st = stage[wave] + lane * UNP_PITCH;
   const int *sw = stage[wave];
   const uint8_t *data = nullptr;
   int ystart = 0, ybits = 0, total = 0; // bit positions inside the slice
+  long long vis = 0;                     // bytes of the payload from the slice's start on that the decoder may look at
   if (active) {
     const int size = p.slice_bytes[slice];
-    data = p.payload + (size_t)pic * p.payload_stride + p.offsets[slice];
+    const unsigned off = p.redo ? p.starts[(size_t)pic * p.n_slices + slice] : p.offsets[slice];
+    const long long plen = p.lens ? (long long)min(p.lens[pic], (unsigned long long)p.payload_stride) : p.payload_stride;
+    vis = max(plen - (long long)off, 0ll);
+    data = p.payload + (size_t)pic * p.payload_stride + min((long long)off, plen);
     unsigned head = 0; // 7 bits of quantiser index, then intlog2(8*size-7) bits of luma length: at most 30 bits
-    for (int k = 0; k < 4; ++k) head = (head << 8) | (k < size ? data[k] : 0xFFu);
+    for (int k = 0; k < 4; ++k) head = (head << 8) | (k < min((long long)(p.redo ? 4 : size), vis) ? data[k] : 0xFFu);
     if (!chroma) p.qidx[(size_t)pic * p.n_slices + slice] = (int)(head >> 25);
     const int split = intlog2_dev(8 * size - 7);
     ybits = split ? (int)((head << 7) >> (32 - split)) : 0;
     ystart = 7 + split;
     total = 8 * size;
+    if (!p.redo && p.shifted && !chroma && ybits > total - ystart) atomicOr(&p.shifted[pic], 1u);
     outp[wave][lane] = (unsigned long long)(p.store + (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs);
   } else outp[wave][lane] = 0;
   WordReader br;
-  // luma: ybits bits from ystart; bits past the slice read as 1 like bits past the bound (VLC.cpp:182-185)
+  // luma: ybits bits from ystart; bits past the slice read as 1 like bits past the bound (VLC.cpp:182-185).  Second pass:
+  // the reference's reader goes on into the bytes behind the slice (bits past the payload read as 1)
   if (!chroma) {
-    const int nb = min(ybits, total - ystart);
+    const int nb = p.redo ? (int)min((long long)ybits, 8 * vis - ystart) : min(ybits, total - ystart);
     if (active && nb > 0) br.init_bits(data + (ystart >> 3), ystart & 7, nb); else br.init_ones();
   }
   const int ny = chroma ? 0 : p.comp_n[0];
@@ -2562,7 +2570,7 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
   // chroma: the rest of the slice, U and V coefficients alternating
   if (chroma) {
     const int cstart = ystart + ybits;
-    const int nb = total - cstart;
+    const int nb = p.redo ? (int)min((long long)(total - cstart), 8 * vis - cstart) : total - cstart;
     if (active && nb > 0 && ybits >= 0) br.init_bits(data + (cstart >> 3), cstart & 7, nb); else br.init_ones();
   }
   const int nc = chroma ? 2 * p.comp_n[1] : 0;
@@ -2588,6 +2596,33 @@ __global__ __launch_bounds__(256) void k_ld_unpack(const LdUnpackParams p) {
 void vc2_launch_ld_unpack(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s) {
   vc2_prof_begin(L, "ld_unpack", s);
   VC2_LAUNCH(L, k_ld_unpack, dim3((p.n_slices + 255) / 256, n_pictures, 2), dim3(256), 0, s, p);
+  vc2_prof_end(L, s);
+}
+// The true slice starts of a picture whose flag is up: one lane follows the reference's reader through the slice
+// headers (LDSliceIO, Slices.cpp:246-303: 7 bits of index, the luma length, that many bits of luma, the rest of the slice --
+// if any is left -- of chroma, then the next byte boundary).  Three dependent loads per slice, for corrupt pictures only.
+// A picture that runs past its payload is the reference's "Failed to read LD compressed frame".
+__global__ __launch_bounds__(64) void k_ld_walk(const LdUnpackParams p) {
+  const int pic = blockIdx.x;
+  if (!p.shifted[pic] || threadIdx.x != 0) return;
+  const uint8_t *pay = p.payload + (size_t)pic * p.payload_stride;
+  const unsigned long long plen = p.lens ? min(p.lens[pic], (unsigned long long)p.payload_stride) : (unsigned long long)p.payload_stride;
+  unsigned long long pos = 0;
+  for (int si = 0; si < p.n_slices; ++si) {
+    const int size = p.slice_bytes[si];
+    p.starts[(size_t)pic * p.n_slices + si] = (uint32_t)min(pos, plen);
+    unsigned head = 0;
+    for (int k = 0; k < 4; ++k) head = (head << 8) | (pos + k < plen ? pay[pos + k] : 0xFFu);
+    const int split = intlog2_dev(8 * size - 7);
+    const long long ybits = split ? (long long)((head << 7) >> (32 - split)) : 0;
+    const long long uvbits = 8ll * size - 7 - split - ybits;
+    pos += (unsigned long long)((7 + split + ybits + max(uvbits, 0ll) + 7) >> 3);
+  }
+  if (pos > plen) atomicOr(p.err, VC2_DEVERR_STREAM);
+}
+void vc2_launch_ld_walk(Launcher &L, const LdUnpackParams &p, int n_pictures, hipStream_t s) {
+  vc2_prof_begin(L, "ld_unpack", s);
+  VC2_LAUNCH(L, k_ld_walk, dim3(n_pictures), dim3(64), 0, s, p);
   vc2_prof_end(L, s);
 }
 
@@ -2641,7 +2676,10 @@ __global__ __launch_bounds__(1024) void k_ld_ll(const int32_t *store, long long 
 //     goes into the upper-left term and B / 3 comes off the residual, both known a step early: add3, mul_hi, shift, add.
 //     (s = INT_MIN, where this differs, and s = INT_MAX, where the reference's s + 1 overflows, need |samples| ~ 2^30.)
 //   * column 0 (prediction = the sample above) is a prefix sum down the column, done first; row 0 (prediction = the
-//     sample to the left) is the formula with left standing in for up and upper-left: floor((3 l + 1) / 3) = l.
+//     sample to the left) is a select in the lane that owns it.
+#ifndef VC2_LD_LL_WAVE_MAXR
+#define VC2_LD_LL_WAVE_MAXR 4 // rows per lane up to which a plane goes to ld_ll_wave (0: every plane takes the anti-diagonal sweep)
+#endif
 template <int R> __device__ __forceinline__ void ld_ll_wave(int *rs, int llh, int llw) {
   constexpr unsigned BIAS = 0x7FFFFFFEu, BIAS3 = BIAS / 3u;
   const int lane = threadIdx.x, y0 = lane * R, nl = (llh + R - 1) / R;
@@ -2674,10 +2712,12 @@ template <int R> __device__ __forceinline__ void ld_ll_wave(int *rs, int llh, in
       const int xn = min(x + 1, llw - 1);
 #pragma unroll
       for (int r = 0; r < R; ++r) nres[r] = (unsigned)rs[row[r] + xn] - BIAS3; // (column x + 1 is the next step's: not yet overwritten)
-      unsigned ul = (top ? left[0] : prev_up) + (BIAS + 1u), up = top ? left[0] : up_in;
+      unsigned ul = prev_up + (BIAS + 1u), up = up_in;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const unsigned a = res[r] + (__umulhi(ul + up + left[r], 0xAAAAAAABu) >> 1);
+        unsigned d3 = __umulhi(ul + up + left[r], 0xAAAAAAABu) >> 1;
+        if (r == 0) d3 = top ? left[0] + BIAS3 : d3; // row 0 of the plane: the sample to the left (a select; the formula with left standing in for up and upper-left wraps for |left| > 2^31 / 3, as corrupt streams' indices make it)
+        const unsigned a = res[r] + d3;
         if (ok[r]) rs[row[r] + x] = (int)a;
         ul = left[r] + (BIAS + 1u);
         left[r] = a;
@@ -2769,7 +2809,7 @@ __device__ __forceinline__ void ld_ll_lds_body(int pic, const int32_t *store, lo
     // instructions each) instead of a workgroup barrier and an LDS round trip per anti-diagonal of blocks:
     // 16 HD pictures 0.148 -> ... ms.
     const int R = (llh + 63) / 64;
-    if (R <= 4) {
+    if (R <= VC2_LD_LL_WAVE_MAXR) {
       if (threadIdx.x < 64) {
         if (R == 1) ld_ll_wave<1>(rs, llh, llw);
         else if (R == 2) ld_ll_wave<2>(rs, llh, llw);

@@ -343,6 +343,11 @@ int main(int argc, char *argv[]) {
           // the unit; a valid picture ends where its unit ends and never looks at them.
           std::size_t visible = dlen;
           if (!ld) visible += (std::size_t)pre.slice_prefix + 4 + 3 * 255 * (std::size_t)pre.slice_size_scalar;
+          else { // LD: a luma length field beyond its slice makes the reference's reader run on (Slices.cpp:246-303); a
+                 // slice of n bytes can claim fewer than 2 * (8 n - 7) bits, so twice the budget bounds what it looks at
+            const std::size_t reach = 2 * (std::size_t)ldPictureBytes(pre) + 2 * (std::size_t)pre.slices_y * pre.slices_x + 16;
+            if (reach > visible) visible = reach;
+          }
           handlePicture(ld, pre, ld ? ldPictureBytes(pre) : 0, body + hdr, visible < avail - hdr ? visible : avail - hdr, nullptr);
           if (output != DECODED) ++frame;
           used = unit;
