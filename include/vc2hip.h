@@ -115,7 +115,10 @@ int vc2hip_hq_pack(vc2hip_ctx *ctx, const int32_t *y, const int32_t *u, const in
 int vc2hip_hq_unpack(vc2hip_ctx *ctx, const uint8_t *in, size_t len, const vc2hip_geom *g,
                      int prefix, int scalar, int32_t *y, int32_t *u, int32_t *v, int32_t *qidx,
                      size_t *consumed);
-/* operator>>(istream&, Slices&) under sliceio::lowDelay(bytes), Slices.cpp:246-303 */
+/* operator>>(istream&, Slices&) under sliceio::lowDelay(bytes), Slices.cpp:246-303.  Every slice is read at its own
+ * offset (the running sum of slice_bytes): a corrupt slice whose luma length field exceeds the slice does not move the
+ * slices behind it as the reference's stream reader would -- vc2hip_decode_picture_ld / vc2hip_decode_batch_dev follow
+ * the reference there. */
 int vc2hip_ld_unpack(vc2hip_ctx *ctx, const uint8_t *in, size_t len, const vc2hip_geom *g,
                      const int32_t *slice_bytes, int32_t *y, int32_t *u, int32_t *v,
                      int32_t *qidx, size_t *consumed);
