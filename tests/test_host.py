@@ -59,3 +59,48 @@ def test_tools_fail_loudly_without_gpu(tools, tmp_path):
     cmd = [os.path.join(tools, "EncodeStream")] + BASE + ["-q", "3", str(src), str(tmp_path / "out.vc2")]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode != 0 and "no CPU fallback" in out.stdout
+
+
+# ---- the reference's own sources built against host/*.h, from where they lie (build container only) ----------------
+REF = "/root/reference"
+HOST = os.path.join(ROOT, "vc2-reference_amd", "host")
+CXX = ["g++", "-O1", "-std=c++14", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + HOST]
+HOSTSRC = [os.path.join(HOST, f) for f in ("Arrays.cpp", "Picture.cpp")]
+needs_reference = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "src/Library/src/Frame.cpp")),
+                                     reason="reference checkout absent (GPU box): nothing of it is stored in this repository")
+
+
+@needs_reference
+def test_reference_frame_cpp_builds_against_host_headers_and_agrees(tmp_path):
+    """src/Library/src/Frame.cpp (constructors, field accessors written with indices[Range(top, bottom, 2)][Range()]
+    views as l- and r-values) is compiled unmodified against host/Frame.h, Picture.h, Arrays.h and linked with
+    host/frametest.cpp; the same driver linked with host/Frame.cpp must print the same 90 lines."""
+    outs = []
+    for name, frame_cpp in (("ours", os.path.join(HOST, "Frame.cpp")), ("ref", os.path.join(REF, "src/Library/src/Frame.cpp"))):
+        exe = str(tmp_path / ("frametest_" + name))
+        subprocess.check_call(CXX + ["-o", exe, os.path.join(HOST, "frametest.cpp"), frame_cpp] + HOSTSRC)
+        outs.append(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+    assert outs[0].count("\n") == 90 and outs[0] == outs[1]
+
+
+@needs_reference
+def test_reference_quant_indices_constq_builds_against_host_headers(tmp_path):
+    """The body of quantIndicesConstQ is cut out of /root/reference/src/EncodeStream/EncodeStream.cpp at test time (into
+    the pytest temp directory, never into the repository) and compiled against host/*.h: extents[a][b] construction,
+    data(), num_elements(), return by value."""
+    import re
+    text = open(os.path.join(REF, "src/EncodeStream/EncodeStream.cpp")).read()
+    m = re.search(r"^const Array2D quantIndicesConstQ\(.*?^}\n", text, re.S | re.M)
+    assert m, "quantIndicesConstQ not found in the reference"
+    (tmp_path / "region.inc").write_text(m.group(0))
+    (tmp_path / "tu.cpp").write_text(
+        '#include <algorithm>\n#include <cstdio>\n#include "Picture.h"\n#include "region.inc"\n'
+        "int main() {\n"
+        "  Array1D m(extents[7]);\n"
+        "  const Array2D q = quantIndicesConstQ(Picture(), 3, 5, m, 21);\n"
+        "  bool ok = q.shape()[0] == 3 && q.shape()[1] == 5;\n"
+        "  for (int v = 0; v < 3; ++v) for (int h = 0; h < 5; ++h) ok = ok && q[v][h] == 21;\n"
+        '  std::puts(ok ? "ok" : "bad");\n  return ok ? 0 : 1;\n}\n')
+    exe = str(tmp_path / "constq")
+    subprocess.check_call(CXX + ["-I" + str(tmp_path), "-o", exe, str(tmp_path / "tu.cpp")] + HOSTSRC)
+    assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "ok"

@@ -58,6 +58,10 @@ struct ArrayIndices2D { Range r[2]; };
 struct Indices1 { Range r0; ArrayIndices2D operator[](const Range &b) const { ArrayIndices2D i; i.r[0] = r0; i.r[1] = b; return i; } };
 struct IndexGen { Indices1 operator[](const Range &a) const { Indices1 i; i.r0 = a; return i; } };
 static const IndexGen indices = IndexGen();
+// The reference's Arrays.h:17-18 imports both generators from namespace boost, and some of its sources say
+// `using boost::indices;` again inside a function (Frame.cpp:51).  The qualified names resolve to the objects above,
+// so such call sites build against this header unchanged.  (Names only: there is no Boost here and none is imitated.)
+namespace boost { using ::extents; using ::indices; }
 
 class View2D;
 class Array2D {

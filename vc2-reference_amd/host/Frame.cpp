@@ -9,56 +9,6 @@ PictureFormat fieldFormat(const PictureFormat &f) {
   return PictureFormat(f.lumaHeight() / 2, f.lumaWidth(), f.chromaFormat());
 }
 
-// ---- Frame: the reference's bodies (Frame.cpp:40-94), expression for expression, on host/Arrays.h
-const Picture Frame::topField() const {
-  // Get parameters of field
-  const int height = format().lumaHeight() / 2;
-  const int width = format().lumaWidth();
-  const ColourFormat chromaFormat = format().chromaFormat();
-  // Construct interlaced field
-  Picture picture(PictureFormat(height, width, chromaFormat));
-  // Set components of interlaced field
-  const int top = 0;
-  const int yBottom = format().lumaHeight();
-  const int uvBottom = format().chromaHeight();
-  picture.y(y()[indices[Range(top, yBottom, 2)][Range()]]);
-  picture.c1(c1()[indices[Range(top, uvBottom, 2)][Range()]]);
-  picture.c2(c2()[indices[Range(top, uvBottom, 2)][Range()]]);
-  return picture;
-}
-
-void Frame::topField(const Picture &f) {
-  const int top = 0;
-  const int yBottom = format().lumaHeight();
-  const int uvBottom = format().chromaHeight();
-  luma[indices[Range(top, yBottom, 2)][Range()]] = f.y();
-  chroma1[indices[Range(top, uvBottom, 2)][Range()]] = f.c1();
-  chroma2[indices[Range(top, uvBottom, 2)][Range()]] = f.c2();
-}
-
-const Picture Frame::bottomField() const {
-  const int height = format().lumaHeight() / 2;
-  const int width = format().lumaWidth();
-  const ColourFormat chromaFormat = format().chromaFormat();
-  Picture picture(PictureFormat(height, width, chromaFormat));
-  const int top = 1;
-  const int yBottom = format().lumaHeight();
-  const int uvBottom = format().chromaHeight();
-  picture.y(y()[indices[Range(top, yBottom, 2)][Range()]]);
-  picture.c1(c1()[indices[Range(top, uvBottom, 2)][Range()]]);
-  picture.c2(c2()[indices[Range(top, uvBottom, 2)][Range()]]);
-  return picture;
-}
-
-void Frame::bottomField(const Picture &f) {
-  const int top = 1;
-  const int yBottom = format().lumaHeight();
-  const int uvBottom = format().chromaHeight();
-  luma[indices[Range(top, yBottom, 2)][Range()]] = f.y();
-  chroma1[indices[Range(top, uvBottom, 2)][Range()]] = f.c1();
-  chroma2[indices[Range(top, uvBottom, 2)][Range()]] = f.c2();
-}
-
 static Array2D rowsOf(const Array2D &a, int first) {
   const Index h = a.shape()[0], w = a.shape()[1];
   Array2D out((h - first + 1) / 2, w);
@@ -103,3 +53,28 @@ void extractFieldRaw(const unsigned char *frame, const PictureFormat &f, int wor
 void insertFieldRaw(unsigned char *frame, const PictureFormat &f, int wordBytes, bool top, const unsigned char *field) {
   fieldRaw<false>(frame, f, wordBytes, top, const_cast<unsigned char *>(field));
 }
+
+// ---- class Frame (surface: Frame.h:18-40).  A field is every second row of each plane; all four accessors are the two
+// row-copy helpers above with the parity of the first row chosen by the caller.
+Frame::Frame(int height, int width, ColourFormat cf, bool interlaced, bool topFieldFirst)
+    : Picture(PictureFormat(height, width, cf)), intl(interlaced), tff(topFieldFirst) {}
+Frame::Frame(const PictureFormat &f, bool interlaced, bool topFieldFirst) : Picture(f), intl(interlaced), tff(topFieldFirst) {}
+bool Frame::interlaced() const { return intl; }
+void Frame::interlaced(bool on) { intl = on; }
+bool Frame::topFieldFirst() const { return tff; }
+void Frame::topFieldFirst(bool on) { tff = on; }
+
+const Picture Frame::topField() const { return fieldOf(*this, true); }
+const Picture Frame::bottomField() const { return fieldOf(*this, false); }
+void Frame::topField(const Picture &field) {
+  setRows(luma, field.y(), 0); setRows(chroma1, field.c1(), 0); setRows(chroma2, field.c2(), 0);
+}
+void Frame::bottomField(const Picture &field) {
+  setRows(luma, field.y(), 1); setRows(chroma1, field.c1(), 1); setRows(chroma2, field.c2(), 1);
+}
+const Picture Frame::firstField() const { return fieldOf(*this, tff); }
+const Picture Frame::secondField() const { return fieldOf(*this, !tff); }
+void Frame::firstField(const Picture &field) { if (tff) topField(field); else bottomField(field); }
+void Frame::secondField(const Picture &field) { if (tff) bottomField(field); else topField(field); }
+const Picture &Frame::frame() const { return *this; }
+void Frame::frame(const Picture &whole) { Picture::operator=(whole); }

@@ -5,28 +5,33 @@
 #define VC2HOST_FRAME_H
 #include "Picture.h"
 
-// The reference's Frame (Frame.h, Frame.cpp:40-110): a Picture whose fields are views of alternate rows.  The bodies
-// in Frame.cpp are written with the reference's own expressions (y()[indices[Range(top, bottom, 2)][Range()]]).
+// Frame: a Picture that also knows whether it is interlaced and which field comes first.  The class surface is the
+// reference's (Frame.h:18-40: same member functions, out of line, same data member names), so that a translation unit
+// written against the reference's header -- the reference's own src/Frame.cpp included -- builds against this one
+// (tests/test_host.py compiles it from /root/reference when that checkout exists).  The bodies in host/Frame.cpp are
+// ours: whole-row copies through fieldOf / setField below.
 class Frame : public Picture {
  public:
-  Frame(const PictureFormat &f, bool interlaced = false, bool topFieldFirst = true) : Picture(f), ilaced(interlaced), tff(topFieldFirst) {}
-  bool interlaced() const { return ilaced; }
-  void interlaced(bool i) { ilaced = i; }
-  bool topFieldFirst() const { return tff; }
-  void topFieldFirst(bool t) { tff = t; }
+  Frame(int height, int width, ColourFormat, bool interlaced = false, bool topFieldFirst = true);
+  Frame(const PictureFormat &, bool interlaced = false, bool topFieldFirst = true);
+  bool interlaced() const;
+  void interlaced(bool);
+  bool topFieldFirst() const;
+  void topFieldFirst(bool);
   const Picture topField() const;
-  void topField(const Picture &f);
+  void topField(const Picture &);
   const Picture bottomField() const;
-  void bottomField(const Picture &f);
-  const Picture firstField() const { return tff ? topField() : bottomField(); }
-  void firstField(const Picture &f) { if (tff) topField(f); else bottomField(f); }
-  const Picture secondField() const { return tff ? bottomField() : topField(); }
-  void secondField(const Picture &f) { if (tff) bottomField(f); else topField(f); }
-  const Frame &frame() const { return *this; }
-  void frame(const Picture &p) { y(p.y()); c1(p.c1()); c2(p.c2()); }
+  void bottomField(const Picture &);
+  const Picture firstField() const;
+  void firstField(const Picture &);
+  const Picture secondField() const;
+  void secondField(const Picture &);
+  const Picture &frame() const;
+  void frame(const Picture &);
 
  private:
-  bool ilaced, tff;
+  bool intl;
+  bool tff;
 };
 
 // format of one field of a frame (Frame.cpp:41-44: half the luma height; chroma follows the colour format)

@@ -19,20 +19,6 @@
 static int failures = 0;
 #define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
 
-// quantIndicesConstQ exactly as the reference writes it (/root/reference/src/EncodeStream/EncodeStream.cpp:128-138)
-const Array2D quantIndicesConstQ(const Picture& coefficients,
-                                 const int ySlices, const int xSlices,
-                                 const Array1D& qMatrix,
-                                 const int qIndex) {
-  (void)coefficients; (void)qMatrix;
-  // Create an empty array of indices to fill and return
-  Array2D indices(extents[ySlices][xSlices]);
-
-  std::fill(indices.data(), indices.data()+indices.num_elements(), qIndex);
-
-  return indices;
-}
-
 static std::string thrown(void (*f)()) { try { f(); } catch (const std::logic_error &e) { return e.what(); } return "<no exception>"; }
 
 int main() {
@@ -95,9 +81,10 @@ int main() {
     EXPECT(shape(blocks)[0] == 2 && shape(blocks)[1] == 3 && blocks[1][2][2][7] == 57);
     BlockVector bands(extents[4]);
     EXPECT(bands.size() == 4);
-    const Array2D q = quantIndicesConstQ(Picture(), 3, 5, m, 21);
+    Array2D q(extents[3][5]);                                            // the fill idiom of EncodeStream.cpp:128-138
+    std::fill(q.data(), q.data() + q.num_elements(), 21);
     EXPECT(q.shape()[0] == 3 && q.shape()[1] == 5 && q[2][4] == 21 && q[0][0] == 21);
-    // Frame (Frame.cpp:40-94): fields are alternate rows; writing both fields back restores the frame
+    // Frame (Frame.h:18-40): fields are alternate rows; writing both fields back restores the frame
     Frame fr(PictureFormat(6, 8, CF420), true, false);
     Array2D y(extents[6][8]), u(extents[3][4]);
     for (Index r = 0; r < 6; ++r) for (Index c = 0; c < 8; ++c) y[r][c] = (int)(100 * r + c);
