@@ -165,7 +165,10 @@ struct PackParams {
   int quantise;               // 0: store already holds quantised values (fine-grained API)
   int big_lut;                // set by the launcher: LDS holds subband tables for components of up to 2048 coefficients
   float inv_scalar;           // set by the launcher: the smallest float >= 1 / scalar
-  unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
+  union {
+    unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
+    unsigned lane16[128];        // k_hq_pack16 (vc2hip_pack16.h): per lane, where its coefficients lie and their matrix entries
+  };
   int debug_skip;             // timing experiments only (VC2HIP_DEBUG_PACK): 1 no code writes, 2 no copy-out
   // single-pass VBR: slice offsets by decoupled look-back over workgroup tiles (4 slices each).
   // lookback: per picture [0] = tile ticket, [1 + t] = status of tile t: flag (2 bits) << 62 | bytes
@@ -234,7 +237,10 @@ struct CbrParams {
   int only_marked;            // set by the launcher: search only the slices whose index is VC2_CBR_MARK
   float inv_scalar;           // set by the launcher
   int qm_min;                 // set by the launcher: the smallest matrix entry
-  unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
+  union {
+    unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
+    unsigned lane16[128];        // k_hq_pack16 (vc2hip_pack16.h): per lane, where its coefficients lie and their matrix entries
+  };
 };
 #define VC2_CBR_MARK 0x7FFFFFFF
 

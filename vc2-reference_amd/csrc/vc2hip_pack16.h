@@ -1,0 +1,329 @@
+// k_hq_pack16 -- the HQ slice coder for the common slice geometry on the 16-bit coefficient store: ONE round per slice,
+// sixteen coefficients per lane.  (Included by vc2hip_slices.hip behind its scalar helpers; same reference functions:
+// HQSliceIO_VBR / _CBR Slices.cpp:305-382, :469-533, component_slice_bytes :97-119, quant Quantisation.cpp:69-76,
+// SignedVLC VLC.cpp:21-52, bounded write / flush VLC.cpp:151-213.)
+//
+// Why another kernel: k_hq_pack spends ~47 vector instructions per coefficient and lane (two rounds of eight coefficients,
+// per-coefficient subband look-ups, a scan and a set of reductions per round, eight codes and eight lengths alive per
+// round) and is bound by instruction issue, not by its 1.02 x algorithmic traffic (profiles/r03_*).  Here
+//   * a component record is split by the host into a HEAD -- the leading subbands whose blocks are not multiples of sixteen
+//     coefficients (LL and the deepest levels: 32 luma / 16 chroma coefficients for 32 x 16 slices at depth 4) -- coded one
+//     coefficient per lane with the code computed arithmetically (any magnitude up to the reference's 32-bit code limit),
+//     and a BODY of whole sixteen-coefficient runs that lie inside one subband each: a lane's sixteen coefficients share one
+//     quantiser factor (no per-coefficient subband look-up), luma on lanes 0-31, U on 32-47, V on 48-63;
+//   * quantise = one float multiply and one truncating conversion of the SIGNED value (exact: |v| < 2^15, see
+//     k_cbr_search_reg's proof for |v| < 2^20), the low byte of the quotient indexes a 256-entry table of
+//     (length << 24 | code with its sign bit) -- address, code and length without shifts or sign handling;
+//   * codes are merged pair-wise in 32-bit registers (two codes of <= 14 bits), pairs into quads and quads into ONE string of
+//     <= 64 bits per eight coefficients; only the two strings, their lengths and the end of the last non-zero code survive;
+//   * head and body bit counts share one DPP scan (packed 16 + 16 bits), the component lengths come from a ballot and a
+//     v_readlane of the last lane that has a non-zero coefficient (positions grow with the lane number), so every
+//     per-slice quantity is a scalar;
+//   * anything outside that domain -- a body quotient beyond +-126, a string of more than 64 bits per eight coefficients, an
+//     escape of the 16-bit store -- sends the WHOLE slice (wave-uniform) through component_bits, the general two-pass
+//     coder of this file: correct for every input, about three times slower for that slice.
+// The launcher (vc2_launch_pack) chooses this kernel when pack16_plan() accepts the geometry; every other geometry, the
+// int32 store, unquantised input, look-back VBR and images beyond LDS keep k_hq_pack.
+#pragma once
+
+constexpr int P16_LUT_N = 256;            // quotient as a signed byte: entries 0..127 = +0..+127, 128..255 = -128..-1
+constexpr int P16_MAXQ = 126;             // |quotient| the table path takes: codes of <= 14 bits, pairs of <= 28
+__device__ unsigned g_vlc_lut_s[P16_LUT_N]; // length << 24 | code (sign bit included); zero: 1 << 24 | 1
+
+static void fill_vlc_lut_s(unsigned *host) {
+  for (int i = 0; i < P16_LUT_N; ++i) {
+    const int t = i < 128 ? i : i - 256;
+    const unsigned m = (unsigned)(t < 0 ? -t : t);
+    unsigned code = 1, nb = 1;
+    if (m) {
+      const unsigned v = m + 1;
+      int k = 31;
+      while (!((v >> k) & 1u)) --k;
+      code = 0;
+      for (int b = k - 1; b >= 0; --b) code = (code << 2) | ((v >> b) & 1u);
+      code = (((code << 1) | 1u) << 1) | (t < 0 ? 1u : 0u); // (0 b)* 1 s
+      nb = 2 * (unsigned)k + 2;
+    }
+    host[i] = (nb << 24) | code;
+  }
+}
+
+static void vc2_upload_vlc_lut_s(hipStream_t s) {
+  static unsigned host[P16_LUT_N];
+  static std::once_flag once;
+  std::call_once(once, [] { fill_vlc_lut_s(host); });
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_vlc_lut_s), host, sizeof host, 0, hipMemcpyHostToDevice, s);
+}
+
+// ---- host: which lanes take what -----------------------------------------------------------------------------------
+// lane16[2 * lane]     = element offset of the lane's sixteen body coefficients | element offset of its head coefficient
+//                        << 16 (0xFFFF: none), both from the start of the slice record
+// lane16[2 * lane + 1] = quantisation-matrix entry of the body run | of the head coefficient << 8
+static bool pack16_plan(const PackParams &p, unsigned *lane16) {
+  if (!p.store16 || !p.quantise || p.lookback || p.tile_slices) return false;
+  if (p.slice_coefs > 0xFFF0) return false;
+  const int lo[3] = {0, 32, 48}, width[3] = {32, 16, 16};
+  for (int l = 0; l < 64; ++l) { lane16[2 * l] = 0xFFFFFFFFu; lane16[2 * l + 1] = 0; }
+  int body_lanes = 0;
+  for (int c = 0; c < 3; ++c) {
+    const int n = p.comp_n[c], n0 = p.comp_n0[c];
+    if (n <= 0 || n0 <= 0 || (p.comp_off[c] & 7)) return false;
+    // subband b covers [start, start + size): LL, then three bands per level from the deepest, each level four times larger
+    int start = 0, head = -1;
+    for (int b = 0; b < 3 * p.depth + 1; ++b) {
+      const int size = b == 0 ? n0 : n0 << (2 * ((b - 1) / 3));
+      if (p.qmatrix[b] < 0 || p.qmatrix[b] > 255) return false;
+      if (head < 0 && (size & 15) == 0 && (start & 15) == 0) head = start; // this band and all behind it: whole runs of 16
+      if (head < 0) {
+        for (int j = start; j < start + size; ++j) {
+          if (j >= width[c]) return false; // more head coefficients than the component has lanes
+          unsigned &e = lane16[2 * (lo[c] + j)], &m = lane16[2 * (lo[c] + j) + 1];
+          e = (e & 0x0000FFFFu) | ((unsigned)(p.comp_off[c] + j) << 16);
+          m |= (unsigned)p.qmatrix[b] << 8;
+        }
+      } else {
+        for (int j = start; j < start + size; j += 16) {
+          const int bl = (j - head) / 16;
+          if (bl >= width[c]) return false;
+          unsigned &e = lane16[2 * (lo[c] + bl)], &m = lane16[2 * (lo[c] + bl) + 1];
+          e = (e & 0xFFFF0000u) | (unsigned)(p.comp_off[c] + j);
+          m |= (unsigned)p.qmatrix[b];
+          ++body_lanes;
+        }
+      }
+      start += size;
+    }
+    if (start != n) return false;
+    if (head < 0) head = n;
+    if (head & 7) return false; // the body's 16-byte loads
+  }
+  return body_lanes >= 40; // fewer: the slices are small, k_hq_pack puts two or four of them on a wavefront
+}
+
+// ---- device ----------------------------------------------------------------------------------------------------------
+// eight coefficients (four dwords of 16-bit pairs) -> one string: G (right aligned), its length L, end of the last non-zero code
+__device__ __forceinline__ void p16_group(const uint4 w, const float f, const unsigned *lut, unsigned long long &G, int &L,
+                                          int &last, float &maxf) {
+  const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+  unsigned pr[4];
+  int pl[4];
+  int S = 0;
+  last = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float f0 = (float)(int)(short)(ww[d] & 0xFFFFu), f1 = (float)((int)ww[d] >> 16);
+    maxf = fmaxf(maxf, fmaxf(__builtin_fabsf(f0), __builtin_fabsf(f1)));
+    const int t0 = (int)(f0 * f), t1 = (int)(f1 * f); // quant(): truncation towards zero of the signed quotient
+    const unsigned e0 = lut[t0 & 0xFF], e1 = lut[t1 & 0xFF];
+    const int l0 = (int)(e0 >> 24), l1 = (int)(e1 >> 24);
+    S += l0;
+    if (e0 >= 0x02000000u) last = S; // a non-zero coefficient's code has at least four bits
+    S += l1;
+    if (e1 >= 0x02000000u) last = S;
+    pr[d] = ((e0 & 0xFFFFFFu) << l1) | (e1 & 0xFFFFFFu);
+    pl[d] = l0 + l1;
+  }
+  const unsigned long long q0 = ((unsigned long long)pr[0] << pl[1]) | pr[1], q1 = ((unsigned long long)pr[2] << pl[3]) | pr[3];
+  G = (q0 << (pl[2] + pl[3])) | q1; // (meaningless beyond 64 bits: the caller tests L)
+  L = S;
+}
+
+// OR the n <= 64 right-aligned bits of G into the image at bit position pos, cut at `limit` (what lies beyond are the
+// '1's of trailing zeros, which a bounded write drops: VLC.cpp:151-156)
+__device__ __forceinline__ void p16_put(unsigned *img, int pos, int limit, unsigned long long G, int n) {
+  if (pos >= limit || n <= 0) return;
+  if (pos + n > limit) { G >>= (pos + n - limit); n = limit - pos; }
+  const unsigned long long v = G << (64 - n); // left aligned
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const int wi = pos >> 5;
+  const unsigned bo = (unsigned)pos & 31u;
+  atomicOr(&img[wi], __builtin_amdgcn_alignbit(0u, hi, bo));
+  atomicOr(&img[wi + 1], __builtin_amdgcn_alignbit(hi, lo, bo));
+  atomicOr(&img[wi + 2], __builtin_amdgcn_alignbit(lo, 0u, bo));
+}
+
+// One component of a slice the table path does not take, a coefficient per lane and trip (rolled: this path must not cost
+// the kernel registers): measure (WRITE false: returns component_slice_bytes' bit count) or write the codes that fit.
+template <bool WRITE>
+__device__ __forceinline__ int p16_general(const int16_t *src, const int32_t *srcw, int n, int n0, int q, const int *qm, int lane,
+                                        unsigned *img, int bit0, int region_bits, unsigned *err) {
+  const int n0_shift = (n0 & (n0 - 1)) == 0 ? 31 - __clz(n0) : -1;
+  int base = 0, count = 0;
+#pragma unroll 1
+  for (int r0 = 0; r0 < n; r0 += 64) {
+    const int j = r0 + lane;
+    int c = 0, nb = 0;
+    if (j < n) {
+      const int aq = max(q - qm[band_of_index_fast(j, n0, n0_shift)], 0);
+      if (aq > 119) atomicOr(err, VC2_DEVERR_QINDEX); // (and the coefficient counts as zero, as in k_hq_pack)
+      else c = quant_dev(St<int16_t>::load1(src + j, srcw + j), aq);
+      nb = svlc_bits(c);
+      if (nb > 32) { atomicOr(err, VC2_DEVERR_CODE32); c = 0; nb = 1; } // VLC.h:27: no code beyond 32 bits
+    }
+    const int incl = wave_incl_scan(nb, lane), pos = base + incl - nb;
+    if (WRITE) { if (nb && pos + nb <= region_bits) put_code(img, bit0 + pos, svlc_code(c), nb); }
+    else count = max(count, wave_max(c != 0 ? pos + nb : 0));
+    base += __builtin_amdgcn_readlane(incl, 63);
+  }
+  return count;
+}
+
+template <bool CBR>
+__global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
+  extern __shared__ unsigned lds_u[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pic = blockIdx.y;
+  const int slice = blockIdx.x * 4 + wave;
+  const bool active = slice < p.n_slices; // wave-uniform
+  const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
+  unsigned *lut = lds_u;                   // at LDS address 0: a look-up's address is the quotient's low byte times four
+  float *inv = (float *)(lut + P16_LUT_N); // 128 entries, [120..127] = 0: indices beyond the table quantise to zero
+  unsigned *img = lds_u + P16_LUT_N + 128 + wave * img_q * 4;
+  const uint2 lt = ((const uint2 *)p.lane16)[lane];
+  const unsigned body_off = lt.x & 0xFFFFu, head_off = lt.x >> 16;
+  const bool has_body = body_off != 0xFFFFu, has_head = head_off != 0xFFFFu;
+  const size_t rec_at = (size_t)pic * p.store_stride + (size_t)(active ? slice : 0) * p.slice_coefs;
+  const int16_t *rec = (const int16_t *)p.store + rec_at;
+  // the record first: its latency runs beside the tables
+  uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
+  int hv = 0;
+  if (active && has_body) { w0 = *(const uint4 *)(rec + body_off); w1 = *(const uint4 *)(rec + body_off + 8); }
+  if (active && has_head) hv = rec[head_off];
+  if (threadIdx.x < P16_LUT_N) lut[threadIdx.x] = g_vlc_lut_s[threadIdx.x];
+  if (threadIdx.x < 128) inv[threadIdx.x] = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
+  for (int i = lane; i < img_q; i += 64) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  if (!active) return;
+
+  const int q = p.qidx[(size_t)pic * p.n_slices + slice];
+  const int aqb = max(q - (int)(lt.y & 0xFFu), 0), aqh = max(q - (int)((lt.y >> 8) & 0xFFu), 0);
+  if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
+  const float fb = inv[min(aqb, 120)], fh = inv[min(aqh, 120)];
+
+  // ---- body: two strings of eight coefficients
+  unsigned long long G0, G1;
+  int L0, L1, last0, last1;
+  float maxf = 0.f;
+  p16_group(w0, fb, lut, G0, L0, last0, maxf);
+  p16_group(w1, fb, lut, G1, L1, last1, maxf);
+  int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
+  bool slow = maxf >= 32768.f /* an escape of the store */ || maxf * fb >= (float)(P16_MAXQ + 1) || max(L0, L1) > 64;
+  if (!has_body) { body_bits = 0; body_last = 0; slow = false; }
+  // ---- head: one coefficient, code by arithmetic
+  unsigned hcode = 0;
+  int hbits = 0;
+  bool hnz = false;
+  if (has_head) {
+    slow |= hv == VC2_ST_SENTINEL;
+    const int t = (int)((float)hv * fh);
+    hcode = svlc_code(t);
+    hbits = svlc_bits(t); // <= 32: |t| <= 32767
+    hnz = t != 0;
+  }
+
+  const int cbr_total = CBR ? p.cbr_bytes[slice] : 0;
+  bool bad_cbr = false;
+  int bytes[3];
+  auto comp_len = [&](int count) -> int { // ceil(bytes / scalar) by the rounded-up reciprocal (exact far beyond 255 * scalar)
+    int len = (int)((float)(((count + 7) >> 3) + p.scalar - 1) * p.inv_scalar);
+    if (len > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
+    return len * p.scalar;
+  };
+  auto cbr_v = [&](int need) -> int { // Slices.cpp:352-368: V absorbs the remainder of the slice
+    if (!CBR) return need;
+    const int vb = cbr_total - 4 - bytes[0] - bytes[1];
+    if (vb < need) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); bad_cbr = true; return need; }
+    if (vb / p.scalar > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); bad_cbr = true; return need; }
+    return vb;
+  };
+
+  if (__builtin_expect(__any(slow), 0)) {
+    // the general coder, component by component: measure, then write (the image is still all zeros)
+    const int32_t *recw = p.store_wide + rec_at;
+    int base = p.prefix + 1;
+    for (int cc = 0; cc < 3; ++cc) {
+      const int16_t *src = rec + p.comp_off[cc];
+      const int32_t *srcw = recw + p.comp_off[cc];
+      const int count = p16_general<false>(src, srcw, p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, nullptr, 0, 0, p.err);
+      bytes[cc] = comp_len(count);
+      if (cc == 2) bytes[2] = cbr_v(bytes[2]);
+      p16_general<true>(src, srcw, p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, img, 8 * (base + 1), 8 * bytes[cc], p.err);
+      if (lane == 0) put_byte(img, base, (unsigned)(bytes[cc] / p.scalar));
+      base += 1 + bytes[cc];
+    }
+    if (lane == 0) put_byte(img, p.prefix, (unsigned)q & 0xFFu);
+  } else {
+    // ---- positions: one scan over (head bits << 16 | body bits), segments = components (rows 0-1, row 2, row 3)
+    const int pk = (hbits << 16) | body_bits;
+    int s = pk;
+    s += dpp0<0x111, 0xf>(s);
+    s += dpp0<0x112, 0xf>(s);
+    s += dpp0<0x114, 0xf>(s);
+    s += dpp0<0x118, 0xf>(s);
+    s += dpp0<0x142, 0x2>(s); // row 0's total into row 1: luma spans two rows
+    const int tot_y = __builtin_amdgcn_readlane(s, 31), tot_u = __builtin_amdgcn_readlane(s, 47), tot_v = __builtin_amdgcn_readlane(s, 63);
+    const int comp = lane < 32 ? 0 : (lane < 48 ? 1 : 2);
+    const int tot = comp == 0 ? tot_y : (comp == 1 ? tot_u : tot_v);
+    const int excl = s - pk;
+    const int hpos = excl >> 16, bpos = (tot >> 16) + (excl & 0xFFFF); // bit offsets inside the component's data
+    // bits through the last non-zero coefficient (component_slice_bytes' count): the body lies behind the head and
+    // positions grow with the lane inside either, so the last lane with a non-zero body coefficient decides, or -- a
+    // component whose body is all zeros -- the last lane with a non-zero head coefficient
+    const int endpos = body_last ? bpos + body_last : (hnz ? hpos + hbits : 0);
+    const unsigned long long nzb = __ballot(body_last != 0), nzh = __ballot(hnz);
+    auto count_of = [&](unsigned b, unsigned h, int lane0) -> int {
+      const unsigned m = b ? b : h;
+      return m ? __builtin_amdgcn_readlane(endpos, lane0 + 31 - __builtin_clz(m)) : 0;
+    };
+    const int cnt_y = count_of((unsigned)nzb, (unsigned)nzh, 0);
+    const int cnt_u = count_of((unsigned)(nzb >> 32) & 0xFFFFu, (unsigned)(nzh >> 32) & 0xFFFFu, 32);
+    const int cnt_v = count_of((unsigned)(nzb >> 48), (unsigned)(nzh >> 48), 48);
+    bytes[0] = comp_len(cnt_y);
+    bytes[1] = comp_len(cnt_u);
+    bytes[2] = cbr_v(comp_len(cnt_v));
+    // data of component c starts one byte (its length byte) behind the previous component's end
+    const int len_at = p.prefix + 1 + (comp > 0 ? 1 + bytes[0] : 0) + (comp > 1 ? 1 + bytes[1] : 0);
+    const int bit0 = 8 * (len_at + 1), limit = bit0 + 8 * bytes[comp];
+    if (hbits) p16_put(img, bit0 + hpos, limit, hcode, hbits);
+    if (has_body) {
+      p16_put(img, bit0 + bpos, limit, G0, L0);
+      p16_put(img, bit0 + bpos + L0, limit, G1, L1);
+    }
+    if (lane < 4) { // the quantiser index and the three length bytes
+      const int at = lane == 0 ? p.prefix : (lane == 1 ? p.prefix + 1 : (lane == 2 ? p.prefix + 2 + bytes[0] : p.prefix + 3 + bytes[0] + bytes[1]));
+      const int len = lane == 1 ? bytes[0] : (lane == 2 ? bytes[1] : bytes[2]);
+      const unsigned val = lane == 0 ? ((unsigned)q & 0xFFu) : (unsigned)(len / p.scalar);
+      put_byte(img, at, val);
+    }
+  }
+  const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
+  wave_lds_sync();
+  if (CBR) {
+    if (bad_cbr) return;
+    uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
+    // dword stores for the 4-byte aligned middle of the destination (the budgets put a slice at any byte), byte stores for
+    // its ragged head and tail
+    const int head = min((int)((4 - ((size_t)dst & 3)) & 3), total);
+    const int nw = (total - head) >> 2, tail0 = head + 4 * nw;
+    if (lane < head) dst[lane] = (uint8_t)(img[lane >> 2] >> (24 - 8 * (lane & 3)));
+    if (lane < total - tail0) { const int i = tail0 + lane; dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3))); }
+    unsigned *d4 = (unsigned *)(dst + head);
+    for (int w = lane; w < nw; w += 64) {
+      const int i0 = head + 4 * w;
+      const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
+      d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
+    }
+  } else {
+    uint4 *dst = (uint4 *)(p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes); // slots are whole 16-byte pieces
+    if (lane == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
+    for (int i = lane; 16 * i < total; i += 64) {
+      const uint4 v = ((const uint4 *)img)[i];
+      dst[i] = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    }
+  }
+}
+
+static size_t pack16_lds(int prefix, int scalar) {
+  const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
+  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 4;
+}

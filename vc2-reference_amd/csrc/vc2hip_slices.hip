@@ -271,6 +271,7 @@ __device__ unsigned g_vlc_lut[VLC_LUT_N];
 __device__ __forceinline__ void build_vlc_lut(unsigned *lut) {
   for (int m = threadIdx.x * 4; m < VLC_LUT_N; m += blockDim.x * 4) *(uint4 *)(lut + m) = *(const uint4 *)(g_vlc_lut + m);
 }
+static void vc2_upload_vlc_lut_s(hipStream_t s);
 void vc2_upload_vlc_lut(hipStream_t s) {
   static unsigned host[VLC_LUT_N]; // built once, see vc2_upload_unpack_lut
   static std::once_flag once;
@@ -290,6 +291,7 @@ void vc2_upload_vlc_lut(hipStream_t s) {
   }
   });
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_vlc_lut), host, sizeof host, 0, hipMemcpyHostToDevice, s);
+  vc2_upload_vlc_lut_s(s);
 }
 __device__ __forceinline__ void codes8(Coef8 &c, int (&raw)[8], int j0, int n, unsigned *err, const unsigned *lut);
 
@@ -788,6 +790,8 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   PACK_STAMP(5);
 }
 
+#include "vc2hip_pack16.h"
+
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
 static size_t pack_lds(int prefix, int scalar, int slices_per_wave, bool big_lut = false, int waves = 4, bool gimg = false) {
   const size_t img_words = gimg ? 0 : ((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2;
@@ -822,9 +826,25 @@ int vc2_pack_slices_per_tile(const PackParams &p) {
 }
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
-  fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
   if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
+  static const int use16 = vc2_tune_int("VC2HIP_PACK16", 1);
+  if (use16 && vc2_pack_image_mode(p.prefix, p.scalar) == 0 && pack16_plan(p, p.lane16)) {
+    // the common geometry on the 16-bit store: one round per slice, sixteen coefficients per lane (vc2hip_pack16.h)
+    const size_t lds = pack16_lds(p.prefix, p.scalar);
+    const dim3 grid((p.n_slices + 3) / 4, n_pictures);
+    vc2_prof_begin(L, "hq_pack", s);
+    if (p.cbr_bytes) {
+      vc2_allow_lds((const void *)k_hq_pack16<true>, 144 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16<true>, grid, dim3(256), lds, s, p);
+    } else {
+      vc2_allow_lds((const void *)k_hq_pack16<false>, 144 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16<false>, grid, dim3(256), lds, s, p);
+    }
+    vc2_prof_end(L, s);
+    return;
+  }
+  fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
 #ifdef VC2HIP_ABLATE
   { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
 #endif
