@@ -28,7 +28,7 @@
 
 constexpr int P16_LUT_N = 256;            // quotient as a signed byte: entries 0..127 = +0..+127, 128..255 = -128..-1
 constexpr int P16_MAXQ = 126;             // |quotient| the table path takes: codes of <= 14 bits, pairs of <= 28
-__device__ unsigned g_vlc_lut_s[P16_LUT_N]; // length << 24 | code (sign bit included); zero: 1 << 24 | 1
+__device__ unsigned g_vlc_lut_s[P16_LUT_N]; // length << 24 | (non-zero ? 0xFF : 0) << 16 | code with its sign bit (<= 14 bits)
 
 static void fill_vlc_lut_s(unsigned *host) {
   for (int i = 0; i < P16_LUT_N; ++i) {
@@ -44,7 +44,7 @@ static void fill_vlc_lut_s(unsigned *host) {
       code = (((code << 1) | 1u) << 1) | (t < 0 ? 1u : 0u); // (0 b)* 1 s
       nb = 2 * (unsigned)k + 2;
     }
-    host[i] = (nb << 24) | code;
+    host[i] = (nb << 24) | (m ? 0xFF0000u : 0u) | code; // every field a byte or a word of its own: SDWA operand selects
   }
 }
 
@@ -56,14 +56,15 @@ static void vc2_upload_vlc_lut_s(hipStream_t s) {
 }
 
 // ---- host: which lanes take what -----------------------------------------------------------------------------------
-// lane16[2 * lane]     = element offset of the lane's sixteen body coefficients | element offset of its head coefficient
-//                        << 16 (0xFFFF: none), both from the start of the slice record
-// lane16[2 * lane + 1] = quantisation-matrix entry of the body run | of the head coefficient << 8
+// Component c owns lanes [lo, lo + width) = [0, 32), [32, 48), [48, 64).  Its first head[c] coefficients (the subbands
+// whose blocks are not whole runs of sixteen) go one per lane, the rest sixteen per lane, both from lane lo upwards:
+//   lane16[lane]   = quantisation-matrix entry of the lane's body run | of its head coefficient << 8
+//   lane16[64 + c] = head[c],  lane16[67 + c] = body lanes of component c
+// (the offsets of a lane's coefficients follow from those six numbers by arithmetic: no load in front of the record loads)
 static bool pack16_plan(const PackParams &p, unsigned *lane16) {
   if (!p.store16 || !p.quantise || p.lookback || p.tile_slices) return false;
-  if (p.slice_coefs > 0xFFF0) return false;
   const int lo[3] = {0, 32, 48}, width[3] = {32, 16, 16};
-  for (int l = 0; l < 64; ++l) { lane16[2 * l] = 0xFFFFFFFFu; lane16[2 * l + 1] = 0; }
+  for (int l = 0; l < 128; ++l) lane16[l] = 0;
   int body_lanes = 0;
   for (int c = 0; c < 3; ++c) {
     const int n = p.comp_n[c], n0 = p.comp_n0[c];
@@ -75,33 +76,29 @@ static bool pack16_plan(const PackParams &p, unsigned *lane16) {
       if (p.qmatrix[b] < 0 || p.qmatrix[b] > 255) return false;
       if (head < 0 && (size & 15) == 0 && (start & 15) == 0) head = start; // this band and all behind it: whole runs of 16
       if (head < 0) {
-        for (int j = start; j < start + size; ++j) {
-          if (j >= width[c]) return false; // more head coefficients than the component has lanes
-          unsigned &e = lane16[2 * (lo[c] + j)], &m = lane16[2 * (lo[c] + j) + 1];
-          e = (e & 0x0000FFFFu) | ((unsigned)(p.comp_off[c] + j) << 16);
-          m |= (unsigned)p.qmatrix[b] << 8;
-        }
+        if (start + size > width[c]) return false; // more head coefficients than the component has lanes
+        for (int j = start; j < start + size; ++j) lane16[lo[c] + j] |= (unsigned)p.qmatrix[b] << 8;
       } else {
-        for (int j = start; j < start + size; j += 16) {
-          const int bl = (j - head) / 16;
-          if (bl >= width[c]) return false;
-          unsigned &e = lane16[2 * (lo[c] + bl)], &m = lane16[2 * (lo[c] + bl) + 1];
-          e = (e & 0xFFFF0000u) | (unsigned)(p.comp_off[c] + j);
-          m |= (unsigned)p.qmatrix[b];
-          ++body_lanes;
-        }
+        if ((start + size - head) / 16 > width[c]) return false;
+        for (int j = start; j < start + size; j += 16) lane16[lo[c] + (j - head) / 16] |= (unsigned)p.qmatrix[b];
       }
       start += size;
     }
     if (start != n) return false;
     if (head < 0) head = n;
     if (head & 7) return false; // the body's 16-byte loads
+    lane16[64 + c] = (unsigned)head;
+    lane16[67 + c] = (unsigned)((n - head) / 16);
+    body_lanes += (n - head) / 16;
   }
   return body_lanes >= 40; // fewer: the slices are small, k_hq_pack puts two or four of them on a wavefront
 }
 
 // ---- device ----------------------------------------------------------------------------------------------------------
-// eight coefficients (four dwords of 16-bit pairs) -> one string: G (right aligned), its length L, end of the last non-zero code
+// eight coefficients (four dwords of 16-bit pairs) -> one string: G (right aligned), its length L, end of the last non-zero code.
+// Every field of a table entry is a byte or a word of its own, so that lengths, codes and the non-zero mask are operand
+// selects (SDWA) of the adds, shifts and ORs that use them; `last` is a running maximum of (bits so far AND mask) -- no
+// compare, no select, nothing through VCC.
 __device__ __forceinline__ void p16_group(const uint4 w, const float f, const unsigned *lut, unsigned long long &G, int &L,
                                           int &last, float &maxf) {
   const unsigned ww[4] = {w.x, w.y, w.z, w.w};
@@ -117,10 +114,11 @@ __device__ __forceinline__ void p16_group(const uint4 w, const float f, const un
     const unsigned e0 = lut[t0 & 0xFF], e1 = lut[t1 & 0xFF];
     const int l0 = (int)(e0 >> 24), l1 = (int)(e1 >> 24);
     S += l0;
-    if (e0 >= 0x02000000u) last = S; // a non-zero coefficient's code has at least four bits
+    const int c0 = S & (int)(signed char)(e0 >> 16);
     S += l1;
-    if (e1 >= 0x02000000u) last = S;
-    pr[d] = ((e0 & 0xFFFFFFu) << l1) | (e1 & 0xFFFFFFu);
+    const int c1 = S & (int)(signed char)(e1 >> 16);
+    last = max(last, max(c0, c1));
+    pr[d] = ((e0 & 0xFFFFu) << l1) | (e1 & 0xFFFFu);
     pl[d] = l0 + l1;
   }
   const unsigned long long q0 = ((unsigned long long)pr[0] << pl[1]) | pr[1], q1 = ((unsigned long long)pr[2] << pl[3]) | pr[3];
@@ -128,18 +126,17 @@ __device__ __forceinline__ void p16_group(const uint4 w, const float f, const un
   L = S;
 }
 
-// OR the n <= 64 right-aligned bits of G into the image at bit position pos, cut at `limit` (what lies beyond are the
-// '1's of trailing zeros, which a bounded write drops: VLC.cpp:151-156)
-__device__ __forceinline__ void p16_put(unsigned *img, int pos, int limit, unsigned long long G, int n) {
-  if (pos >= limit || n <= 0) return;
-  if (pos + n > limit) { G >>= (pos + n - limit); n = limit - pos; }
-  const unsigned long long v = G << (64 - n); // left aligned
+// OR the first `keep` of the n <= 63 right-aligned bits of G into the image at bit position pos (0 <= keep <= n; what a
+// bounded write drops beyond the component's length are the '1's of trailing zeros, VLC.cpp:151-156).  No special cases:
+// n - keep and 64 - keep stay inside a 64-bit shift's range except keep == 0, where G >> n is already zero.
+__device__ __forceinline__ void p16_put(unsigned *img, int pos, unsigned long long G, int n, int keep) {
+  const unsigned long long v = (G >> (n - keep)) << (64 - keep); // left aligned
   const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-  const int wi = pos >> 5;
-  const unsigned bo = (unsigned)pos & 31u;
-  atomicOr(&img[wi], __builtin_amdgcn_alignbit(0u, hi, bo));
-  atomicOr(&img[wi + 1], __builtin_amdgcn_alignbit(hi, lo, bo));
-  atomicOr(&img[wi + 2], __builtin_amdgcn_alignbit(lo, 0u, bo));
+  unsigned *at = img + (pos >> 5);
+  const unsigned bo = (unsigned)pos; // (v_alignbit takes the low five bits)
+  atomicOr(at, __builtin_amdgcn_alignbit(0u, hi, bo));
+  atomicOr(at + 1, __builtin_amdgcn_alignbit(hi, lo, bo));
+  atomicOr(at + 2, __builtin_amdgcn_alignbit(lo, 0u, bo));
 }
 
 // One component of a slice the table path does not take, a coefficient per lane and trip (rolled: this path must not cost
@@ -179,24 +176,29 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   unsigned *lut = lds_u;                   // at LDS address 0: a look-up's address is the quotient's low byte times four
   float *inv = (float *)(lut + P16_LUT_N); // 128 entries, [120..127] = 0: indices beyond the table quantise to zero
   unsigned *img = lds_u + P16_LUT_N + 128 + wave * img_q * 4;
-  const uint2 lt = ((const uint2 *)p.lane16)[lane];
-  const unsigned body_off = lt.x & 0xFFFFu, head_off = lt.x >> 16;
-  const bool has_body = body_off != 0xFFFFu, has_head = head_off != 0xFFFFu;
+  // the tables' loads first (L2), the record's behind them: the table writes and the barrier then wait for the former only
+  const unsigned lut_e = threadIdx.x < P16_LUT_N ? g_vlc_lut_s[threadIdx.x] : 0u;
+  const float inv_e = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
+  const unsigned lt = p.lane16[lane];
+  const int comp = lane < 32 ? 0 : (lane < 48 ? 1 : 2), cl = lane - (lane < 32 ? 0 : (lane < 48 ? 32 : 48));
+  const int head_n = (int)(comp == 0 ? p.lane16[64] : (comp == 1 ? p.lane16[65] : p.lane16[66]));
+  const int body_n = (int)(comp == 0 ? p.lane16[67] : (comp == 1 ? p.lane16[68] : p.lane16[69]));
+  const int coff = comp == 0 ? p.comp_off[0] : (comp == 1 ? p.comp_off[1] : p.comp_off[2]);
+  const bool has_body = cl < body_n, has_head = cl < head_n;
   const size_t rec_at = (size_t)pic * p.store_stride + (size_t)(active ? slice : 0) * p.slice_coefs;
   const int16_t *rec = (const int16_t *)p.store + rec_at;
-  // the record first: its latency runs beside the tables
   uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
   int hv = 0;
-  if (active && has_body) { w0 = *(const uint4 *)(rec + body_off); w1 = *(const uint4 *)(rec + body_off + 8); }
-  if (active && has_head) hv = rec[head_off];
-  if (threadIdx.x < P16_LUT_N) lut[threadIdx.x] = g_vlc_lut_s[threadIdx.x];
-  if (threadIdx.x < 128) inv[threadIdx.x] = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
+  if (active && has_body) { const int16_t *b = rec + coff + head_n + 16 * cl; w0 = *(const uint4 *)b; w1 = *(const uint4 *)(b + 8); }
+  if (active && has_head) hv = rec[coff + cl];
+  if (threadIdx.x < P16_LUT_N) lut[threadIdx.x] = lut_e;
+  if (threadIdx.x < 128) inv[threadIdx.x] = inv_e;
   for (int i = lane; i < img_q; i += 64) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   if (!active) return;
 
   const int q = p.qidx[(size_t)pic * p.n_slices + slice];
-  const int aqb = max(q - (int)(lt.y & 0xFFu), 0), aqh = max(q - (int)((lt.y >> 8) & 0xFFu), 0);
+  const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
   const float fb = inv[min(aqb, 120)], fh = inv[min(aqh, 120)];
 
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   p16_group(w0, fb, lut, G0, L0, last0, maxf);
   p16_group(w1, fb, lut, G1, L1, last1, maxf);
   int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
-  bool slow = maxf >= 32768.f /* an escape of the store */ || maxf * fb >= (float)(P16_MAXQ + 1) || max(L0, L1) > 64;
+  bool slow = maxf >= 32768.f /* an escape of the store */ || maxf * fb >= (float)(P16_MAXQ + 1) || max(L0, L1) > 63;
   if (!has_body) { body_bits = 0; body_last = 0; slow = false; }
   // ---- head: one coefficient, code by arithmetic
   unsigned hcode = 0;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   int bytes[3];
   auto comp_len = [&](int count) -> int { // ceil(bytes / scalar) by the rounded-up reciprocal (exact far beyond 255 * scalar)
     int len = (int)((float)(((count + 7) >> 3) + p.scalar - 1) * p.inv_scalar);
-    if (len > 255) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
+    if (len > 255) { atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
     return len * p.scalar;
   };
   auto cbr_v = [&](int need) -> int { // Slices.cpp:352-368: V absorbs the remainder of the slice
@@ -262,7 +264,6 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
     s += dpp0<0x118, 0xf>(s);
     s += dpp0<0x142, 0x2>(s); // row 0's total into row 1: luma spans two rows
     const int tot_y = __builtin_amdgcn_readlane(s, 31), tot_u = __builtin_amdgcn_readlane(s, 47), tot_v = __builtin_amdgcn_readlane(s, 63);
-    const int comp = lane < 32 ? 0 : (lane < 48 ? 1 : 2);
     const int tot = comp == 0 ? tot_y : (comp == 1 ? tot_u : tot_v);
     const int excl = s - pk;
     const int hpos = excl >> 16, bpos = (tot >> 16) + (excl & 0xFFFF); // bit offsets inside the component's data
@@ -278,21 +279,32 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
     const int cnt_y = count_of((unsigned)nzb, (unsigned)nzh, 0);
     const int cnt_u = count_of((unsigned)(nzb >> 32) & 0xFFFFu, (unsigned)(nzh >> 32) & 0xFFFFu, 32);
     const int cnt_v = count_of((unsigned)(nzb >> 48), (unsigned)(nzh >> 48), 48);
-    bytes[0] = comp_len(cnt_y);
-    bytes[1] = comp_len(cnt_u);
-    bytes[2] = cbr_v(comp_len(cnt_v));
+    // the three lengths side by side on lanes 0-2, back into scalars
+    const int len = comp_len(lane == 0 ? cnt_y : (lane == 1 ? cnt_u : cnt_v));
+    bytes[0] = __builtin_amdgcn_readlane(len, 0);
+    bytes[1] = __builtin_amdgcn_readlane(len, 1);
+    bytes[2] = cbr_v(__builtin_amdgcn_readlane(len, 2));
     // data of component c starts one byte (its length byte) behind the previous component's end
-    const int len_at = p.prefix + 1 + (comp > 0 ? 1 + bytes[0] : 0) + (comp > 1 ? 1 + bytes[1] : 0);
-    const int bit0 = 8 * (len_at + 1), limit = bit0 + 8 * bytes[comp];
-    if (hbits) p16_put(img, bit0 + hpos, limit, hcode, hbits);
+    const int at_u = p.prefix + 2 + bytes[0], at_v = at_u + 1 + bytes[1]; // the length bytes of U and V
+    const int bit0 = 8 * ((comp == 0 ? p.prefix + 1 : (comp == 1 ? at_u : at_v)) + 1);
+    const int room = 8 * (comp == 0 ? bytes[0] : (comp == 1 ? bytes[1] : bytes[2])); // bits of the component's data
+    // a head code is inside the length or wholly beyond it (beyond the last non-zero coefficient every code is one bit)
+    if (hbits && hpos + hbits <= room) {
+      const unsigned v = hcode << (32 - hbits);
+      unsigned *at = img + ((bit0 + hpos) >> 5);
+      const unsigned bo = (unsigned)(bit0 + hpos);
+      atomicOr(at, __builtin_amdgcn_alignbit(0u, v, bo));
+      atomicOr(at + 1, __builtin_amdgcn_alignbit(v, 0u, bo));
+    }
     if (has_body) {
-      p16_put(img, bit0 + bpos, limit, G0, L0);
-      p16_put(img, bit0 + bpos + L0, limit, G1, L1);
+      const int keep = min(max(room - bpos, 0), body_bits), k0 = min(keep, L0);
+      p16_put(img, bit0 + bpos, G0, L0, k0);
+      p16_put(img, bit0 + bpos + L0, G1, L1, keep - k0);
     }
     if (lane < 4) { // the quantiser index and the three length bytes
-      const int at = lane == 0 ? p.prefix : (lane == 1 ? p.prefix + 1 : (lane == 2 ? p.prefix + 2 + bytes[0] : p.prefix + 3 + bytes[0] + bytes[1]));
-      const int len = lane == 1 ? bytes[0] : (lane == 2 ? bytes[1] : bytes[2]);
-      const unsigned val = lane == 0 ? ((unsigned)q & 0xFFu) : (unsigned)(len / p.scalar);
+      const int at = lane == 0 ? p.prefix : (lane == 1 ? p.prefix + 1 : (lane == 2 ? at_u : at_v));
+      const int lb = lane == 1 ? bytes[0] : (lane == 2 ? bytes[1] : bytes[2]);
+      const unsigned val = lane == 0 ? ((unsigned)q & 0xFFu) : (unsigned)((float)lb * p.inv_scalar);
       put_byte(img, at, val);
     }
   }
@@ -314,11 +326,11 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
       d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
     }
   } else {
-    uint4 *dst = (uint4 *)(p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes); // slots are whole 16-byte pieces
+    uint8_t *dst = p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes; // slots are whole 16-byte pieces
     if (lane == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
-    for (int i = lane; 16 * i < total; i += 64) {
-      const uint4 v = ((const uint4 *)img)[i];
-      dst[i] = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    for (int i = lane * 16; i < total; i += 64 * 16) {
+      const uint4 v = *(const uint4 *)((const uint8_t *)img + i);
+      *(uint4 *)(dst + i) = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
     }
   }
 }
