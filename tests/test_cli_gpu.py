@@ -258,6 +258,57 @@ def test_several_workers_keep_the_stream_order(tools, oracle, tmp_path, devices)
     assert (tmp_path / "dec.raw").read_bytes() == want_dec
 
 
+def test_more_pictures_than_the_output_mapping_was_sized_for(tools, oracle, tmp_path):
+    """DecodeStream sizes its mapped output from a pre-scan that stops at a zero next-parse-offset, while
+    the main loop parses on behind a sequence header that carries one.  [picture][sequence header, next = 0][picture]
+    [picture]: the pre-scan counts one picture, the loop skips the first (no sequence header yet) and decodes two -- the
+    second has no place in the mapping and must go out through pwrite, not past the end of the map."""
+    w, h, frames = 256, 128, 2
+    raw = synth(w, h, "422", 10, 71, frames=frames)
+    p = make_params(w, h, "422", 10, "DD97", 3, 1, 2, q=7, scalar=2)
+    stream = oracle.encode_stream(p, raw, frames)
+    want, n = oracle.decode_stream(p, stream, frames)
+    units, pos = [], 0
+    while pos < len(stream):
+        nxt = int.from_bytes(stream[pos + 5:pos + 9], "big") or 13
+        units.append(bytearray(stream[pos:pos + nxt]))
+        pos += nxt
+    assert len(units) == 4 and units[0][4] == 0x00 and units[1][4] == 0xE8   # sequence header, 2 pictures, end of sequence
+    seq = bytearray(units[0])
+    seq[5:9] = (0).to_bytes(4, "big")   # next parse offset 0: "the rest follows"
+    crafted = bytes(units[1]) + bytes(seq) + bytes(units[1]) + bytes(units[2]) + bytes(units[3])
+    (tmp_path / "c.vc2").write_bytes(crafted)
+    out = subprocess.run([os.path.join(BIN, "DecodeStream"), str(tmp_path / "c.vc2"), str(tmp_path / "d.raw")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert (tmp_path / "d.raw").read_bytes() == want
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (the gpurun boxes have one): runs on the driver's multi-GPU node")
+def test_workers_on_distinct_devices(tools, oracle, tmp_path):
+    """--devices 0,1: one worker, one library context and one pinned staging pool PER DEVICE (vc2hip_host_alloc on the
+    worker's own device); the stream and the decoded file must be those of one device and of the oracle."""
+    w, h, frames = 512, 256, 9
+    raw = synth(w, h, "422", 10, 67, frames=frames)
+    p = make_params(w, h, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    want_stream = oracle.encode_stream(p, raw, frames)
+    want_dec, n = oracle.decode_stream(p, want_stream, frames)
+    (tmp_path / "in.raw").write_bytes(raw)
+    args = enc_args(w, h, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    devices = ",".join(str(d) for d in range(min(_gpu_count(), 8)))
+    run("EncodeStream", *args, "--devices", devices, tmp_path / "in.raw", tmp_path / "many.vc2")
+    assert (tmp_path / "many.vc2").read_bytes() == want_stream
+    run("DecodeStream", "--devices", devices, tmp_path / "many.vc2", tmp_path / "dec.raw")
+    assert (tmp_path / "dec.raw").read_bytes() == want_dec
+    run("DecodeStream", "--devices", "1", tmp_path / "many.vc2", tmp_path / "dec1.raw")   # a context on a device other than 0
+    assert (tmp_path / "dec1.raw").read_bytes() == want_dec
+
+
 def test_several_workers_interlaced_cbr(tools, oracle, tmp_path):
     w, h, frames = 256, 128, 5
     raw = synth(w, h, "422", 10, 62, frames=frames)

@@ -41,6 +41,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["pictures_per_gpu_per_step"] == 4 and two["scaling"] == "weak"
     assert "every rank" in two["parity_checked"] and "AND-reduced over 2 ranks" in two["parity_checked"]
+    assert "slots 2-3 of every rank byte for byte against the oracle" in two["parity_checked"]   # each rank forked its own oracle pool
     assert "reference digest" in one["parity_checked"]
     # two ranks on one GPU: twice the pictures in (at least) the time one rank needs for its own -- the aggregate stays within
     # what one GPU delivers (overlap between the ranks' kernels can add a little; contention and two processes take away)
@@ -57,3 +58,19 @@ def test_bench_refuses_a_wrong_slot(tmp_path):
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "refusing to report a number" in out.stderr + out.stdout
+
+
+def test_bench_two_ranks_on_two_gpus_over_rccl():
+    """the driver's N = 2 command as it stands (backend nccl = RCCL, rank r on device r); skipped on the one-GPU boxes"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: runs on the driver's multi-GPU node")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("VC2_BENCH_DRYRUN", None)
+    env.pop("VC2_BENCH_DEVICE_MAP", None)
+    one = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + COMMON, env=env, capture_output=True, text=True, timeout=900))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + COMMON
+    two = _line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900))
+    assert two["n_gpus"] == 2 and "against the oracle" in two["parity_checked"]
+    assert two["value"] > 1.5 * one["value"], (one["value"], two["value"])   # frame-parallel, no collective: close to 2 x

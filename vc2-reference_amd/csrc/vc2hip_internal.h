@@ -219,6 +219,7 @@ struct UnpackParams {
   BandPlanes bp;
   HeadSplit hs;
   int xs;                     // slices across
+  int debug_skip;             // timing experiments only (VC2HIP_DEBUG_UNPACK, -DVC2HIP_ABLATE): 1 stream reads from a hot 16 KiB window, 2 no stores
 };
 
 struct CbrParams {

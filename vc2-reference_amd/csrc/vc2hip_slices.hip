@@ -1807,6 +1807,9 @@ struct Reader32 {
 #endif
   unsigned off;            // byte offset (from the payload base) of the word after those
   int left;                // data bits from that word on (<= 0: none)
+#ifdef VC2HIP_ABLATE
+  unsigned dbg_mask;
+#endif
   __device__ __forceinline__ unsigned fetch1(const uint8_t *pay) {
     unsigned v = ~0u;
     if (left > 0) {
@@ -1819,7 +1822,11 @@ struct Reader32 {
   }
   __device__ __forceinline__ void fetch4(const uint8_t *pay, unsigned &a, unsigned &b, unsigned &c, unsigned &d) {
     if (left >= 128) { // sixteen bytes of data: one load
+#ifdef VC2HIP_ABLATE
+      const Dword4 v = *(const Dword4 *)(pay + (off & dbg_mask));
+#else
       const Dword4 v = *(const Dword4 *)(pay + off);
+#endif
       a = __builtin_bswap32(v.x); b = __builtin_bswap32(v.y); c = __builtin_bswap32(v.z); d = __builtin_bswap32(v.w);
       off += 16;
       left -= 128;
@@ -1880,8 +1887,17 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
   __shared__ unsigned lut[UNP_LUT_N];
   for (int i = threadIdx.x * 4; i < UNP_LUT_N; i += blockDim.x * 4) *(uint4 *)(lut + i) = *(const uint4 *)(g_unp_lut + i);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pic = blockIdx.y, comp = blockIdx.z;
-  const int slice0 = blockIdx.x * (64 * VC2_UNP16_WAVES) + wave * 64, slice = slice0 + lane;
+  // One-dimensional work list: workgroup b runs on XCD b mod 8 (each with its own L2), and the Y, U and V passes over the
+  // same 256 slices read the same payload lines -- with (blocks, pictures, 3) as the grid they were 2048 workgroups apart
+  // and every line was fetched again for each (rocprofv3 FETCH_SIZE 3.9 x the payload, round 3).  Here the three
+  // components of a block of slices are consecutive in dispatch order ON THE SAME XCD: b = ((g * 3 + comp) * 8 + x),
+  // block = g * 8 + x.
+  const int pic = blockIdx.y;
+  const int nblk = (p.n_slices + 64 * VC2_UNP16_WAVES - 1) / (64 * VC2_UNP16_WAVES);
+  const int bx = blockIdx.x & 7, bg = blockIdx.x >> 3;
+  const int comp = bg % 3, blk = (bg / 3) * 8 + bx;
+  if (blk >= nblk) return; // (the list is padded to whole groups of eight blocks)
+  const int slice0 = blk * (64 * VC2_UNP16_WAVES) + wave * 64, slice = slice0 + lane;
   const bool active = slice < p.n_slices;
   const int n = p.comp_n[comp];
   short *st = stage[wave] + lane * UNP_PITCH;
@@ -1917,6 +1933,9 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
       }
       pos = at < plen ? (unsigned)at : 0u;
     }
+#ifdef VC2HIP_ABLATE
+    br.dbg_mask = VC2_SKIP(p, 1) ? 0x3FFCu : ~0u;
+#endif
     br.init(pay, pos + mis, (int)len);
   }
 #pragma unroll
@@ -1982,8 +2001,8 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
     const short *sw = stage[wave];
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v2i __attribute__((ext_vector_type(2)));
-    const int rec_end = min(room, p.bp.from[comp] - base); // coefficients of this round that belong in the slice record
-    if (rec_end > 0) {
+    const int rec_end = VC2_SKIP(p, 2) ? room : min(room, p.bp.from[comp] - base); // coefficients of this round that belong in the slice record
+    if (rec_end > 0 && !VC2_SKIP(p, 2)) {
 #pragma unroll
       for (int j = 0; j < PR; ++j) {
         const int r = j * (64 / PR) + lane / PR, c = (lane % PR) * 8;
@@ -2053,12 +2072,16 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
 
 void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipStream_t s) {
   UnpackParams p = p0;
+#ifdef VC2HIP_ABLATE
+  { const char *e = getenv("VC2HIP_DEBUG_UNPACK"); p.debug_skip = e ? atoi(e) : 0; }
+#endif
   if (!p.bp.levels) for (int c = 0; c < 3; ++c) p.bp.from[c] = 1 << 30; // everything in the slice records
   if (p.xs < 1) p.xs = 1;
   vc2_prof_begin(L, "hq_unpack", s);
   if (p.store16) {
     constexpr int T = 64 * VC2_UNP16_WAVES;
-    VC2_LAUNCH(L, k_hq_unpack16, dim3((p.n_slices + T - 1) / T, n_pictures, 3), dim3(T), 0, s, p);
+    const int nblk = (p.n_slices + T - 1) / T;
+    VC2_LAUNCH(L, k_hq_unpack16, dim3(((nblk + 7) / 8) * 8 * 3, n_pictures), dim3(T), 0, s, p);
     vc2_prof_end(L, s);
     return;
   }

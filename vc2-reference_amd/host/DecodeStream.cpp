@@ -8,10 +8,13 @@
 #include <cstring>
 #include <memory>
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <fstream>
 #include <iostream>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include <fcntl.h>
@@ -91,8 +94,10 @@ int main(int argc, char *argv[]) {
 
     std::ifstream inFile; std::ofstream outFile;
     std::ostream *out = &cout;
-    if (inFileName != "-") { inFile.open(inFileName.c_str(), std::ios::binary); if (!inFile) { perror((string("Failed to open input file \"") + inFileName + "\"").c_str()); return EXIT_FAILURE; } inFile.close(); }
-    if (outFileName != "-") { outFile.open(outFileName.c_str(), std::ios::binary); if (!outFile) { perror((string("Failed to open output file \"") + outFileName + "\"").c_str()); return EXIT_FAILURE; } out = &outFile; }
+    // (the input is opened once, below, as a descriptor: opening and closing it here first would drop the only reader of a
+    // named pipe whose writer is already producing)
+    // (decoded pictures go out through a raw descriptor, below; the stream serves the diagnostic outputs)
+    if (outFileName != "-" && output != DECODED) { outFile.open(outFileName.c_str(), std::ios::binary); if (!outFile) { perror((string("Failed to open output file \"") + outFileName + "\"").c_str()); return EXIT_FAILURE; } out = &outFile; }
     // the whole stream: a regular file is mapped (no copy at all until a picture's bytes go into a pinned buffer), a pipe
     // is read in 8 MiB pieces (the round-2 tool read either through istreambuf_iterator, a byte at a time)
     struct Bytes {
@@ -129,7 +134,11 @@ int main(int argc, char *argv[]) {
     if (output == DECODED) {
       out->flush();
       struct stat st;
-      ofd = outFileName == "-" ? 1 : ::open(outFileName.c_str(), O_WRONLY);
+      // A regular file is NOT truncated up front: every picture has its place, and the size is set once at the end (also on
+      // an error: exactly the frames written before it remain, as with the reference's tool).  Decoding over an existing
+      // file of the same size then reuses its pages -- on the GPU boxes a NEW file in /dev/shm takes 4 - 6 GB/s however
+      // many threads fill it (tools/probe/pagetouch.c: the kernel's page allocation for the file), a populated one 10+.
+      ofd = outFileName == "-" ? 1 : ::open(outFileName.c_str(), O_WRONLY | O_CREAT, 0666);
       if (ofd < 0) { perror((string("Failed to open output file \"") + outFileName + "\"").c_str()); return EXIT_FAILURE; }
       outSeekable = outFileName != "-" && fstat(ofd, &st) == 0 && S_ISREG(st.st_mode);
     }
@@ -157,11 +166,8 @@ int main(int argc, char *argv[]) {
     // Decoded output: pictures go to the per-GPU workers (picture k to worker k mod N, two in flight per worker:
     // Pipeline.h) and come back in order.  The largest data unit of the input bounds a picture's payload.
     std::size_t maxUnit = 0;
-    long long nSeqHeaders = 0, nPictureUnits = 0, nFragmentUnits = 0; // (for the mapped output below)
     for (std::size_t p0 = pos; p0 + 13 <= s.size();) {
       const std::size_t nxt = ((std::size_t)s[p0 + 5] << 24) | ((std::size_t)s[p0 + 6] << 16) | ((std::size_t)s[p0 + 7] << 8) | s[p0 + 8];
-      const unsigned code = s[p0 + 4];
-      if (code == 0x00) ++nSeqHeaders; else if (code == 0xE8 || code == 0xC8) ++nPictureUnits; else if (code == 0xEC || code == 0xCC) ++nFragmentUnits;
       if (nxt == 0) { maxUnit = std::max(maxUnit, s.size() - p0); break; }
       maxUnit = std::max(maxUnit, nxt);
       p0 += nxt;
@@ -169,7 +175,15 @@ int main(int argc, char *argv[]) {
     std::unique_ptr<GpuWorkers> workers;
     unsigned long long seq = 0;
     std::size_t seqPictureBytes = 0; // raw bytes of one picture of the current worker pool
-    unsigned char *outMap = nullptr; std::size_t outMapBytes = 0; // the mapped output file (one-sequence streams)
+    double ctxSeconds = 0;
+    std::mutex writeMutex; // pwrites of several threads to one file queue behind its inode lock and take longer than one after the other (pagetouch.c)
+    long long doneBytes = 0; // end of the last frame written in order
+    // the size of a regular output file: the frames written in order (on every way out of this block)
+    auto finishFile = [&]() {
+      workers.reset(); // (joins the workers: none of them is still writing)
+      if (outSeekable && ofd > 1) { if (ftruncate(ofd, (off_t)doneBytes) != 0) {} }
+    };
+    struct FileGuard { std::function<void()> f; ~FileGuard() { f(); } } fileGuard{finishFile};
     const bool stats = getenv("VC2_TOOL_STATS") != nullptr; // steady-state rate on stderr, as in EncodeStream
     const int warmPics = 4 * (int)devices.size();
     std::chrono::steady_clock::time_point tWarm, tStart = std::chrono::steady_clock::now();
@@ -187,9 +201,11 @@ int main(int argc, char *argv[]) {
         if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
         writeAt(outFrame.data(), outFrame.size(), outPos);
         outPos += (long long)outFrame.size();
+        doneBytes += (long long)outFrame.size();
       } else {
         if (verbose) clog << "Clipping output" << endl << "Writing decoded output file" << endl;
         if (!sinkWrites) { writeAt(r.bytes.data(), r.bytes.size(), outPos); outPos += (long long)r.bytes.size(); }
+        doneBytes += (long long)seqPictureBytes;
       }
       ++frame;
       if (frame == warmPics) tWarm = std::chrono::steady_clock::now();
@@ -214,30 +230,21 @@ int main(int argc, char *argv[]) {
         vc2hip_coding_params cp = {(int)pre.wavelet_kernel, pre.depth, pre.slices_y, pre.slices_x, ld ? VC2HIP_LD : VC2HIP_HQ_CONSTQ, 0,
                                    compressedBytes, pre.slice_prefix, pre.slice_size_scalar};
         if (!workers) {
+          const std::chrono::steady_clock::time_point tCtx0 = std::chrono::steady_clock::now();
           workers.reset(new GpuWorkers(devices, std::max(maxUnit, dlen), vc2hip_raw_picture_bytes(&pf)));
+          ctxSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tCtx0).count();
           seqPictureBytes = vc2hip_raw_picture_bytes(&pf);
           sinkWrites = outSeekable && !interlaced;
           outBase = outPos;
           if (sinkWrites) {
             const long long base = outBase;
             const std::size_t pb = seqPictureBytes;
-            // One sequence of whole pictures (the usual stream): the output's size is known, so the file is sized and mapped
-            // once and every worker copies its picture into its place -- page faults of a mapping run in parallel, pwrites
-            // to one file queue behind its inode lock (measured: four workers slower than one).  Otherwise: pwrite.
-            unsigned char *omap = nullptr;
-            if (nSeqHeaders == 1 && nFragmentUnits == 0 && nPictureUnits > 0 && base == 0) {
-              const long long total = nPictureUnits * (long long)pb;
-              if (ftruncate(ofd, (off_t)total) == 0) {
-                const int rfd = ::open(outFileName.c_str(), O_RDWR);
-                void *m = rfd >= 0 ? mmap(nullptr, (std::size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, rfd, 0) : MAP_FAILED;
-                if (rfd >= 0) ::close(rfd);
-                if (m != MAP_FAILED) { omap = (unsigned char *)m; outMap = omap; outMapBytes = (std::size_t)total; }
-              }
-            }
-            workers->setSink([&writeAt, base, pb, omap](unsigned long long sq, const unsigned char *data, std::size_t len, const string &err) {
+            // every worker writes its picture into its place, straight from its pinned buffer, one pwrite at a time (round 3
+            // mapped the file and let the workers' copies fault its pages in: 104 - 129 frames/s; see the note at the open)
+            workers->setSink([&writeAt, &writeMutex, base, pb](unsigned long long sq, const unsigned char *data, std::size_t len, const string &err) {
               if (!err.empty() || !len) return;
-              if (omap) std::memcpy(omap + sq * pb, data, len);
-              else writeAt(data, len, base + (long long)sq * (long long)pb);
+              std::lock_guard<std::mutex> lock(writeMutex);
+              writeAt(data, len, base + (long long)sq * (long long)pb);
             });
           }
         }
@@ -424,14 +431,12 @@ int main(int argc, char *argv[]) {
     out->flush();
     if (stats && output == DECODED) {
       const std::chrono::steady_clock::time_point tEnd = std::chrono::steady_clock::now();
-      cerr << "DecodeStream stats: " << frame << " frames in " << std::chrono::duration<double>(tEnd - tStart).count() << " s";
+      cerr << "DecodeStream stats: " << frame << " frames in " << std::chrono::duration<double>(tEnd - tStart).count() << " s (" << ctxSeconds
+           << " s of it creating the workers' contexts)";
       if (frame > warmPics + 1) cerr << "; steady state " << (double)(frame - warmPics) / std::chrono::duration<double>(tEnd - tWarm).count() << " frames/s";
       cerr << endl;
     }
-    if (outMap) { // (pictures that failed to decode leave their place zero, as a sparse write would)
-      munmap(outMap, outMapBytes);
-      if (ftruncate(ofd, (off_t)((long long)frame * (long long)seqPictureBytes)) != 0) {}
-    }
+    finishFile();
     if (ofd > 1) ::close(ofd);
   } catch (const std::exception &ex) {
     cout << "Error: " << ex.what() << endl;

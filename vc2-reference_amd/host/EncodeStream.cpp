@@ -243,7 +243,9 @@ int main(int argc, char *argv[]) {
       const bool inRegular = ifd >= 0 && fstat(ifd, &st) == 0 && S_ISREG(st.st_mode) && inFileName != "-";
       const long long inSize = inRegular ? (long long)st.st_size : 0;
       int ofd = 1;
-      if (outFileName != "-") { outFile.close(); ofd = ::open(outFileName.c_str(), O_WRONLY | O_APPEND); }
+      // (the raw descriptor is opened BEFORE the stream that wrote the sequence header is closed: a named pipe never
+      // sees a moment without a writer, which its reader would take for the end of the stream)
+      if (outFileName != "-") { ofd = ::open(outFileName.c_str(), O_WRONLY | O_APPEND); outFile.close(); }
       if (ifd < 0 || ofd < 0) throw std::runtime_error("cannot reopen the input / output file for the pipelined path");
       const bool outSeekable = outFileName != "-" && fstat(ofd, &st) == 0 && S_ISREG(st.st_mode);
       if (outSeekable) { ::close(ofd); ofd = ::open(outFileName.c_str(), O_WRONLY); } // (pwrite ignores the offset of O_APPEND descriptors)
@@ -255,7 +257,9 @@ int main(int argc, char *argv[]) {
           p += r; n -= (std::size_t)r; at += r;
         }
       };
+      const std::chrono::steady_clock::time_point tCtx0 = std::chrono::steady_clock::now();
       GpuWorkers workers(devices, picBytes, vc2hip_max_payload_bytes(&pf, &cp) + 64);
+      const double ctxSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tCtx0).count();
       const utils::Rational ldRatio = utils::rationalise(pictureBytes, ySlices * xSlices);
       // ---- the ordered part of the writer
       std::mutex om;
@@ -321,6 +325,9 @@ int main(int argc, char *argv[]) {
       PictureResult res;
       auto drain = [&](bool all) { // completed pictures (their bytes went through the sink): errors surface in order
         while (all ? workers.wait(res) : workers.poll(res)) if (!res.error.empty()) throw std::logic_error(res.error);
+        // a failed write (a full disk) ends the run at once instead of coding the rest of the input for nothing
+        std::lock_guard<std::mutex> l2(om);
+        if (!firstError.empty()) throw std::logic_error(firstError);
       };
       const long long wholeFrames = inRegular ? inSize / (long long)frameBytes : -1;
       for (;; ++frame) {
@@ -366,7 +373,7 @@ int main(int argc, char *argv[]) {
       if (stats) {
         const std::chrono::steady_clock::time_point tEnd = std::chrono::steady_clock::now();
         const double all = std::chrono::duration<double>(tEnd - tStart).count();
-        cerr << "EncodeStream stats: " << seq << " pictures in " << all << " s";
+        cerr << "EncodeStream stats: " << seq << " pictures in " << all << " s (" << ctxSeconds << " s of it creating the workers' contexts)";
         if (seq > warmPics + 1) cerr << "; steady state " << (double)(seq - warmPics) / std::chrono::duration<double>(tEnd - tWarm).count() << " pictures/s";
         cerr << endl;
       }
