@@ -167,7 +167,7 @@ struct PackParams {
   float inv_scalar;           // set by the launcher: the smallest float >= 1 / scalar
   union {
     unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
-    unsigned lane16[128];        // k_hq_pack16 (vc2hip_pack16.h): per lane, where its coefficients lie and their matrix entries
+    unsigned lane16[200];        // k_hq_pack16 / k_hq_pack16w (vc2hip_pack16.h): per lane, the matrix entries of its coefficients; head / body sizes
   };
   int debug_skip;             // timing experiments only (VC2HIP_DEBUG_PACK): 1 no code writes, 2 no copy-out
   // single-pass VBR: slice offsets by decoupled look-back over workgroup tiles (4 slices each).
@@ -238,10 +238,7 @@ struct CbrParams {
   int only_marked;            // set by the launcher: search only the slices whose index is VC2_CBR_MARK
   float inv_scalar;           // set by the launcher
   int qm_min;                 // set by the launcher: the smallest matrix entry
-  union {
-    unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
-    unsigned lane16[128];        // k_hq_pack16 (vc2hip_pack16.h): per lane, where its coefficients lie and their matrix entries
-  };
+  unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
 };
 #define VC2_CBR_MARK 0x7FFFFFFF
 

@@ -26,6 +26,12 @@
 // int32 store, unquantised input, look-back VBR and images beyond LDS keep k_hq_pack.
 #pragma once
 
+#ifdef VC2HIP_ABLATE // why wavefronts leave the table path (tools/probe: VC2HIP_P16_STATS=1 prints the counters after every launch)
+__device__ unsigned g_p16_stats[8];
+#define P16_STAT(k, cond) do { if (__any(cond) && lane == 0) atomicAdd(&g_p16_stats[k], 1u); } while (0)
+#else
+#define P16_STAT(k, cond)
+#endif
 constexpr int P16_LUT_N = 256;            // quotient as a signed byte: entries 0..127 = +0..+127, 128..255 = -128..-1
 constexpr int P16_MAXQ = 126;             // |quotient| the table path takes: codes of <= 14 bits, pairs of <= 28
 __device__ unsigned g_vlc_lut_s[P16_LUT_N]; // length << 24 | (non-zero ? 0xFF : 0) << 16 | code with its sign bit (<= 14 bits)
@@ -175,10 +181,13 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
   unsigned *lut = lds_u;                   // at LDS address 0: a look-up's address is the quotient's low byte times four
   float *inv = (float *)(lut + P16_LUT_N); // 128 entries, [120..127] = 0: indices beyond the table quantise to zero
-  unsigned *img = lds_u + P16_LUT_N + 128 + wave * img_q * 4;
+  uint4 *qt = (uint4 *)(lds_u + P16_LUT_N + 128); // by quantiser index: (magic, shift, factor, -) of the exact integer division (the head)
+  unsigned *img = lds_u + P16_LUT_N + 128 + 4 * 128 + wave * img_q * 4;
   // the tables' loads first (L2), the record's behind them: the table writes and the barrier then wait for the former only
   const unsigned lut_e = threadIdx.x < P16_LUT_N ? g_vlc_lut_s[threadIdx.x] : 0u;
   const float inv_e = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
+  const uint4 qt_e = threadIdx.x < 120 ? make_uint4(c_qs.magic[threadIdx.x], (unsigned)c_qs.shift[threadIdx.x], (unsigned)c_qs.qf[threadIdx.x], 0u)
+                                       : make_uint4(0u, 0u, 0x40000000u, 0u);
   const unsigned lt = p.lane16[lane];
   const int comp = lane < 32 ? 0 : (lane < 48 ? 1 : 2), cl = lane - (lane < 32 ? 0 : (lane < 48 ? 32 : 48));
   const int head_n = (int)(comp == 0 ? p.lane16[64] : (comp == 1 ? p.lane16[65] : p.lane16[66]));
@@ -191,8 +200,9 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   int hv = 0;
   if (active && has_body) { const int16_t *b = rec + coff + head_n + 16 * cl; w0 = *(const uint4 *)b; w1 = *(const uint4 *)(b + 8); }
   if (active && has_head) hv = rec[coff + cl];
+  const int32_t *hwide = p.store_wide + rec_at + coff + cl; // the head coefficient's place in the wide array (an escape of the 16-bit store)
   if (threadIdx.x < P16_LUT_N) lut[threadIdx.x] = lut_e;
-  if (threadIdx.x < 128) inv[threadIdx.x] = inv_e;
+  if (threadIdx.x < 128) { inv[threadIdx.x] = inv_e; qt[threadIdx.x] = qt_e; }
   for (int i = lane; i < img_q; i += 64) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   if (!active) return;
@@ -200,7 +210,8 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   const int q = p.qidx[(size_t)pic * p.n_slices + slice];
   const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
-  const float fb = inv[min(aqb, 120)], fh = inv[min(aqh, 120)];
+  const float fb = inv[min(aqb, 120)];
+  const uint4 qh = qt[min(aqh, 120)]; // (index 120: a factor of 2^30 -- every 32-bit value quantises to zero)
 
   // ---- body: two strings of eight coefficients
   unsigned long long G0, G1;
@@ -216,10 +227,15 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   int hbits = 0;
   bool hnz = false;
   if (has_head) {
-    slow |= hv == VC2_ST_SENTINEL;
-    const int t = (int)((float)hv * fh);
+    // the deepest levels' coefficients are the ones that outgrow sixteen bits (and 2^20, where the float quotient stops
+    // being exact: Fidelity's LL of a 12-bit picture after five levels reaches 1.5 million): an escape is fetched from the
+    // wide array here and the quotient is the exact integer division of quant_core, one coefficient per lane; a code has
+    // at most 32 bits (VLC.h:27) -- beyond that, the general coder raises the error
+    if (hv == VC2_ST_SENTINEL) hv = *hwide;
+    const int t = quant_core(hv, (int)qh.z, qh.x, (int)qh.y);
+    slow |= (unsigned)(t + 65534) > 2u * 65534u;
     hcode = svlc_code(t);
-    hbits = svlc_bits(t); // <= 32: |t| <= 32767
+    hbits = svlc_bits(t);
     hnz = t != 0;
   }
 
@@ -239,6 +255,8 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
     return vb;
   };
 
+  P16_STAT(0, true); P16_STAT(1, has_body && maxf >= 32768.f); P16_STAT(2, has_body && maxf * fb >= (float)(P16_MAXQ + 1));
+  P16_STAT(3, has_body && max(L0, L1) > 63); P16_STAT(4, slow);
   if (__builtin_expect(__any(slow), 0)) {
     // the general coder, component by component: measure, then write (the image is still all zeros)
     const int32_t *recw = p.store_wide + rec_at;
@@ -335,7 +353,196 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_hq_pack16w: the same coder for LARGE slices -- a wavefront per COMPONENT, a workgroup (three wavefronts) per slice.
+// A component of up to 64 head coefficients + 64 runs of sixteen (1024 + 64 coefficients: 32 x 32 slices at depth 5,
+// UHD-2 4:4:4) does not fit the 32 / 16 / 16 lanes k_hq_pack16 gives it.  Here every wavefront codes its own component
+// into the slice's one image; the three bit counts meet in LDS over a barrier (a component starts where the one before it
+// ends), and each wavefront decides on its own whether its component takes the table path or the general coder.
+//   lane16[64 c + lane] = matrix entry of the lane's body run | of its head coefficient << 8;  lane16[192 + c] = head[c],
+//   lane16[195 + c] = body lanes of component c
+static bool pack16w_plan(const PackParams &p, unsigned *lane16) {
+  if (!p.store16 || !p.quantise || p.lookback || p.tile_slices) return false;
+  for (int l = 0; l < 200; ++l) lane16[l] = 0;
+  int body_lanes = 0;
+  for (int c = 0; c < 3; ++c) {
+    const int n = p.comp_n[c], n0 = p.comp_n0[c];
+    if (n <= 0 || n0 <= 0 || (p.comp_off[c] & 7)) return false;
+    int start = 0, head = -1;
+    for (int b = 0; b < 3 * p.depth + 1; ++b) {
+      const int size = b == 0 ? n0 : n0 << (2 * ((b - 1) / 3));
+      if (p.qmatrix[b] < 0 || p.qmatrix[b] > 255) return false;
+      if (head < 0 && (size & 15) == 0 && (start & 15) == 0) head = start;
+      if (head < 0) {
+        if (start + size > 64) return false;
+        for (int j = start; j < start + size; ++j) lane16[64 * c + j] |= (unsigned)p.qmatrix[b] << 8;
+      } else {
+        if ((start + size - head) / 16 > 64) return false;
+        for (int j = start; j < start + size; j += 16) lane16[64 * c + (j - head) / 16] |= (unsigned)p.qmatrix[b];
+      }
+      start += size;
+    }
+    if (start != n) return false;
+    if (head < 0) head = n;
+    if (head & 7) return false;
+    lane16[192 + c] = (unsigned)head;
+    lane16[195 + c] = (unsigned)((n - head) / 16);
+    body_lanes += (n - head) / 16;
+  }
+  return body_lanes >= 120; // (smaller slices: k_hq_pack16 or k_hq_pack)
+}
+
+template <bool CBR>
+__global__ __launch_bounds__(192) void k_hq_pack16w(const PackParams p) {
+  extern __shared__ unsigned lds_u[];
+  __shared__ int s_cnt[3];
+  const int lane = threadIdx.x & 63, comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wavefront = component
+  const int pic = blockIdx.y, slice = blockIdx.x;
+  const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
+  unsigned *lut = lds_u;
+  float *inv = (float *)(lut + P16_LUT_N);
+  uint4 *qt = (uint4 *)(lds_u + P16_LUT_N + 128);
+  unsigned *img = lds_u + P16_LUT_N + 128 + 4 * 128;
+  unsigned lut_e[2];
+  lut_e[0] = g_vlc_lut_s[threadIdx.x];
+  lut_e[1] = threadIdx.x < P16_LUT_N - 192 ? g_vlc_lut_s[192 + threadIdx.x] : 0u;
+  const float inv_e = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
+  const uint4 qt_e = threadIdx.x < 120 ? make_uint4(c_qs.magic[threadIdx.x], (unsigned)c_qs.shift[threadIdx.x], (unsigned)c_qs.qf[threadIdx.x], 0u)
+                                       : make_uint4(0u, 0u, 0x40000000u, 0u);
+  const unsigned lt = p.lane16[64 * comp + lane];
+  const int head_n = (int)p.lane16[192 + comp], body_n = (int)p.lane16[195 + comp], coff = p.comp_off[comp];
+  const bool has_body = lane < body_n, has_head = lane < head_n;
+  const size_t rec_at = (size_t)pic * p.store_stride + (size_t)slice * p.slice_coefs;
+  const int16_t *rec = (const int16_t *)p.store + rec_at;
+  uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
+  int hv = 0;
+  if (has_body) { const int16_t *b = rec + coff + head_n + 16 * lane; w0 = *(const uint4 *)b; w1 = *(const uint4 *)(b + 8); }
+  if (has_head) hv = rec[coff + lane];
+  const int32_t *hwide = p.store_wide + rec_at + coff + lane;
+  lut[threadIdx.x] = lut_e[0];
+  if (threadIdx.x < P16_LUT_N - 192) lut[192 + threadIdx.x] = lut_e[1];
+  if (threadIdx.x < 128) { inv[threadIdx.x] = inv_e; qt[threadIdx.x] = qt_e; }
+  for (int i = threadIdx.x; i < img_q; i += 192) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+
+  const int q = p.qidx[(size_t)pic * p.n_slices + slice];
+  const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
+  if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
+  const float fb = inv[min(aqb, 120)];
+  const uint4 qh = qt[min(aqh, 120)]; // (index 120: a factor of 2^30 -- every 32-bit value quantises to zero)
+  unsigned long long G0, G1;
+  int L0, L1, last0, last1;
+  float maxf = 0.f;
+  p16_group(w0, fb, lut, G0, L0, last0, maxf);
+  p16_group(w1, fb, lut, G1, L1, last1, maxf);
+  int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
+  bool slow = maxf >= 32768.f || maxf * fb >= (float)(P16_MAXQ + 1) || max(L0, L1) > 63;
+  if (!has_body) { body_bits = 0; body_last = 0; slow = false; }
+  unsigned hcode = 0;
+  int hbits = 0;
+  bool hnz = false;
+  if (has_head) {
+    // the deepest levels' coefficients are the ones that outgrow sixteen bits (and 2^20, where the float quotient stops
+    // being exact: Fidelity's LL of a 12-bit picture after five levels reaches 1.5 million): an escape is fetched from the
+    // wide array here and the quotient is the exact integer division of quant_core, one coefficient per lane; a code has
+    // at most 32 bits (VLC.h:27) -- beyond that, the general coder raises the error
+    if (hv == VC2_ST_SENTINEL) hv = *hwide;
+    const int t = quant_core(hv, (int)qh.z, qh.x, (int)qh.y);
+    slow |= (unsigned)(t + 65534) > 2u * 65534u;
+    hcode = svlc_code(t);
+    hbits = svlc_bits(t);
+    hnz = t != 0;
+  }
+  P16_STAT(0, true); P16_STAT(1, has_body && maxf >= 32768.f); P16_STAT(2, has_body && maxf * fb >= (float)(P16_MAXQ + 1));
+  P16_STAT(3, has_body && max(L0, L1) > 63); P16_STAT(4, slow);
+  const bool general = __any(slow); // this component only
+  const int16_t *src = rec + coff;
+  const int32_t *srcw = p.store_wide + rec_at + coff;
+  int hpos = 0, bpos = 0, count;
+  if (__builtin_expect(general, 0)) {
+    count = p16_general<false>(src, srcw, p.comp_n[comp], p.comp_n0[comp], q, p.qmatrix, lane, nullptr, 0, 0, p.err);
+  } else {
+    const int pk = (hbits << 16) | body_bits;
+    const int s = seg_incl_scan<64>(pk, lane);
+    const int tot = __builtin_amdgcn_readlane(s, 63);
+    const int excl = s - pk;
+    hpos = excl >> 16;
+    bpos = (tot >> 16) + (excl & 0xFFFF);
+    const int endpos = body_last ? bpos + body_last : (hnz ? hpos + hbits : 0);
+    const unsigned long long nzb = __ballot(body_last != 0), nzh = __ballot(hnz);
+    const unsigned long long m = nzb ? nzb : nzh;
+    count = m ? __builtin_amdgcn_readlane(endpos, 63 - __builtin_clzll(m)) : 0;
+  }
+  if (lane == 0) s_cnt[comp] = count;
+  __syncthreads();
+  bool bad_cbr = false;
+  int bytes[3];
+  auto comp_len = [&](int cnt) -> int {
+    int len = (int)((float)(((cnt + 7) >> 3) + p.scalar - 1) * p.inv_scalar);
+    if (len > 255) { atomicOr(p.err, VC2_DEVERR_SCALAR); len = 255; }
+    return len * p.scalar;
+  };
+  bytes[0] = comp_len(s_cnt[0]);
+  bytes[1] = comp_len(s_cnt[1]);
+  bytes[2] = comp_len(s_cnt[2]);
+  if (CBR) { // Slices.cpp:352-368: V absorbs the remainder of the slice
+    const int vb = p.cbr_bytes[slice] - 4 - bytes[0] - bytes[1];
+    if (vb < bytes[2]) { if (threadIdx.x == 0) atomicOr(p.err, VC2_DEVERR_CBR_TOOBIG); bad_cbr = true; }
+    else if (vb / p.scalar > 255) { if (threadIdx.x == 0) atomicOr(p.err, VC2_DEVERR_CBR_LEN); bad_cbr = true; }
+    else bytes[2] = vb;
+  }
+  const int len_at = p.prefix + 1 + (comp > 0 ? 1 + bytes[0] : 0) + (comp > 1 ? 1 + bytes[1] : 0);
+  const int mine = comp == 0 ? bytes[0] : (comp == 1 ? bytes[1] : bytes[2]);
+  const int bit0 = 8 * (len_at + 1), room = 8 * mine;
+  if (general) {
+    p16_general<true>(src, srcw, p.comp_n[comp], p.comp_n0[comp], q, p.qmatrix, lane, img, bit0, room, p.err);
+  } else {
+    if (hbits && hpos + hbits <= room) {
+      const unsigned v = hcode << (32 - hbits);
+      unsigned *at = img + ((bit0 + hpos) >> 5);
+      const unsigned bo = (unsigned)(bit0 + hpos);
+      atomicOr(at, __builtin_amdgcn_alignbit(0u, v, bo));
+      atomicOr(at + 1, __builtin_amdgcn_alignbit(v, 0u, bo));
+    }
+    if (has_body) {
+      const int keep = min(max(room - bpos, 0), body_bits), k0 = min(keep, L0);
+      p16_put(img, bit0 + bpos, G0, L0, k0);
+      p16_put(img, bit0 + bpos + L0, G1, L1, keep - k0);
+    }
+  }
+  if (lane == 0) put_byte(img, len_at, (unsigned)((float)mine * p.inv_scalar));
+  if (threadIdx.x == 1) put_byte(img, p.prefix, (unsigned)q & 0xFFu);
+  const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
+  __syncthreads();
+  if (CBR) {
+    if (bad_cbr) return;
+    uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
+    const int t = threadIdx.x;
+    const int head = min((int)((4 - ((size_t)dst & 3)) & 3), total);
+    const int nw = (total - head) >> 2, tail0 = head + 4 * nw;
+    if (t < head) dst[t] = (uint8_t)(img[t >> 2] >> (24 - 8 * (t & 3)));
+    if (t < total - tail0) { const int i = tail0 + t; dst[i] = (uint8_t)(img[i >> 2] >> (24 - 8 * (i & 3))); }
+    unsigned *d4 = (unsigned *)(dst + head);
+    for (int w = t; w < nw; w += 192) {
+      const int i0 = head + 4 * w;
+      const unsigned lo = __builtin_bswap32(img[i0 >> 2]), hi = __builtin_bswap32(img[(i0 >> 2) + 1]);
+      d4[w] = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(i0 & 3));
+    }
+  } else {
+    uint8_t *dst = p.slots + ((size_t)pic * p.n_slices + slice) * p.slot_bytes;
+    if (threadIdx.x == 0) p.sizes[(size_t)pic * p.n_slices + slice] = (unsigned)total;
+    for (int i = threadIdx.x * 16; i < total; i += 192 * 16) {
+      const uint4 v = *(const uint4 *)((const uint8_t *)img + i);
+      *(uint4 *)(dst + i) = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    }
+  }
+}
+
+static size_t pack16w_lds(int prefix, int scalar) {
+  const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
+  return img_q * 16 + P16_LUT_N * 4 + 128 * 4 + 128 * 16;
+}
 static size_t pack16_lds(int prefix, int scalar) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
-  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 4;
+  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 4 + 128 * 16;
 }

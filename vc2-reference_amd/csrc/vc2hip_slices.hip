@@ -824,6 +824,19 @@ int vc2_pack_slices_per_tile(const PackParams &p) {
   const int W = pack_lanes(p);
   return W == 64 ? 0 : 4 * (64 / W);
 }
+#ifdef VC2HIP_ABLATE
+static void p16_print_stats(hipStream_t s) {
+  static const bool on = getenv("VC2HIP_P16_STATS") != nullptr;
+  if (!on) return;
+  unsigned h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p16_stats), sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p16_stats), z, sizeof z);
+  fprintf(stderr, "pack16: wavefronts %u, store escape %u, quotient beyond the table %u, string beyond 63 bits %u, general path %u\n", h[0], h[1], h[2], h[3], h[4]);
+}
+#else
+static void p16_print_stats(hipStream_t) {}
+#endif
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
@@ -842,6 +855,23 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
       VC2_LAUNCH(L, k_hq_pack16<false>, grid, dim3(256), lds, s, p);
     }
     vc2_prof_end(L, s);
+    p16_print_stats(s);
+    return;
+  }
+  if (use16 && pack16w_lds(p.prefix, p.scalar) <= 64 * 1024 && pack16w_plan(p, p.lane16)) {
+    // large slices on the 16-bit store: a wavefront per component, a workgroup per slice (vc2hip_pack16.h)
+    const size_t lds = pack16w_lds(p.prefix, p.scalar);
+    const dim3 grid(p.n_slices, n_pictures);
+    vc2_prof_begin(L, "hq_pack", s);
+    if (p.cbr_bytes) {
+      vc2_allow_lds((const void *)k_hq_pack16w<true>, 64 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16w<true>, grid, dim3(192), lds, s, p);
+    } else {
+      vc2_allow_lds((const void *)k_hq_pack16w<false>, 64 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16w<false>, grid, dim3(192), lds, s, p);
+    }
+    vc2_prof_end(L, s);
+    p16_print_stats(s);
     return;
   }
   fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
@@ -1750,7 +1780,10 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 #ifndef UNP_LONG_EVERY
 #define UNP_LONG_EVERY 0
 #endif
-constexpr int UNP_LUT_BITS = 10, UNP_LUT_N = 1 << UNP_LUT_BITS;
+#ifndef VC2_UNP_LUT_BITS
+#define VC2_UNP_LUT_BITS 10
+#endif
+constexpr int UNP_LUT_BITS = VC2_UNP_LUT_BITS, UNP_LUT_N = 1 << UNP_LUT_BITS;
 __device__ unsigned g_unp_lut[UNP_LUT_N];
 void vc2_upload_unpack_lut(hipStream_t s) {
   // built once (contexts are created from several worker threads at a time: the copy below may still be reading it)
