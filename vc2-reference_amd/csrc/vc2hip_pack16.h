@@ -201,13 +201,13 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   if (active && has_body) { const int16_t *b = rec + coff + head_n + 16 * cl; w0 = *(const uint4 *)b; w1 = *(const uint4 *)(b + 8); }
   if (active && has_head) hv = rec[coff + cl];
   const int32_t *hwide = p.store_wide + rec_at + coff + cl; // the head coefficient's place in the wide array (an escape of the 16-bit store)
+  const int q = p.qidx[(size_t)pic * p.n_slices + (active ? slice : 0)]; // (a scalar load: requested before the barrier, used behind it)
   if (threadIdx.x < P16_LUT_N) lut[threadIdx.x] = lut_e;
   if (threadIdx.x < 128) { inv[threadIdx.x] = inv_e; qt[threadIdx.x] = qt_e; }
   for (int i = lane; i < img_q; i += 64) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   if (!active) return;
 
-  const int q = p.qidx[(size_t)pic * p.n_slices + slice];
   const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
   const float fb = inv[min(aqb, 120)];
@@ -422,10 +422,10 @@ __global__ __launch_bounds__(192) void k_hq_pack16w(const PackParams p) {
   lut[threadIdx.x] = lut_e[0];
   if (threadIdx.x < P16_LUT_N - 192) lut[192 + threadIdx.x] = lut_e[1];
   if (threadIdx.x < 128) { inv[threadIdx.x] = inv_e; qt[threadIdx.x] = qt_e; }
+  const int q = p.qidx[(size_t)pic * p.n_slices + slice];
   for (int i = threadIdx.x; i < img_q; i += 192) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
-  const int q = p.qidx[(size_t)pic * p.n_slices + slice];
   const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
   const float fb = inv[min(aqb, 120)];

@@ -1017,6 +1017,18 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_
   if (slice >= n) return;
   const size_t si = (size_t)pic * n + slice;
   const uint8_t *src = slots + si * slot_bytes; // 16-byte aligned
+  // The first two trips' source pieces are requested BEFORE the slice's size and offset are known (the slot is the
+  // slice's own memory up to slot_bytes whatever its size): the kernel is a chain of memory latencies -- size / offset,
+  // then the source, then the stores (rocprofv3: 93 % of a wavefront's life waiting) -- and this puts the first two side
+  // by side.  A typical UHD slice (~580 bytes) is those two trips of 32 lanes.
+  const bool pre = 2 * W * 16 + 16 <= slot_bytes;
+  uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
+  unsigned nx0 = 0, nx1 = 0;
+  if (pre) {
+    const unsigned *s4p = (const unsigned *)src;
+    v0 = *(const uint4 *)(s4p + 4 * sl); nx0 = s4p[4 * sl + 4];
+    v1 = *(const uint4 *)(s4p + 4 * (sl + W)); nx1 = s4p[4 * (sl + W) + 4];
+  }
   uint8_t *dst = payload + (size_t)pic * payload_stride + offsets[si];
   const int size = (int)sizes[si];
   // dword stores for the 4-byte aligned middle of the destination (each built from two aligned source
@@ -1033,8 +1045,11 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_
   const unsigned *s4 = (const unsigned *)src;
   unsigned *d4 = (unsigned *)(dst + head);
   for (int q = sl; 4 * q < nw; q += W) {
-    const uint4 v = *(const uint4 *)(s4 + 4 * q);
-    const unsigned nx = s4[4 * q + 4];
+    uint4 v;
+    unsigned nx;
+    if (q == sl && pre) { v = v0; nx = nx0; }
+    else if (q == sl + W && pre) { v = v1; nx = nx1; }
+    else { v = *(const uint4 *)(s4 + 4 * q); nx = s4[4 * q + 4]; }
     const unsigned h = (unsigned)head;
     Dword4 o;
     o.x = __builtin_amdgcn_alignbyte(v.y, v.x, h);
@@ -1829,6 +1844,9 @@ void vc2_upload_unpack_lut(hipStream_t s) {
 #ifndef VC2_UNP_DEEP
 #define VC2_UNP_DEEP 1
 #endif
+#ifndef VC2_UNP_PAIR
+#define VC2_UNP_PAIR 0 // (1:) the stream's requests two at a time, for 32 adjacent bytes (see Reader32::skip)
+#endif
 struct Reader32 {
   unsigned long long acc;
   int have;                // valid bits in acc, 33..64 between turns
@@ -1836,7 +1854,11 @@ struct Reader32 {
   int qn;
   unsigned n0, n1, n2, n3; // the four words after the queue
 #if VC2_UNP_DEEP
-  unsigned m0, m1, m2, m3; // and the four after those: two requests in flight (eight to twelve words between a request and its use)
+  unsigned m0, m1, m2, m3; // and the four after those ...
+#if VC2_UNP_PAIR
+  unsigned o0, o1, o2, o3; // ... and four more: requests go out TWO AT A TIME, for 32 adjacent bytes (round 4, see skip())
+  int pairs;               // parity of the refills: the odd ones only shift
+#endif
 #endif
   unsigned off;            // byte offset (from the payload base) of the word after those
   int left;                // data bits from that word on (<= 0: none)
@@ -1878,6 +1900,10 @@ struct Reader32 {
     fetch4(pay);
 #if VC2_UNP_DEEP
     fetch4(pay, m0, m1, m2, m3);
+#if VC2_UNP_PAIR
+    fetch4(pay, o0, o1, o2, o3);
+    pairs = 0;
+#endif
 #endif
   }
   __device__ __forceinline__ unsigned top() const { return (unsigned)(acc >> 32); }
@@ -1889,7 +1915,21 @@ struct Reader32 {
       have += 32;
       q0 = q1; q1 = q2; q2 = q3;
 #if VC2_UNP_DEEP
+      // A lane's stream advances 16 bytes per refill, and between two refills the other 1500 lanes of the CU push its
+      // 128-byte line out of L1 and mostly out of L2: with one 16-byte request per refill a payload line was fetched up
+      // to eight times (rocprofv3 FETCH_SIZE 3.2 - 3.9 x the payload).  Every second refill now requests the next 32
+      // bytes at once (two adjacent loads, the second meets the first one's line), the others only shift: half the
+      // requests per line, the same eight words or more between a request and its use.
+#if VC2_UNP_PAIR
+      if (--qn == 0) {
+        q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4;
+        n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+        m0 = o0; m1 = o1; m2 = o2; m3 = o3;
+        if ((pairs ^= 1) == 0) { fetch4(pay, m0, m1, m2, m3); fetch4(pay, o0, o1, o2, o3); }
+      }
+#else
       if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; n0 = m0; n1 = m1; n2 = m2; n3 = m3; fetch4(pay, m0, m1, m2, m3); }
+#endif
 #else
       if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; fetch4(pay); }
 #endif
