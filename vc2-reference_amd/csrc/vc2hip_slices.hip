@@ -2209,7 +2209,7 @@ __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long
 }
 
 static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
-constexpr int idx_threads(int CH) { return CH <= 8192 ? 512 : 1024; }
+constexpr int idx_threads(int CH, int GS = 0) { return (CH >> GS) <= 8192 ? 512 : 1024; } // by the chunk's candidate positions (GS: k_index_tables_nx)
 
 // Chunk function by table walk.  One pass fills next[i] = the position reached if a slice started at byte i
 // of the chunk, from the three length bytes behind every byte position (throughput-bound LDS work: PER
@@ -2222,12 +2222,17 @@ constexpr int idx_threads(int CH) { return CH <= 8192 ? 512 : 1024; }
 // took 5 us: LDS-bound), a thread's walks advanced side by side, a persistent grid that takes the chunks from the
 // lengths and fetches the next chunk's bytes while it works (same time at 8 KiB, 0.24 against 0.16 ms at 16 KiB),
 // the workgroups of chunks beyond the payload last in the grid instead of between those of every picture.)
-template <int CH>
-__global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8_t *payload, long long stride,
+// GS: every slice of the picture starts at a multiple of G = 2^GS bytes -- a slice is prefix + 4 + scalar * (three length
+// bytes) long, so with G = the largest power of two (up to 4) in gcd(scalar, prefix + 4) every slice length and, from
+// offset 0, every slice start is a multiple of G whatever the bytes say.  Only those positions can start a slice: next[],
+// the entry offsets, the landing bytes and the tables are kept per G bytes -- half (scalar 2: cfg 2 / 3) or a quarter
+// (scalar 8: cfg 4) of the LDS reads, walks and table words of round 3 (0.31 -> 0.2 ms per 32 UHD pictures).
+template <int CH, int GS>
+__global__ __launch_bounds__(idx_threads(CH, GS)) void k_index_tables_nx(const uint8_t *payload, long long stride,
                                                                  const unsigned long long *lens, unsigned *tables,
                                                                  int n_chunks, int E, int prefix, int scalar, unsigned *err, const unsigned *skip,
                                                                  int merge) {
-  constexpr int NT = idx_threads(CH);
+  constexpr int NT = idx_threads(CH, GS), NP = CH >> GS; // candidate positions of a chunk
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
   const int chunk = blockIdx.x, pic = blockIdx.y;
@@ -2236,15 +2241,16 @@ __global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride), c0 = (unsigned long long)chunk * CH;
   if (c0 >= plen) return;
   const int nbytes = (CH + E + 16 + 15) & ~15;
-  unsigned short *nx = (unsigned short *)(lds_b + nbytes); // >= CH: left the chunk at offset nx - CH
+  const int EU = E >> GS;                                  // entry offsets (E is a multiple of G)
+  unsigned short *nx = (unsigned short *)(lds_b + nbytes); // per candidate position: the byte reached; >= CH: left the chunk at offset nx - CH
   stage_chunk(lds_b, payload + (size_t)pic * stride, plen, c0, nbytes);
   __syncthreads();
   const int lim = (int)min((unsigned long long)CH, plen - c0); // never walk the zero fill behind the payload
-  constexpr int PER = CH / NT;
+  constexpr int PER = NP / NT;
   {
     int q[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) q[k] = threadIdx.x + k * NT + prefix + 1;
+    for (int k = 0; k < PER; ++k) q[k] = ((threadIdx.x + k * NT) << GS) + prefix + 1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       int len[PER];
@@ -2261,12 +2267,12 @@ __global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8
     }
   }
   __syncthreads();
-  unsigned *tab = tables + ((size_t)pic * n_chunks + chunk) * E;
+  unsigned *tab = tables + ((size_t)pic * n_chunks + chunk) * EU;
   if (!merge) {
-    for (int e = threadIdx.x; e < E; e += NT) {
-      int pos = e, cnt = 0;
-      if (e >= lim) pos = CH; // starts behind the payload end: no slice
-      while (pos < CH) { pos = nx[pos]; ++cnt; }
+    for (int e = threadIdx.x; e < EU; e += NT) {
+      int pos = e << GS, cnt = 0;
+      if (pos >= lim) pos = CH; // starts behind the payload end: no slice
+      while (pos < CH) { pos = nx[pos >> GS]; ++cnt; }
       tab[e] = (unsigned)(pos - CH) << 16 | (unsigned)cnt;
     }
     return;
@@ -2276,25 +2282,25 @@ __global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8
   // [0, E); the distinct landing bytes are collected, walked once each to the chunk's end, and every entry adds its own
   // hops to its landing byte's result -- a fraction of the dependent LDS reads of E full walks (the kernel's time is
   // those reads).
-  unsigned *W = (unsigned *)(nx + CH);               // per byte of [E, 2E): the result of a walk from it (exit offset << 16 | slices)
-  unsigned *need = W + E;                            // one bit per byte of [E, 2E): some walk landed here
-  unsigned short *list = (unsigned short *)(need + (E + 31) / 32);  // the landing bytes, dense
+  unsigned *W = (unsigned *)(nx + NP);               // per candidate position of [E, 2E): the result of a walk from it (exit offset << 16 | slices)
+  unsigned *need = W + EU;                           // one bit per candidate position of [E, 2E): some walk landed here
+  unsigned short *list = (unsigned short *)(need + (EU + 31) / 32);  // the landing positions, dense
   __shared__ unsigned s_count;
-  for (int t = threadIdx.x; t < (E + 31) / 32; t += NT) need[t] = 0;
+  for (int t = threadIdx.x; t < (EU + 31) / 32; t += NT) need[t] = 0;
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
-  constexpr int EPT = 4096 / NT; // entries per thread (the launcher merges only entry regions of up to 4096 bytes)
+  constexpr int EPT = 4096 / NT; // entries per thread (the launcher merges only entry regions of up to 4096 offsets)
   int la[EPT], ca[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = threadIdx.x + k * NT;
     la[k] = CH; ca[k] = 0;
-    if (e < E && e < lim) {
-      int pos = e, cnt = 0;
-      while (pos < E) { pos = nx[pos]; ++cnt; }
+    if (e < EU && (e << GS) < lim) {
+      int pos = e << GS, cnt = 0;
+      while (pos < E) { pos = nx[pos >> GS]; ++cnt; }
       la[k] = pos; ca[k] = cnt;
       if (pos < CH) {
-        const int t = pos - E;
+        const int t = (pos - E) >> GS;
         if (!(atomicOr(&need[t >> 5], 1u << (t & 31)) >> (t & 31) & 1u)) list[atomicAdd(&s_count, 1u)] = (unsigned short)t;
       }
     }
@@ -2302,17 +2308,17 @@ __global__ __launch_bounds__(idx_threads(CH)) void k_index_tables_nx(const uint8
   __syncthreads();
   for (int i = threadIdx.x; i < (int)s_count; i += NT) {
     const int t = list[i];
-    int pos = E + t, cnt = 0;
-    while (pos < CH) { pos = nx[pos]; ++cnt; }
+    int pos = E + (t << GS), cnt = 0;
+    while (pos < CH) { pos = nx[pos >> GS]; ++cnt; }
     W[t] = (unsigned)(pos - CH) << 16 | (unsigned)cnt;
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = threadIdx.x + k * NT;
-    if (e >= E) continue;
+    if (e >= EU) continue;
     if (la[k] >= CH) tab[e] = (unsigned)(la[k] - CH) << 16 | (unsigned)ca[k];
-    else tab[e] = W[la[k] - E] + (unsigned)ca[k];
+    else tab[e] = W[(la[k] - E) >> GS] + (unsigned)ca[k];
   }
 }
 
@@ -2332,10 +2338,11 @@ template <bool WORD> __device__ __forceinline__ uint2 idx_entry(const void *tab,
 }
 
 // out[g] = in[16 g + 15] o ... o in[16 g]; `span` = payload bytes one input function covers
+// (E: entry offsets per table = bytes >> gsh, see k_index_tables_nx; the exit offsets inside the entries stay bytes)
 template <bool WORD>
 __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *lens, long long stride, const void *tables,
                                                      uint2 *groups, int n_chunks, int n_groups, int E, long long span, const unsigned *skip,
-                                                     int dedupe) {
+                                                     int dedupe, int gsh) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(8))) unsigned lds_g[];
   const int g = blockIdx.x, pic = blockIdx.y;
@@ -2343,11 +2350,11 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
   if ((unsigned long long)g * IDX_GROUP * (unsigned long long)span >= plen) return;
   if (!dedupe) {
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
-      unsigned x = (unsigned)e, cnt = 0;
+      unsigned x = (unsigned)e << gsh, cnt = 0;
       for (int k = 0; k < IDX_GROUP; ++k) {
         const int c = g * IDX_GROUP + k;
         if (c >= n_chunks || (unsigned long long)c * (unsigned long long)span >= plen) break;
-        const uint2 t = idx_entry<WORD>(tables, ((size_t)pic * n_chunks + c) * E + x);
+        const uint2 t = idx_entry<WORD>(tables, ((size_t)pic * n_chunks + c) * E + (x >> gsh));
         x = t.x;
         cnt += t.y;
       }
@@ -2367,26 +2374,26 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
   const int c0 = g * IDX_GROUP;
   const size_t t0 = ((size_t)pic * n_chunks + c0) * E;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    const unsigned x = idx_entry<WORD>(tables, t0 + e).x;
+    const unsigned x = idx_entry<WORD>(tables, t0 + e).x >> gsh;
     if (atomicExch(&need[x], 1u) == 0u) list[atomicAdd(&s_count, 1u)] = (unsigned short)x;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < (int)s_count; i += blockDim.x) {
-    unsigned x = list[i], cnt = 0;
+    unsigned x = list[i], cnt = 0; // (entry units here; the tables' exits are bytes)
     const unsigned x0 = x;
     for (int k = 1; k < IDX_GROUP; ++k) {
       const int c = c0 + k;
       if (c >= n_chunks || (unsigned long long)c * (unsigned long long)span >= plen) break;
       const uint2 t = idx_entry<WORD>(tables, ((size_t)pic * n_chunks + c) * E + x);
-      x = t.x;
+      x = t.x >> gsh;
       cnt += t.y;
     }
-    res[x0] = make_uint2(x, cnt);
+    res[x0] = make_uint2(x << gsh, cnt);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     const uint2 t = idx_entry<WORD>(tables, t0 + e);
-    const uint2 r = res[t.x];
+    const uint2 r = res[t.x >> gsh];
     groups[((size_t)pic * n_groups + g) * E + e] = make_uint2(r.x, t.y + r.y);
   }
 }
@@ -2394,7 +2401,7 @@ __global__ __launch_bounds__(256) void k_index_group(const unsigned long long *l
 constexpr int IDX_MAX_GROUPS = 1024;
 __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *lens, long long stride, const unsigned *tables,
                                                     const uint2 *groups, const uint2 *supers, uint2 *entries, int n_chunks,
-                                                    int n_groups, int n_supers, int E, int IDX_CH, const unsigned *skip) {
+                                                    int n_groups, int n_supers, int E, int IDX_CH, const unsigned *skip, int gsh) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   __shared__ uint2 g_entry[IDX_MAX_GROUPS];              // the launcher keeps n_groups within it (larger chunks for larger slots)
   __shared__ uint2 s_entry[IDX_MAX_GROUPS / IDX_GROUP];
@@ -2407,7 +2414,7 @@ __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *
       for (int g = 0; g < n_groups; ++g) {
         g_entry[g] = make_uint2(entry, base);
         if ((unsigned long long)g * gspan >= plen) continue;
-        const uint2 t = groups[((size_t)pic * n_groups + g) * E + entry];
+        const uint2 t = groups[((size_t)pic * n_groups + g) * E + (entry >> gsh)];
         entry = t.x;
         base += t.y;
       }
@@ -2417,7 +2424,7 @@ __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *
     for (int sg = 0; sg < n_supers; ++sg) {
       s_entry[sg] = make_uint2(entry, base);
       if ((unsigned long long)sg * sspan >= plen) continue;
-      const uint2 t = supers[((size_t)pic * n_supers + sg) * E + entry];
+      const uint2 t = supers[((size_t)pic * n_supers + sg) * E + (entry >> gsh)];
       entry = t.x;
       base += t.y;
     }
@@ -2430,7 +2437,7 @@ __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *
       if (g >= n_groups) break;
       g_entry[g] = make_uint2(entry, base);
       if ((unsigned long long)g * gspan >= plen) continue;
-      const uint2 t = groups[((size_t)pic * n_groups + g) * E + entry];
+      const uint2 t = groups[((size_t)pic * n_groups + g) * E + (entry >> gsh)];
       entry = t.x;
       base += t.y;
     }
@@ -2443,7 +2450,7 @@ __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *
       if (c >= n_chunks) break;
       entries[(size_t)pic * n_chunks + c] = make_uint2(entry, base);
       if ((unsigned long long)c * IDX_CH >= plen) continue;
-      const unsigned t = tables[((size_t)pic * n_chunks + c) * E + entry];
+      const unsigned t = tables[((size_t)pic * n_chunks + c) * E + (entry >> gsh)];
       entry = t >> 16;
       base += t & 0xFFFFu;
     }
@@ -2480,6 +2487,16 @@ __global__ __launch_bounds__(64) void k_index_emit(const uint8_t *payload, long 
 }
 
 static int idx_entries(int prefix, int scalar) { return prefix + 4 + 3 * 255 * scalar; }
+// log2 of G: every slice starts at a multiple of G bytes (k_index_tables_nx)
+static int idx_gsh(int prefix, int scalar) {
+  int gsh = 0;
+  while (gsh < 2 && scalar % (2 << gsh) == 0 && (prefix + 4) % (2 << gsh) == 0) ++gsh;
+  return gsh;
+}
+#ifndef VC2_IDX_CHUNK_BY_UNITS
+#define VC2_IDX_CHUNK_BY_UNITS 0
+#endif
+static int idx_chunk_of(int prefix, int scalar) { const int E = idx_entries(prefix, scalar); return idx_chunk(VC2_IDX_CHUNK_BY_UNITS ? std::max(E >> idx_gsh(prefix, scalar), (E + 3) / 4) : E); }
 
 // Last resort for slices that can exceed 32767 bytes (slice size scalar > 42): one lane per picture follows the
 // length bytes through memory.  Correct for any stream, three dependent loads per slice.
@@ -2544,7 +2561,7 @@ bool vc2_slice_index_supported(int prefix, int scalar) { (void)prefix; (void)sca
 size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix, int scalar) {
   const size_t E = idx_entries(prefix, scalar);
   if (E > (size_t)IDX_MAX_E) return 256;
-  const size_t ch = (size_t)idx_chunk((int)E);
+  const size_t ch = (size_t)idx_chunk_of(prefix, scalar);
   const size_t n_chunks = (max_payload + ch - 1) / ch + 1;
   if (n_chunks > (size_t)1024 * 16) return 256; // serial walk (see vc2_launch_slice_index)
   const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
@@ -2561,7 +2578,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   // the chain kernel holds one entry per group of 16 chunks in LDS: slots beyond IDX_MAX_GROUPS groups (256 MiB at
   // 16 KiB chunks) take the serial walk like over-long slices do
   const bool too_many = E <= IDX_MAX_E &&
-      ((size_t)payload_stride + idx_chunk(E) - 1) / idx_chunk(E) + 1 > (size_t)IDX_MAX_GROUPS * IDX_GROUP;
+      ((size_t)payload_stride + idx_chunk_of(prefix, scalar) - 1) / idx_chunk_of(prefix, scalar) + 1 > (size_t)IDX_MAX_GROUPS * IDX_GROUP;
   if (E > IDX_MAX_E || too_many) {
     vc2_prof_begin(L, "slice_index_serial", s);
     VC2_LAUNCH(L, k_index_serial, dim3((n_pictures + 63) / 64), dim3(64), 0, s, payload, payload_stride, lens,
@@ -2569,27 +2586,32 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
     vc2_prof_end(L, s);
     return;
   }
-  const int ch = idx_chunk(E);
+  const int ch = idx_chunk_of(prefix, scalar);
+  // every slice starts at a multiple of G (k_index_tables_nx): the tables hold one entry per G bytes
+  const int gsh = idx_gsh(prefix, scalar);
+  const int EU = E >> gsh; // (E = prefix + 4 + 765 * scalar is a multiple of G)
   // chunk count is bounded by the payload slot size (lens live on the device)
   const int n_chunks = (int)(((size_t)payload_stride + ch - 1) / ch) + 1;
   unsigned *tables = (unsigned *)workspace;
-  uint2 *entries = (uint2 *)(((size_t)(tables + (size_t)n_pictures * n_chunks * E) + 15) & ~(size_t)15);
+  uint2 *entries = (uint2 *)(((size_t)(tables + (size_t)n_pictures * n_chunks * EU) + 15) & ~(size_t)15);
   const size_t stage_bytes = (size_t)((ch + E + 16 + 15) & ~15);
   vc2_prof_begin(L, "slice_index_tables", s);
   {
-    // merged walks (see the kernel): entry regions of up to 4096 bytes whose landing region lies inside the chunk
+    // merged walks (see the kernel): entry regions of up to 4096 offsets whose landing region lies inside the chunk
     static const bool no_merge = vc2_tune_int("VC2HIP_IDX_NO_MERGE", 0) != 0;
-    const int merge = !no_merge && E <= 4096 && 2 * E <= ch;
-    const size_t lds = stage_bytes + (size_t)ch * 2 + (merge ? (size_t)E * 6 + ((size_t)(E + 31) / 32) * 4 + 16 : 0);
-#define VC2_IDX_TABLES(CH)                                                                                                    \
+    const int merge = !no_merge && EU <= 4096 && 2 * E <= ch;
+    const size_t lds = stage_bytes + (size_t)(ch >> gsh) * 2 + (merge ? (size_t)EU * 6 + ((size_t)(EU + 31) / 32) * 4 + 16 : 0);
+#define VC2_IDX_TABLES(CH, GS)                                                                                                    \
   do {                                                                                                                        \
-    vc2_allow_lds((const void *)k_index_tables_nx<CH>, lds);                                                                  \
-    VC2_LAUNCH(L, (k_index_tables_nx<CH>), dim3(n_chunks, n_pictures), dim3(idx_threads(CH)), lds, s, payload, payload_stride, \
+    vc2_allow_lds((const void *)k_index_tables_nx<CH, GS>, lds);                                                                  \
+    VC2_LAUNCH(L, (k_index_tables_nx<CH, GS>), dim3(n_chunks, n_pictures), dim3(idx_threads(CH, GS)), lds, s, payload, payload_stride, \
                lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);                                                  \
   } while (0)
-    if (ch == 8192) VC2_IDX_TABLES(8192);
-    else if (ch == 16384) VC2_IDX_TABLES(16384);
-    else VC2_IDX_TABLES(32768);
+#define VC2_IDX_TABLES_G(CH) do { if (gsh == 0) VC2_IDX_TABLES(CH, 0); else if (gsh == 1) VC2_IDX_TABLES(CH, 1); else VC2_IDX_TABLES(CH, 2); } while (0)
+    if (ch == 8192) VC2_IDX_TABLES_G(8192);
+    else if (ch == 16384) VC2_IDX_TABLES_G(16384);
+    else VC2_IDX_TABLES_G(32768);
+#undef VC2_IDX_TABLES_G
 #undef VC2_IDX_TABLES
   }
   vc2_prof_end(L, s);
@@ -2597,19 +2619,19 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   // (the third level costs a launch: 5 us; it pays from a few hundred groups on -- UHD-2 pictures: 0.163 -> 0.132 ms)
   const int n_supers = n_groups > 128 ? (n_groups + IDX_GROUP - 1) / IDX_GROUP : 0;
   uint2 *groups = entries + (size_t)n_pictures * n_chunks;
-  uint2 *supers = groups + (size_t)n_pictures * n_groups * E;
+  uint2 *supers = groups + (size_t)n_pictures * n_groups * EU;
   vc2_prof_begin(L, "slice_index_chain", s);
   {
     // (exit offsets are below E and fit 16 bits up to IDX_MAX_E; the dedupe tables need 14 bytes of LDS per entry)
     static const bool no_dedupe = vc2_tune_int("VC2HIP_IDX_NO_DEDUPE", 0) != 0;
-    const int dedupe = !no_dedupe && E <= 8192;
-    const size_t glds = dedupe ? ((size_t)((E + 1) & ~1) * 4 + (size_t)E * 8 + (size_t)E * 2 + 16) : 0;
+    const int dedupe = !no_dedupe && EU <= 8192;
+    const size_t glds = dedupe ? ((size_t)((EU + 1) & ~1) * 4 + (size_t)EU * 8 + (size_t)EU * 2 + 16) : 0;
     if (glds) { vc2_allow_lds((const void *)k_index_group<true>, glds); vc2_allow_lds((const void *)k_index_group<false>, glds); }
-    VC2_LAUNCH(L, k_index_group<true>, dim3(n_groups, n_pictures), dim3(256), glds, s, lens, payload_stride, (const void *)tables, groups, n_chunks, n_groups, E, (long long)ch, skip, dedupe);
-    if (n_supers) VC2_LAUNCH(L, k_index_group<false>, dim3(n_supers, n_pictures), dim3(256), glds, s, lens, payload_stride, (const void *)groups, supers, n_groups, n_supers, E, (long long)ch * IDX_GROUP, skip, dedupe);
+    VC2_LAUNCH(L, k_index_group<true>, dim3(n_groups, n_pictures), dim3(256), glds, s, lens, payload_stride, (const void *)tables, groups, n_chunks, n_groups, EU, (long long)ch, skip, dedupe, gsh);
+    if (n_supers) VC2_LAUNCH(L, k_index_group<false>, dim3(n_supers, n_pictures), dim3(256), glds, s, lens, payload_stride, (const void *)groups, supers, n_groups, n_supers, EU, (long long)ch * IDX_GROUP, skip, dedupe, gsh);
   }
   // (one lane follows the super-groups of a picture; then a thread per super-group / group expands it: sixteen dependent reads each, all at once)
-  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(std::min(1024, (n_groups + 63) / 64 * 64)), 0, s, lens, payload_stride, tables, groups, supers, entries, n_chunks, n_groups, n_supers, E, ch, skip);
+  VC2_LAUNCH(L, k_index_chain, dim3(n_pictures), dim3(std::min(1024, (n_groups + 63) / 64 * 64)), 0, s, lens, payload_stride, tables, groups, supers, entries, n_chunks, n_groups, n_supers, EU, ch, skip, gsh);
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
   VC2_LAUNCH(L, k_index_emit, dim3((n_chunks + 63) / 64, n_pictures), dim3(64), 0, s, payload,
