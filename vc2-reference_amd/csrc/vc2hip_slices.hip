@@ -1960,15 +1960,26 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
   __shared__ unsigned lut[UNP_LUT_N];
   for (int i = threadIdx.x * 4; i < UNP_LUT_N; i += blockDim.x * 4) *(uint4 *)(lut + i) = *(const uint4 *)(g_unp_lut + i);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // One-dimensional work list: workgroup b runs on XCD b mod 8 (each with its own L2), and the Y, U and V passes over the
-  // same 256 slices read the same payload lines -- with (blocks, pictures, 3) as the grid they were 2048 workgroups apart
-  // and every line was fetched again for each (rocprofv3 FETCH_SIZE 3.9 x the payload, round 3).  Here the three
-  // components of a block of slices are consecutive in dispatch order ON THE SAME XCD: b = ((g * 3 + comp) * 8 + x),
-  // block = g * 8 + x.
+  // Dispatch order (VC2_UNP_ORDER).  2 (the default, round 3's grid): (blocks, pictures, 3) -- the luma blocks of all
+  // pictures first, whose wavefronts live twice as long as the chroma ones, then U, then V: the short wavefronts fill the
+  // end of the launch.  0: a one-dimensional list that puts the Y, U and V passes over the same 256 slices next to each
+  // other on one XCD, so that the payload lines they share are fetched once: rocprofv3
+  // FETCH_SIZE 1158 -> 955 MB per launch and 0.587 -> 0.610 ms on the same box -- the traffic is not what bounds this
+  // kernel, the order of long and short wavefronts is worth 4 %.  1: component-major inside each picture: 0.593.
   const int pic = blockIdx.y;
   const int nblk = (p.n_slices + 64 * VC2_UNP16_WAVES - 1) / (64 * VC2_UNP16_WAVES);
+#ifndef VC2_UNP_ORDER
+#define VC2_UNP_ORDER 2
+#endif
+#if VC2_UNP_ORDER == 0
   const int bx = blockIdx.x & 7, bg = blockIdx.x >> 3;
   const int comp = bg % 3, blk = (bg / 3) * 8 + bx;
+#elif VC2_UNP_ORDER == 1 // component-major inside a picture: all its luma blocks, then U, then V
+  const int nblk8 = ((nblk + 7) / 8) * 8;
+  const int comp = blockIdx.x / nblk8, blk = blockIdx.x % nblk8;
+#else // component-major over the launch (grid.z): the luma blocks of all pictures first
+  const int comp = blockIdx.z, blk = blockIdx.x;
+#endif
   if (blk >= nblk) return; // (the list is padded to whole groups of eight blocks)
   const int slice0 = blk * (64 * VC2_UNP16_WAVES) + wave * 64, slice = slice0 + lane;
   const bool active = slice < p.n_slices;
@@ -2154,7 +2165,11 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipS
   if (p.store16) {
     constexpr int T = 64 * VC2_UNP16_WAVES;
     const int nblk = (p.n_slices + T - 1) / T;
+#if VC2_UNP_ORDER == 2
+    VC2_LAUNCH(L, k_hq_unpack16, dim3(nblk, n_pictures, 3), dim3(T), 0, s, p);
+#else
     VC2_LAUNCH(L, k_hq_unpack16, dim3(((nblk + 7) / 8) * 8 * 3, n_pictures), dim3(T), 0, s, p);
+#endif
     vc2_prof_end(L, s);
     return;
   }
