@@ -28,7 +28,7 @@
 
 #ifdef VC2HIP_ABLATE // why wavefronts leave the table path (tools/probe: VC2HIP_P16_STATS=1 prints the counters after every launch)
 __device__ unsigned g_p16_stats[8];
-#define P16_STAT(k, cond) do { if (__any(cond) && lane == 0) atomicAdd(&g_p16_stats[k], 1u); } while (0)
+#define P16_STAT(k, cond) do { if (VC2_SKIP(p, 8) && __any(cond) && lane == 0) atomicAdd(&g_p16_stats[k], 1u); } while (0)
 #else
 #define P16_STAT(k, cond)
 #endif
@@ -54,6 +54,18 @@ static void fill_vlc_lut_s(unsigned *host) {
   }
 }
 
+// by quantiser index: (magic, shift, factor) of the exact integer division and the rounded-up 4 / factor as a float -- the
+// rows of c_qs the coder needs, side by side: one 16-byte load per thread instead of four; [120..127]: a factor of 2^30 and
+// a reciprocal of zero (indices beyond the table quantise to zero)
+__device__ uint4 g_p16_qt[128];
+void vc2_upload_p16_tables(const QuantTables &t, hipStream_t s) {
+  static uint4 host[128]; // (written by whichever context comes first: the values are the same for all)
+  for (int q = 0; q < 128; ++q) {
+    if (q < 120) { union { float f; unsigned u; } w; w.f = t.inv4[q]; host[q] = make_uint4(t.magic[q], (unsigned)t.shift[q], (unsigned)t.qf[q], w.u); }
+    else host[q] = make_uint4(0u, 0u, 0x40000000u, 0u);
+  }
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_p16_qt), host, sizeof host, 0, hipMemcpyHostToDevice, s);
+}
 static void vc2_upload_vlc_lut_s(hipStream_t s) {
   static unsigned host[P16_LUT_N];
   static std::once_flag once;
@@ -180,14 +192,15 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   const bool active = slice < p.n_slices; // wave-uniform
   const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
   unsigned *lut = lds_u;                   // at LDS address 0: a look-up's address is the quotient's low byte times four
-  float *inv = (float *)(lut + P16_LUT_N); // 128 entries, [120..127] = 0: indices beyond the table quantise to zero
-  uint4 *qt = (uint4 *)(lds_u + P16_LUT_N + 128); // by quantiser index: (magic, shift, factor, -) of the exact integer division (the head)
-  unsigned *img = lds_u + P16_LUT_N + 128 + 4 * 128 + wave * img_q * 4;
+  uint4 *qt = (uint4 *)(lds_u + P16_LUT_N); // by quantiser index: g_p16_qt
+  unsigned *img = lds_u + P16_LUT_N + 4 * 128 + wave * img_q * 4;
   // the tables' loads first (L2), the record's behind them: the table writes and the barrier then wait for the former only
-  const unsigned lut_e = threadIdx.x < P16_LUT_N ? g_vlc_lut_s[threadIdx.x] : 0u;
-  const float inv_e = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
-  const uint4 qt_e = threadIdx.x < 120 ? make_uint4(c_qs.magic[threadIdx.x], (unsigned)c_qs.shift[threadIdx.x], (unsigned)c_qs.qf[threadIdx.x], 0u)
-                                       : make_uint4(0u, 0u, 0x40000000u, 0u);
+  unsigned lut_e = 0x04000002u;
+  uint4 qt_e = make_uint4(0u, 0u, 0x40000000u, 0u);
+  if (!VC2_SKIP(p, 4)) { // (ablation 4: the tables without their loads -- what amortising the set-up over several slices could gain: 6 %)
+    lut_e = g_vlc_lut_s[threadIdx.x & (P16_LUT_N - 1)];
+    qt_e = g_p16_qt[threadIdx.x & 127];
+  }
   const unsigned lt = p.lane16[lane];
   const int comp = lane < 32 ? 0 : (lane < 48 ? 1 : 2), cl = lane - (lane < 32 ? 0 : (lane < 48 ? 32 : 48));
   const int head_n = (int)(comp == 0 ? p.lane16[64] : (comp == 1 ? p.lane16[65] : p.lane16[66]));
@@ -203,14 +216,14 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   const int32_t *hwide = p.store_wide + rec_at + coff + cl; // the head coefficient's place in the wide array (an escape of the 16-bit store)
   const int q = p.qidx[(size_t)pic * p.n_slices + (active ? slice : 0)]; // (a scalar load: requested before the barrier, used behind it)
   if (threadIdx.x < P16_LUT_N) lut[threadIdx.x] = lut_e;
-  if (threadIdx.x < 128) { inv[threadIdx.x] = inv_e; qt[threadIdx.x] = qt_e; }
+  if (threadIdx.x < 128) qt[threadIdx.x] = qt_e;
   for (int i = lane; i < img_q; i += 64) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   if (!active) return;
 
   const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
-  const float fb = inv[min(aqb, 120)];
+  const float fb = __uint_as_float(qt[min(aqb, 120)].w);
   const uint4 qh = qt[min(aqh, 120)]; // (index 120: a factor of 2^30 -- every 32-bit value quantises to zero)
 
   // ---- body: two strings of eight coefficients
@@ -400,15 +413,12 @@ __global__ __launch_bounds__(192) void k_hq_pack16w(const PackParams p) {
   const int pic = blockIdx.y, slice = blockIdx.x;
   const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
   unsigned *lut = lds_u;
-  float *inv = (float *)(lut + P16_LUT_N);
-  uint4 *qt = (uint4 *)(lds_u + P16_LUT_N + 128);
-  unsigned *img = lds_u + P16_LUT_N + 128 + 4 * 128;
+  uint4 *qt = (uint4 *)(lds_u + P16_LUT_N);
+  unsigned *img = lds_u + P16_LUT_N + 4 * 128;
   unsigned lut_e[2];
   lut_e[0] = g_vlc_lut_s[threadIdx.x];
   lut_e[1] = threadIdx.x < P16_LUT_N - 192 ? g_vlc_lut_s[192 + threadIdx.x] : 0u;
-  const float inv_e = threadIdx.x < 120 ? c_qs.inv4[threadIdx.x] : 0.f;
-  const uint4 qt_e = threadIdx.x < 120 ? make_uint4(c_qs.magic[threadIdx.x], (unsigned)c_qs.shift[threadIdx.x], (unsigned)c_qs.qf[threadIdx.x], 0u)
-                                       : make_uint4(0u, 0u, 0x40000000u, 0u);
+  const uint4 qt_e = g_p16_qt[threadIdx.x & 127];
   const unsigned lt = p.lane16[64 * comp + lane];
   const int head_n = (int)p.lane16[192 + comp], body_n = (int)p.lane16[195 + comp], coff = p.comp_off[comp];
   const bool has_body = lane < body_n, has_head = lane < head_n;
@@ -421,14 +431,14 @@ __global__ __launch_bounds__(192) void k_hq_pack16w(const PackParams p) {
   const int32_t *hwide = p.store_wide + rec_at + coff + lane;
   lut[threadIdx.x] = lut_e[0];
   if (threadIdx.x < P16_LUT_N - 192) lut[192 + threadIdx.x] = lut_e[1];
-  if (threadIdx.x < 128) { inv[threadIdx.x] = inv_e; qt[threadIdx.x] = qt_e; }
+  if (threadIdx.x < 128) qt[threadIdx.x] = qt_e;
   const int q = p.qidx[(size_t)pic * p.n_slices + slice];
   for (int i = threadIdx.x; i < img_q; i += 192) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
   const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
-  const float fb = inv[min(aqb, 120)];
+  const float fb = __uint_as_float(qt[min(aqb, 120)].w);
   const uint4 qh = qt[min(aqh, 120)]; // (index 120: a factor of 2^30 -- every 32-bit value quantises to zero)
   unsigned long long G0, G1;
   int L0, L1, last0, last1;
@@ -540,9 +550,9 @@ __global__ __launch_bounds__(192) void k_hq_pack16w(const PackParams p) {
 
 static size_t pack16w_lds(int prefix, int scalar) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
-  return img_q * 16 + P16_LUT_N * 4 + 128 * 4 + 128 * 16;
+  return img_q * 16 + P16_LUT_N * 4 + 128 * 16;
 }
 static size_t pack16_lds(int prefix, int scalar) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
-  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 4 + 128 * 16;
+  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 16;
 }

@@ -25,8 +25,10 @@ void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s);
 void vc2_prof_end(Launcher &L, hipStream_t s);
 
 __constant__ QuantTables c_qs;
+void vc2_upload_p16_tables(const QuantTables &t, hipStream_t s);
 void vc2_upload_tables_slices(const QuantTables &t, hipStream_t s) {
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_qs), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
+  vc2_upload_p16_tables(t, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -839,6 +841,9 @@ static void p16_print_stats(hipStream_t) {}
 #endif
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
+#ifdef VC2HIP_ABLATE
+  { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = (e ? atoi(e) : 0) | (getenv("VC2HIP_P16_STATS") ? 8 : 0); }
+#endif
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
   if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
   static const int use16 = vc2_tune_int("VC2HIP_PACK16", 1);
@@ -875,9 +880,6 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
     return;
   }
   fill_band_lut(p.band_lut, p.comp_n, p.comp_n0);
-#ifdef VC2HIP_ABLATE
-  { const char *e = getenv("VC2HIP_DEBUG_PACK"); p.debug_skip = e ? atoi(e) : 0; }
-#endif
   const int W = pack_lanes(p);
   const bool same_c = p.comp_n[1] == p.comp_n[2];
   const int S = 64 / W;
