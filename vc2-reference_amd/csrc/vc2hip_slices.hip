@@ -1023,13 +1023,16 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_
   // slice's own memory up to slot_bytes whatever its size): the kernel is a chain of memory latencies -- size / offset,
   // then the source, then the stores (rocprofv3: 93 % of a wavefront's life waiting) -- and this puts the first two side
   // by side.  A typical UHD slice (~580 bytes) is those two trips of 32 lanes.
-  const bool pre = 2 * W * 16 + 16 <= slot_bytes;
-  uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
-  unsigned nx0 = 0, nx1 = 0;
+  constexpr int PRE = 2; // trips requested up front (16 lanes: 512 bytes, 32: 1024; three trips of 16 lanes: 0.132 against 0.117 ms)
+  const bool pre = PRE * W * 16 + 16 <= slot_bytes;
+  uint4 vp[PRE];
+  unsigned nxp[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) { vp[k] = make_uint4(0u, 0u, 0u, 0u); nxp[k] = 0; }
   if (pre) {
     const unsigned *s4p = (const unsigned *)src;
-    v0 = *(const uint4 *)(s4p + 4 * sl); nx0 = s4p[4 * sl + 4];
-    v1 = *(const uint4 *)(s4p + 4 * (sl + W)); nx1 = s4p[4 * (sl + W) + 4];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) { vp[k] = *(const uint4 *)(s4p + 4 * (sl + k * W)); nxp[k] = s4p[4 * (sl + k * W) + 4]; }
   }
   uint8_t *dst = payload + (size_t)pic * payload_stride + offsets[si];
   const int size = (int)sizes[si];
@@ -1049,9 +1052,12 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_
   for (int q = sl; 4 * q < nw; q += W) {
     uint4 v;
     unsigned nx;
-    if (q == sl && pre) { v = v0; nx = nx0; }
-    else if (q == sl + W && pre) { v = v1; nx = nx1; }
-    else { v = *(const uint4 *)(s4 + 4 * q); nx = s4[4 * q + 4]; }
+    const int trip = (q - sl) / W;
+    if (pre && trip < PRE) {
+      v = vp[0]; nx = nxp[0];
+#pragma unroll
+      for (int k = 1; k < PRE; ++k) if (trip == k) { v = vp[k]; nx = nxp[k]; }
+    } else { v = *(const uint4 *)(s4 + 4 * q); nx = s4[4 * q + 4]; }
     const unsigned h = (unsigned)head;
     Dword4 o;
     o.x = __builtin_amdgcn_alignbyte(v.y, v.x, h);
@@ -1073,10 +1079,13 @@ void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const
   vc2_prof_begin(L, "slice_compact", s);
   // lanes per slice from the slot size (an upper bound of the slice size; typical slices are far shorter)
   static const int force = vc2_tune_int("VC2HIP_COMPACT_LANES", 0);
-  const int W = force ? force : (slot_bytes <= 800 ? 16 : (slot_bytes <= 8192 ? 32 : 64)); // (slots of four UHD slices, 6 KiB: 32 lanes 0.062 ms, 64 0.067; of sixteen HD slices, 12 KiB: 0.047 / 0.044)
+  // (round 4, with the first two trips' pieces requested up front: slots of one UHD slice, 1.5 KiB: 16 lanes 0.117 ms, 32 0.150,
+  // 8 0.17, 64 0.19; of one UHD-2 slice, 6 KiB: 0.063 / 0.055 / - / 0.068; of sixteen HD slices, 12 KiB: 0.054 / 0.043 / 0.051)
+  const int W = force ? force : (slot_bytes <= 2048 ? 16 : (slot_bytes <= 16384 ? 32 : 64));
   const int per_wg = 256 / W;
   const dim3 grid((n_slices + per_wg - 1) / per_wg, n_pictures);
-  if (W == 16) VC2_LAUNCH(L, k_compact<16>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  if (W == 8) VC2_LAUNCH(L, k_compact<8>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
+  else if (W == 16) VC2_LAUNCH(L, k_compact<16>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
   else if (W == 32) VC2_LAUNCH(L, k_compact<32>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
   else VC2_LAUNCH(L, k_compact<64>, grid, dim3(256), 0, s, slots, slot_bytes, sizes, offsets, payload, payload_stride, n_slices);
   vc2_prof_end(L, s);
