@@ -1050,6 +1050,12 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     if (best < 0 || cost <= best) { best = cost; nseg = g; } // (ties: more wavefronts)
   }
   if (force_nseg > 0) nseg = std::min(force_nseg, p.ys);
+  { // (ablation build: one of the four kernels only -- forward first / forward level / inverse final / inverse level)
+    static const int f4[4] = {vc2_tune_int("VC2HIP_STREAM_NSEG_FF", 0), vc2_tune_int("VC2HIP_STREAM_NSEG_FL", 0),
+                              vc2_tune_int("VC2HIP_STREAM_NSEG_IF", 0), vc2_tune_int("VC2HIP_STREAM_NSEG_IL", 0)};
+    const int f = f4[(inverse ? 2 : 0) + (edge ? 0 : 1)];
+    if (f > 0) nseg = std::min(f, p.ys);
+  }
 #ifdef VC2HIP_STAMPS
   fprintf(stderr, "stream level: kernel %d edge %d inv %d lds %zu cols %d slots %d runin %d -> nseg %d\n", kernel, (int)edge, (int)inverse, lds, cols, slots, runin, nseg);
 #endif
