@@ -486,13 +486,12 @@ static int need(vc2hip_ctx *c, int which, size_t bytes, void **out) {
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
-    // Large workspaces are sized in whole 2 MiB units.  Measured (tools/probe/bimodal.py, round 4): with sizes rounded to
-    // 4 KiB every second process -- every second context -- ran the level-0 transforms 10 % slower for its whole life
-    // (dwt_level_first 0.45 or 0.50 ms per 32 UHD pictures, the levels below alike; what round 3 took for "fast and slow
-    // boxes"), independent of the buffers' virtual addresses, of the stream and of the workgroup-to-XCD rotation
-    // (tools/probe/xcd_map.hip, stream_bw.hip); with 2 MiB multiples 8 of 8 processes are in the fast mode and the
-    // inverse level-0 kernel gains 4 % as well -- the driver then backs the whole buffer with large page-table fragments.
-    const size_t cap = bytes >= (1u << 21) ? (bytes + (1u << 21) - 1) & ~(size_t)((1u << 21) - 1) : (bytes + 4095) & ~(size_t)4095;
+    // Large workspaces are sized in whole 2 MiB units (the driver's large page-table fragments; no measurable effect on
+    // the kernels: the 10 % spread of the level-0 transforms between processes that prompted it follows the box and the
+    // moment, not the allocation -- see VC2_STREAM_WG_WAVES in vc2hip_dwt_stream.hip).
+    size_t cap = bytes >= (1u << 21) ? (bytes + (1u << 21) - 1) & ~(size_t)((1u << 21) - 1) : (bytes + 4095) & ~(size_t)4095;
+    { static const size_t unit = (size_t)vc2_tune_int("VC2HIP_ALLOC_ROUND_MB", 0) << 20; // (ablation build: another unit)
+      if (unit && bytes >= (1u << 21)) cap = (bytes + unit - 1) / unit * unit; }
     HIPCHK(c, hipMalloc(&b.p, cap));
     b.cap = cap;
 #ifdef VC2HIP_ABLATE

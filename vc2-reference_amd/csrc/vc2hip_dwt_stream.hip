@@ -277,9 +277,27 @@ struct Strip {
 // columns being all (picture, strip) of the luma planes, then of the U planes, then of the V planes.
 // (Round 2 launched a strips x segments x (3 * pictures) grid: with 8 luma and 4 chroma strips the XCD was the strip
 // number, XCDs 0-3 got three times the work of XCDs 4-7 and half the chip idled for half of the kernel.)
+// A workgroup is VC2_STREAM_WG_WAVES wavefronts, each with a work item of its own and no barrier between them: 1 (one
+// wavefront per workgroup, rounds 2 - 4), or 4 -- the four wavefronts of a workgroup go one to each SIMD of a CU whatever
+// the dispatcher's state.  Round 4 built the second to see whether wavefront placement explains why the level-0
+// transforms run at 0.45 ms per 32 UHD pictures in some processes and at 0.50 in others (tools/probe/bimodal*.py): it
+// does not -- on a box that shows both modes both workgroup shapes show them, a second box is always fast, a third always
+// slow (A/B of the two builds, five processes each per box).  Neither do the buffers' addresses, their size rounding, the
+// stream or the workgroup-to-XCD rotation (tools/probe/xcd_map.hip, stream_bw.hip): the mode follows the box and the
+// moment, i.e. the GPU's clock / power state.  Item of wavefront w of workgroup g: 8 * (4 * (g / 8) + w) + g % 8 -- item
+// mod 8 is still the workgroup's XCD.
+#ifndef VC2_STREAM_WG_WAVES
+#define VC2_STREAM_WG_WAVES 1
+#endif
+__device__ __forceinline__ int stream_wave() { return VC2_STREAM_WG_WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0; }
+__device__ __forceinline__ int stream_item() {
+  if (VC2_STREAM_WG_WAVES == 1) return (int)blockIdx.x;
+  const int g = (int)blockIdx.x;
+  return 8 * (VC2_STREAM_WG_WAVES * (g >> 3) + stream_wave()) + (g & 7);
+}
 template <int K> __device__ __forceinline__ bool strip_of_block(const LevelParams &p, int &comp, int &pic, Strip &s) {
   constexpr int HLN = halo_lanes<K>();
-  const int b = blockIdx.x, x = b & 7, t = b >> 3;
+  const int b = stream_item(), x = b & 7, t = b >> 3;
   const int seg = t % p.st_segmax, col = (t / p.st_segmax) * 8 + x;
   const int n0 = p.st_npic * p.st_strips[0], n1 = p.st_npic * p.st_strips[1], n2 = p.st_npic * p.st_strips[2];
   int within;
@@ -332,14 +350,14 @@ __device__ __forceinline__ size_t mul24z(int a, int b) { return (size_t)__umul24
 #endif
 template <int K, bool TAIL> constexpr int stream_wpe() { return TAIL ? 1 : K == VC2HIP_FIDELITY ? 2 : VC2_STREAM_WPE; }
 template <int K, bool FIRST, class ST, bool TAIL = false>
-__global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_fwd_stream(const LevelParams p) {
+__global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) void k_fwd_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, false>;
   using T = typename VE::T;
   constexpr int RL = RLK<K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  ST *stg = (ST *)smem;
-  const int lane = threadIdx.x;
+  ST *stg = (ST *)(smem + (size_t)stream_wave() * p.st_lds);
+  const int lane = threadIdx.x & 63;
   int comp, pic;
   VC2_STAMP_BEGIN
   Strip sp;
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_fwd_stream(cons
     mb += RL;
   }
   const int mstop = last ? (np & ~(RL - 1)) : mend; // whole steady blocks (a walk that does not end at the bottom may run over)
-  const int prio0 = (int)(blockIdx.x >> 10);
+  const int prio0 = VC2_STREAM_WG_WAVES > 1 ? (int)(blockIdx.x >> 8) : (int)(blockIdx.x >> 10); // (the wavefronts that share a SIMD: a chip full of workgroups apart)
   for (; mb < mstop; mb += RL) { if (p.st_prio) prio_turn(prio0 + (mb >> p.st_prio)); VC2_FWD_BLOCK(0) }
   if (last) { // the np mod RL pairs left, then the OFFL iterations below the plane at the phases that follow
 #define VC2_FWD_DRAIN(R) { VC2_FWD_ITERD((R + 0) % RL, 2, 0) VC2_FWD_ITERD((R + 1) % RL, 2, 1) VC2_FWD_ITERD((R + 2) % RL, 2, 2) \
@@ -545,13 +563,13 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
 }
 
 template <int K, bool FINAL, class ST, bool TAIL = false>
-__global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_inv_stream(const LevelParams p) {
+__global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) void k_inv_stream(const LevelParams p) {
   using S_ = St<ST>;
   using VE = VEng<K, true>;
   using T = typename VE::T;
   constexpr int RL = RLK<K>;
-  __shared__ int qtab[360]; // quant_factor / quant_offset / domain limit by adjusted index
-  const int lane = threadIdx.x;
+  __shared__ int qtab[360]; // quant_factor / quant_offset / domain limit by adjusted index (every wavefront of the workgroup writes all of it: the same values)
+  const int lane = threadIdx.x & 63;
   int comp, pic;
   VC2_STAMP_BEGIN
   Strip sp;
@@ -823,7 +841,7 @@ __global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_inv_stream(cons
     mb += RL;
   }
   const int mstop = last ? (np & ~(RL - 1)) : mend;
-  const int prio0 = (int)(blockIdx.x >> 10);
+  const int prio0 = VC2_STREAM_WG_WAVES > 1 ? (int)(blockIdx.x >> 8) : (int)(blockIdx.x >> 10); // (the wavefronts that share a SIMD: a chip full of workgroups apart)
   for (; mb < mstop; mb += RL) { if (p.st_prio) prio_turn(prio0 + (mb >> p.st_prio)); VC2_INV_BLOCK(0) }
   if (last) { // as in the forward kernel
 #define VC2_INV_DRAIN(R) { VC2_INV_ITERD((R + 0) % RL, 2, 0) VC2_INV_ITERD((R + 1) % RL, 2, 1) VC2_INV_ITERD((R + 2) % RL, 2, 2) \
@@ -851,8 +869,12 @@ __global__ __launch_bounds__(64, (stream_wpe<K, TAIL>())) void k_inv_stream(cons
 template <int K, bool EDGE, bool INV, class ST, bool TAIL>
 void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds, hipStream_t s) {
   const int cols = (p.st_strips[0] + p.st_strips[1] + p.st_strips[2]) * n_pictures;
-  const int gx = ((cols + 7) / 8) * p.st_segmax * 8;
-  dim3 grid(gx), block(64);
+  const int gx = ((cols + 7) / 8) * p.st_segmax * 8; // work items (a multiple of 8)
+  constexpr int WW = VC2_STREAM_WG_WAVES;
+  dim3 grid(WW > 1 ? ((gx + 8 * WW - 1) / (8 * WW)) * 8 : gx), block(64 * WW);
+  LevelParams pw = p;
+  pw.st_lds = (int)lds;
+  const size_t lds_wg = lds * WW;
 #ifdef VC2HIP_STAMPS
   const char *stamp_file = getenv("VC2HIP_STAMPS_FILE");
   const size_t stamp_n = (size_t)gx * 4;
@@ -865,12 +887,12 @@ void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds
 #endif
   if constexpr (INV) {
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
-    vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST, TAIL>, 64 * 1024);
-    VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST, TAIL>), grid, block, lds, s, p);
+    vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST, TAIL>, std::max<size_t>(64 * 1024, lds_wg));
+    VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST, TAIL>), grid, block, lds_wg, s, pw);
   } else {
     vc2_prof_begin(L, EDGE ? "dwt_level_first" : "dwt_level", s);
-    vc2_allow_lds((const void *)k_fwd_stream<K, EDGE, ST, TAIL>, 64 * 1024);
-    VC2_LAUNCH(L, (k_fwd_stream<K, EDGE, ST, TAIL>), grid, block, lds, s, p);
+    vc2_allow_lds((const void *)k_fwd_stream<K, EDGE, ST, TAIL>, std::max<size_t>(64 * 1024, lds_wg));
+    VC2_LAUNCH(L, (k_fwd_stream<K, EDGE, ST, TAIL>), grid, block, lds_wg, s, pw);
   }
 #ifdef VC2HIP_STAMPS
   if (stamp_file) {
@@ -946,12 +968,13 @@ template <int K, bool EDGE, bool INV, class ST, bool TAIL> int slots_of(size_t l
   int nb = 0, dev = 0;
   hipDeviceProp_t prop;
   const void *fn = INV ? (const void *)k_inv_stream<K, EDGE, ST, TAIL> : (const void *)k_fwd_stream<K, EDGE, ST, TAIL>;
-  vc2_allow_lds(fn, 64 * 1024);
+  constexpr int WW = VC2_STREAM_WG_WAVES;
+  vc2_allow_lds(fn, std::max<size_t>(64 * 1024, lds * WW));
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, lds) != hipSuccess || nb < 1)
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * WW, lds * WW) != hipSuccess || nb < 1)
     return 256 * 8;
-  if (nb >= 4) nb &= ~3;
-  return nb * prop.multiProcessorCount;
+  if (WW == 1 && nb >= 4) nb &= ~3;
+  return nb * WW * prop.multiProcessorCount; // (workgroups of four wavefronts: one per SIMD)
 }
 template <bool INV, class ST> int slots_dispatch(int kernel, bool edge, bool tail, size_t lds) {
 #define VC2_CASE(KK)                                                                       \
@@ -1030,7 +1053,7 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     else img = 16; // the inverse kernel reads the records directly
     lds = std::max(lds, img);
   }
-  if (lds > 40 * 1024) return 0;
+  if (lds > 40 * 1024 || lds * VC2_STREAM_WG_WAVES > 144 * 1024) return 0;
   // Segments: whole rows of slices, `nseg` per strip, the same for every component; segment g of a strip covers the
   // slice rows [g * ys / nseg, (g + 1) * ys / nseg) -- heights differ by at most one slice row.  A segment runs in over
   // the filter's reach before its first output row (about 8 row pairs for DD97, 22 for Fidelity): short segments waste

@@ -119,6 +119,7 @@ struct LevelParams {
   int st_tail;                  // some plane's pair count is not a multiple of four: the TAIL instantiation
   int st_prio;                  // > 0: wavefronts take turns at the highest issue priority, a new turn every 2^st_prio row pairs
   int st_segmax, st_npic;       // most segments of any component; pictures of the launch (the kernels' work-item numbering)
+  int st_lds;                   // dynamic LDS bytes of ONE wavefront (a workgroup holds VC2_STREAM_WG_WAVES of them)
   // inverse, streaming kernels: element offset (from the picture's store) of this level's HL band plane, LH and HH behind
   // it, when the decoder keeps the level's bands as planes (BandPlanes below); -1: in the slice records
   long long bp_base[3];
