@@ -239,7 +239,10 @@ struct CbrParams {
   int only_marked;            // set by the launcher: search only the slices whose index is VC2_CBR_MARK
   float inv_scalar;           // set by the launcher
   int qm_min;                 // set by the launcher: the smallest matrix entry
-  unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
+  union {
+    unsigned char band_lut[768]; // set by the launcher: subband of a coefficient index, 512 luma + 256 chroma entries
+    unsigned lane8[72];          // k_cbr_search16 (vc2hip_cbr16.h): per lane the matrix entries of its runs and head; [64..67] head / run counts
+  };
 };
 #define VC2_CBR_MARK 0x7FFFFFFF
 

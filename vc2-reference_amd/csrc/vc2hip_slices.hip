@@ -1477,6 +1477,8 @@ __global__ __launch_bounds__(256) void k_cbr_search_reg(const CbrParams p) {
   } // slices of the wavefront
 }
 
+#include "vc2hip_cbr16.h"
+
 // wavefronts per workgroup so that their LDS (per_wave bytes each) fits: 4 down to 1; 0 if even one does not
 int vc2_waves_for_lds(size_t per_wave);
 int vc2_waves_for_lds(size_t per_wave) {
@@ -1500,7 +1502,11 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_
                    p.comp_off[1] % 8 == 0 && p.comp_off[2] % 8 == 0;
   if (reg) { // the register kernel, then the general one over the slices it handed back (usually none: a small grid)
     const int per_wg = 4 * CBR_SPW; // slices per workgroup
-    if (p.store16) VC2_LAUNCH(L, k_cbr_search_reg<int16_t>, dim3((p.n_slices + per_wg - 1) / per_wg, n_pictures), dim3(256), 0, s, p);
+    static const int use16 = vc2_tune_int("VC2HIP_CBR16", 1);
+    CbrParams p16 = p;
+    if (use16 && cbr16_plan(p16, p16.lane8)) // the head / run layout of the slice coder: three constants per lane and trial
+      VC2_LAUNCH(L, k_cbr_search16, dim3((p.n_slices + per_wg - 1) / per_wg, n_pictures), dim3(256), 0, s, p16);
+    else if (p.store16) VC2_LAUNCH(L, k_cbr_search_reg<int16_t>, dim3((p.n_slices + per_wg - 1) / per_wg, n_pictures), dim3(256), 0, s, p);
     else VC2_LAUNCH(L, k_cbr_search_reg<int32_t>, dim3((p.n_slices + per_wg - 1) / per_wg, n_pictures), dim3(256), 0, s, p);
     p.only_marked = 1;
   }
