@@ -547,6 +547,125 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
   TILE_STAMP(3);
 }
 
+#ifndef VC2_INV_SHAPED
+#define VC2_INV_SHAPED 1 // 0: the generic loop for every shape (A/B on one box)
+#endif
+// ------------------------------------------------------------------------------------------
+// inverse, deep levels: the slice-by-slice gather with the block shape known at compile time
+// ------------------------------------------------------------------------------------------
+// A slice's coefficients of the level are CN = (3 or 4) * BN contiguous elements ([LL |] HL | LH | HH, blocks of
+// BSH x BSW = 2^(LN-LW) x 2^LW).  One thread takes whole slices: every load of its GB slices (the quads of
+// coefficients, the quantiser index) is issued before the first is consumed -- one trip to memory per workgroup for
+// every shape of the BASELINE formats -- and band, block row and column of every element are constants: a band's
+// quantiser constants are looked up once per slice, a block row goes to LDS as one 4 / 8 / 16-byte write.  (The generic
+// loop of k_inv_fast derives all of that per piece of four elements: 145 instructions a piece; its phase was 14 of a
+// workgroup's 21 us at the deepest level of UHD, 8 of 15 at the level above.)  Same values as the generic loop.
+template <class C, int NT, class ST, int LW, int LN, bool LLF>
+__device__ __forceinline__ void gather_slices(int *lds, const int *qtab, const LevelParams &p, int comp, const ST *store,
+                                              const int32_t *wide, const int32_t *qidx, int ky_base, int kx_base, int npy,
+                                              int npx, int chunk0) {
+  using S_ = St<ST>;
+  constexpr int BSW = 1 << LW, BN = 1 << LN, BSH = BN / BSW, LH = LN - LW;
+  constexpr int B0 = LLF ? 0 : 1, NB = 4 - B0, CN = NB * BN, NQ = CN / 4;
+  static_assert(CN % 4 == 0 && LH >= 0, "whole quads");
+  constexpr int GB = NQ >= 6 ? 1 : NQ >= 3 ? 2 : NQ == 2 ? 4 : 8;
+  constexpr int WYP = C::WYP, WXP = C::WXP;
+  const int sr0 = max(ky_base, 0) >> LH, sr1 = min(ky_base + WYP - 1, npy - 1) >> LH;
+  const int sc0 = max(kx_base, 0) >> LW, sc1 = min(kx_base + WXP - 1, npx - 1) >> LW;
+  const int nsc = sc1 - sc0 + 1, nsl = (sr1 - sr0 + 1) * nsc;
+  const unsigned mg_nsc = 0xFFFFFFFFu / (unsigned)nsc + 1u;
+  const int rs = p.rec_stride[comp], xs = p.xs;
+  int qm[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) qm[b] = (B0 + b) == 0 ? p.qmatrix[0] : p.qmatrix[p.band + B0 + b - 1];
+  for (int id0 = threadIdx.x; id0 < nsl; id0 += NT * GB) {
+    int4 raw[GB][NQ]; // int16 store: four elements in .x, .y
+    int q[GB], sv_[GB], sh_[GB];
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int id = id0 + g * NT;
+      q[g] = 0; sv_[g] = -1; sh_[g] = 0;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) raw[g][k] = make_int4(0, 0, 0, 0);
+      if (id >= nsl) continue;
+      const int sr = nsc == 1 ? id : (int)__umulhi((unsigned)id, mg_nsc);
+      const int sv = sr0 + sr, sh = sc0 + (id - sr * nsc);
+      sv_[g] = sv; sh_[g] = sh;
+      const ST *src = store + (size_t)(sv * xs + sh) * rs + chunk0;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        if constexpr (S_::narrow) { const uint2 v = *(const uint2 *)(src + 4 * k); raw[g][k].x = (int)v.x; raw[g][k].y = (int)v.y; }
+        else raw[g][k] = *(const int4 *)(src + 4 * k);
+      }
+      if (p.dequant) q[g] = qidx[sv * xs + sh];
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      if (sv_[g] < 0) continue;
+      const int sv = sv_[g], sh = sh_[g];
+      int v[CN];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        if constexpr (S_::narrow) {
+          const unsigned w0 = (unsigned)raw[g][k].x, w1 = (unsigned)raw[g][k].y;
+          v[4 * k] = vc2_lo16(w0); v[4 * k + 1] = vc2_hi16(w0); v[4 * k + 2] = vc2_lo16(w1); v[4 * k + 3] = vc2_hi16(w1);
+        } else { v[4 * k] = raw[g][k].x; v[4 * k + 1] = raw[g][k].y; v[4 * k + 2] = raw[g][k].z; v[4 * k + 3] = raw[g][k].w; }
+      }
+      if constexpr (S_::narrow) {
+        int mn = v[0];
+#pragma unroll
+        for (int k = 1; k < CN; ++k) mn = min(mn, v[k]);
+        if (mn == VC2_ST_SENTINEL) { // values that did not fit 16 bits: the wide plane
+          const int32_t *wq = wide + (size_t)(sv * xs + sh) * rs + chunk0;
+#pragma unroll
+          for (int k = 0; k < CN; ++k) if (v[k] == VC2_ST_SENTINEL) v[k] = wq[k];
+        }
+      }
+      const int i0 = (sv << LH) - ky_base, j0 = (sh << LW) - kx_base;
+      const bool cols_in = j0 >= 0 && j0 + BSW <= WXP; // (window origin and width are multiples of four: all or none)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        int *e = v + b * BN;
+        if (p.dequant && !VC2_SKIP(p, 8)) {
+          const int aq = max(q[g] - qm[b], 0);
+          if (aq > 119) atomicOr(p.err, VC2_DEVERR_QINDEX);
+          const int qf = qtab[min(aq, 119)], qo = qtab[120 + min(aq, 119)], lim = qtab[240 + min(aq, 119)];
+          // scale(), Quantisation.cpp:86-95: (|v| * factor + offset + 2) >> 2 for v != 0 inside the domain (no int
+          // overflow: one magnitude test for the band's elements), the literal sequence outside
+          unsigned mg[BN], any = 0;
+#pragma unroll
+          for (int k = 0; k < BN; ++k) { mg[k] = e[k] < 0 ? 0u - (unsigned)e[k] : (unsigned)e[k]; any |= mg[k]; }
+          if ((int)any >= 0 && (int)any <= lim) {
+#pragma unroll
+            for (int k = 0; k < BN; ++k) {
+              const unsigned r = mg[k] ? (mg[k] * (unsigned)qf + (unsigned)(qo + 2)) >> 2 : 0u;
+              e[k] = e[k] < 0 ? (int)(0u - r) : (int)r;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < BN; ++k) e[k] = dequant_f(e[k], qf, qo);
+          }
+        }
+        int *dst = lds + (B0 + b) * C::PLANE + i0 * WXP + j0;
+#pragma unroll
+        for (int r = 0; r < BSH; ++r) {
+          if (i0 + r < 0 || i0 + r >= WYP) continue;
+          int *d = dst + r * WXP;
+          const int *s = e + r * BSW;
+          if (cols_in) {
+            if constexpr (BSW == 4) lds_st4(d, {s[0], s[1], s[2], s[3]});
+            else if constexpr (BSW == 2) *(int2 *)d = make_int2(s[0], s[1]);
+            else d[0] = s[0];
+          } else {
+#pragma unroll
+            for (int c = 0; c < BSW; ++c) if (j0 + c >= 0 && j0 + c < WXP) d[c] = s[c];
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse level
 // ------------------------------------------------------------------------------------------
@@ -576,14 +695,11 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
 
   // quant_factor / quant_offset by adjusted index, copied next to the planes: the look-up that follows the
   // slice's index load is then an LDS read instead of a second dependent trip to memory
+  // (requested here, put into LDS behind the window's own requests below: the two trips to memory side by side instead of
+  // one after the other with a barrier between them -- 1.1 - 1.6 us of a workgroup's 15 - 21 at the deep levels of UHD)
   int *qtab = lds + 4 * C::PLANE;
-  if (threadIdx.x < 120) {
-    const int qf = c_qd.qf[threadIdx.x], off = c_qd.off[threadIdx.x];
-    qtab[threadIdx.x] = qf; qtab[120 + threadIdx.x] = off;
-    // largest magnitude for which |v| * factor + offset + 2 stays below 2^31 (the literal arithmetic otherwise)
-    qtab[240 + threadIdx.x] = qf > 0 ? (int)((0x7FFFFFFFu - (unsigned)off - 2u) / (unsigned)qf) : -1;
-  }
-  __syncthreads();
+  int qt_f = 0, qt_o = 0;
+  if (threadIdx.x < 120) { qt_f = c_qd.qf[threadIdx.x]; qt_o = c_qd.off[threadIdx.x]; }
   TILE_STAMP(1);
 
   // ---- gather LL + the three detail bands of tile + halo, dequantising on the way in.
@@ -626,6 +742,12 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
         }
       }
     }
+    if (threadIdx.x < 120) {
+      qtab[threadIdx.x] = qt_f; qtab[120 + threadIdx.x] = qt_o;
+      // largest magnitude for which |v| * factor + offset + 2 stays below 2^31 (the literal arithmetic otherwise)
+      qtab[240 + threadIdx.x] = qt_f > 0 ? (int)((0x7FFFFFFFu - (unsigned)qt_o - 2u) / (unsigned)qt_f) : -1;
+    }
+    __syncthreads();
 #pragma unroll
     for (int band = 0; band < 4; ++band) {
       int *dst = lds + band * C::PLANE;
@@ -723,7 +845,19 @@ __global__ __launch_bounds__(NTK<K>) void k_inv_fast(const LevelParams p) {
     // two divisions by run-time constants per piece are multiplications (exact for the < 2^16 pieces of a tile).
     constexpr int GB = 4;
     const bool pairs = lbn >= 1 && lbsw >= 1 && (chunk_n & 1) == 0;
-    const int total = VC2_SKIP(p, 1) ? 0 : nsl * nq;
+    // block shapes known at compile time (every deep level of the BASELINE formats): gather_slices above
+    bool shaped = false;
+    if (VC2_INV_SHAPED && al && !VC2_SKIP(p, 1)) {
+#define VC2_SHAPE(LW_, LN_, LLF_)                                                                                          \
+  if (!shaped && lbsw == LW_ && lbn == LN_ && band_first == (LLF_ ? 0 : 1)) {                                              \
+    gather_slices<C, NT, ST, LW_, LN_, LLF_>(lds, qtab, p, comp, store, wide, qidx, ky_base, kx_base, npy, npx, chunk0);   \
+    shaped = true;                                                                                                         \
+  }
+      VC2_SHAPE(0, 0, true) VC2_SHAPE(0, 1, true) VC2_SHAPE(1, 1, true) VC2_SHAPE(1, 2, true) VC2_SHAPE(2, 2, true) VC2_SHAPE(2, 3, true)
+      VC2_SHAPE(1, 2, false) VC2_SHAPE(2, 2, false) VC2_SHAPE(2, 3, false)
+#undef VC2_SHAPE
+    }
+    const int total = (VC2_SKIP(p, 1) || shaped) ? 0 : nsl * nq;
     const unsigned mg_nq = 0xFFFFFFFFu / (unsigned)nq + 1u, mg_nsc = 0xFFFFFFFFu / (unsigned)nsc + 1u;
     for (int id0 = threadIdx.x; id0 < total; id0 += NT * GB) {
       int e[GB][4], q[GB], sv_[GB], sh_[GB], qd_[GB];
