@@ -104,6 +104,31 @@ def test_store16_escapes_both_directions(variants, oracle):
     assert hit is not None, "no quantiser index puts quantised values between 32768 and 65534"
 
 
+@pytest.mark.parametrize("cf", ["422", "444"])
+def test_deep_level_shapes_with_escapes(variants, oracle, cf):
+    """The deep levels of the UHD slice geometry (32 x 16 slices, depth 4: blocks of 2 x 1 and 1 x 1 coefficients with LL
+    at the deepest level, 4 x 2 and 2 x 2 above it -- the compile-time shapes of the inverse tile kernel's slice
+    gather) on 16-bit noise: LL and the coarse bands pass 32767 after quantisation, so the record heads hold escapes
+    exactly where that gather reads them; the lowest index the reference's code words allow."""
+    w, h, depth, u, a = 2048, 256, 4, 1, 2
+    raw = noise_frame(w, h, cf, 16, seed=91)
+    hip = variants["default"]
+    hit = None
+    for q in (40, 36, 32, 28, 24, 20, 16, 12):
+        fmt, cp = _fmt_cp(hip, w, h, cf, 16, "DD97", depth, u, a, q=q, scalar=8)
+        try:
+            payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+        except Exception:   # |quantised| > 65534: outside the reference's domain
+            break
+        cw = w if cf == "444" else w // 2
+        y, cu, cv, _, _ = oracle.hq_unpack(np.frombuffer(payload, np.uint8), (h, w), (h, cw), depth, cp.y_slices, cp.x_slices, 0, 8)
+        mx = max(int(np.abs(x).max()) for x in (y, cu, cv))
+        if 32767 < mx <= 65534:
+            hit = q
+    assert hit is not None, "no quantiser index puts quantised values between 32768 and 65534"
+    _check(variants, oracle, raw, w, h, cf, 16, "DD97", depth, u, a, q=hit, scalar=8)
+
+
 def test_pipelined_picture_calls(variants, oracle):
     """vc2hip_encode_picture_begin / _end and the decode pair (two pictures in flight, pinned staging): the bytes of the
     synchronous calls, in order; a third _begin before an _end is refused"""

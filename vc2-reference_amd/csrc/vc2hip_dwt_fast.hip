@@ -322,6 +322,7 @@ __device__ __forceinline__ int dequant_f(int v, int qf, int off) {
 }
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
 // workgroup `lin` runs on XCD lin % 8.  Re-number the tiles so that every XCD gets one contiguous,
@@ -337,6 +338,42 @@ __device__ __forceinline__ bool tile_of_block(int tiles_x, int tiles_y, int &tx,
   ty = L / tiles_x;
   tx = L - ty * tiles_x;
   return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, deep levels: the slice-by-slice write with the block shape known at compile time (the counterpart of
+// gather_slices further down: a thread assembles a slice's [LL |] HL | LH | HH run from whole block rows of the four
+// planes and stores it quad by quad; slice row / column of a thread by shifts)
+// ------------------------------------------------------------------------------------------
+#ifndef VC2_FWD_SHAPED
+#define VC2_FWD_SHAPED 1 // 0: the generic loop for every shape (A/B on one box)
+#endif
+template <class C, int NT, class ST, int LW, int LN, bool LLF>
+__device__ __forceinline__ void scatter_slices(const int *core, const LevelParams &p, int comp, ST *store, int32_t *wide,
+                                               int s_y0, int s_x0, int chunk0) {
+  using S_ = St<ST>;
+  constexpr int BSW = 1 << LW, BN = 1 << LN, BSH = BN / BSW;
+  constexpr int B0 = LLF ? 0 : 1, NB = 4 - B0, CN = NB * BN, NQ = CN / 4;
+  static_assert(CN % 4 == 0 && LN >= LW, "whole quads");
+  constexpr int LTSX = ilog2c(TX / 2) - LW, NSL = ((TY / 2) * (TX / 2)) >> LN; // slices across a tile (log2), slices of a tile
+  const int rs = p.rec_stride[comp], xs = p.xs;
+  for (int sidx = threadIdx.x; sidx < NSL; sidx += NT) {
+    const int si = sidx >> LTSX, sj = sidx & ((1 << LTSX) - 1);
+    int v[CN];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < BSH; ++r) {
+        const int *s = core + (B0 + b) * C::PLANE + (si * BSH + r) * C::WXP + sj * BSW;
+        int *d = v + b * BN + r * BSW;
+        if constexpr (BSW == 4) { const I4 t = lds_ld4(s); d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+        else if constexpr (BSW == 2) { const int2 t = *(const int2 *)s; d[0] = t.x; d[1] = t.y; }
+        else d[0] = s[0];
+      }
+    const size_t at = (size_t)((s_y0 + si) * xs + s_x0 + sj) * rs + chunk0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) S_::store4(store + at + 4 * k, wide + at + 4 * k, v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,7 +523,18 @@ __global__ __launch_bounds__(NTK<K>) void k_fwd_fast(const LevelParams p) {
     const int chunk_n = (4 - band_first) * band_n, nq = (chunk_n + 3) >> 2;
     const int tsx = TX / fw, nsl = (TY / fh) * tsx;
     const bool al = ((chunk0 | p.rec_stride[comp]) & 3) == 0;
-    for (int id = threadIdx.x; id < nsl * nq; id += NT) {
+    bool shaped = false;
+    if (VC2_FWD_SHAPED && al) {
+#define VC2_SHAPE(LW_, LN_, LLF_)                                                                  \
+  if (!shaped && lbsw == LW_ && lbn == LN_ && band_first == (LLF_ ? 0 : 1)) {                      \
+    scatter_slices<C, NT, ST, LW_, LN_, LLF_>(core, p, comp, store, wide, s_y0, s_x0, chunk0);     \
+    shaped = true;                                                                                 \
+  }
+      VC2_SHAPE(0, 0, true) VC2_SHAPE(0, 1, true) VC2_SHAPE(1, 1, true) VC2_SHAPE(1, 2, true)
+      VC2_SHAPE(1, 2, false) VC2_SHAPE(1, 3, false)
+#undef VC2_SHAPE
+    }
+    for (int id = threadIdx.x; id < (shaped ? 0 : nsl * nq); id += NT) {
       const int sidx = id / nq, qd = id - sidx * nq;
       const int si = sidx / tsx, sj = sidx - si * tsx;
       int e[4];
