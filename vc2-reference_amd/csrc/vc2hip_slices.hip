@@ -1861,6 +1861,9 @@ void vc2_upload_unpack_lut(hipStream_t s) {
 #ifndef VC2_UNP_DEEP
 #define VC2_UNP_DEEP 1
 #endif
+#ifndef VC2_UNP_TAIL16
+#define VC2_UNP_TAIL16 1
+#endif
 #ifndef VC2_UNP_PAIR
 #define VC2_UNP_PAIR 0 // (1:) the stream's requests two at a time, for 32 adjacent bytes (see Reader32::skip)
 #endif
@@ -1879,6 +1882,7 @@ struct Reader32 {
 #endif
   unsigned off;            // byte offset (from the payload base) of the word after those
   int left;                // data bits from that word on (<= 0: none)
+  unsigned safe;           // end of the picture's payload slot, as such an offset (wave-uniform)
 #ifdef VC2HIP_ABLATE
   unsigned dbg_mask;
 #endif
@@ -1902,7 +1906,23 @@ struct Reader32 {
       a = __builtin_bswap32(v.x); b = __builtin_bswap32(v.y); c = __builtin_bswap32(v.z); d = __builtin_bswap32(v.w);
       off += 16;
       left -= 128;
-    } else { a = fetch1(pay); b = fetch1(pay); c = fetch1(pay); d = fetch1(pay); } // the stream's end: word by word
+    }
+#if VC2_UNP_TAIL16
+    // The stream's last data bytes: still ONE load when its sixteen bytes lie inside the picture's slot (`safe`), the bits
+    // behind the data forced to 1.  Word by word (below) every load was waited for before the next went out, and a
+    // wavefront meets the end of a stream once per lane: 64 times up to four trips to L2 in a row.
+    else if (left > 0 && off + 16u <= safe) {
+      const Dword4 v = *(const Dword4 *)(pay + off);
+      auto ones_from = [](int k) -> unsigned { return k >= 32 ? 0u : ~0u >> max(k, 0); }; // bits k.. of a word (k = its data bits)
+      a = __builtin_bswap32(v.x) | ones_from(left);
+      b = __builtin_bswap32(v.y) | ones_from(left - 32);
+      c = __builtin_bswap32(v.z) | ones_from(left - 64);
+      d = __builtin_bswap32(v.w) | ones_from(left - 96);
+      off += 16;
+      left -= 128;
+    }
+#endif
+    else { a = fetch1(pay); b = fetch1(pay); c = fetch1(pay); d = fetch1(pay); } // the slot's end (or no data left): word by word
   }
   __device__ __forceinline__ void fetch4(const uint8_t *pay) { fetch4(pay, n0, n1, n2, n3); }
   // nbytes of data at byte offset pos of the payload
@@ -1971,6 +1991,9 @@ __device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int
 #ifndef VC2_UNP16_WAVES
 #define VC2_UNP16_WAVES 4
 #endif
+#ifndef VC2_UNP_BRANCHLESS
+#define VC2_UNP_BRANCHLESS 1
+#endif
 __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const UnpackParams p) {
   constexpr int UNP_N = VC2_UNP16_N, UNP_PITCH = UNP_N + 8, PR = UNP_N / 8; // shorts per staging row (8 of slack), 16-byte aligned rows; pieces per row
   __shared__ __attribute__((aligned(16))) short stage[VC2_UNP16_WAVES][64 * UNP_PITCH];
@@ -2037,6 +2060,7 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
 #ifdef VC2HIP_ABLATE
     br.dbg_mask = VC2_SKIP(p, 1) ? 0x3FFCu : ~0u;
 #endif
+    br.safe = (unsigned)min((unsigned long long)p.payload_stride + mis, 0xFFFFFFF0ull);
     br.init(pay, pos + mis, (int)len);
   }
 #pragma unroll
@@ -2051,8 +2075,15 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
 #pragma unroll
       for (int look = 0; look < UNP_LOOKS; ++look) {
         const unsigned w = look ? (unsigned)((br.acc << used) >> 32) : br.top();
-        const unsigned e = lut[w >> (32 - UNP_LUT_BITS)];
-        if (e != 0 && (look == 0 || (used != 0 && cnt < room))) {
+        unsigned e = lut[w >> (32 - UNP_LUT_BITS)];
+#if VC2_UNP_BRANCHLESS
+        // Applied without a branch: an entry of 0 (no whole code in the window) rewrites the zero at st[cnt] and moves
+        // nothing, and a lane whose row is full takes 0 for its entry -- three nested EXEC branches per look-up otherwise
+        if (look) e = cnt < room ? e : 0u;
+#else
+        if (e != 0 && (look == 0 || (used != 0 && cnt < room)))
+#endif
+        {
           st[cnt + (int)((e >> 8) & 15u)] = (short)__builtin_amdgcn_sbfe((int)e, 16, 8);
           st[cnt + (int)((e >> 12) & 15u)] = (short)((int)e >> 24);
           cnt += (int)((e >> 4) & 15u);
