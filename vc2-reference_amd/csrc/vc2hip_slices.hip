@@ -1872,7 +1872,7 @@ struct Reader32 {
   int have;                // valid bits in acc, 33..64 between turns
   unsigned q0, q1, q2, q3; // the words after those in acc (q0 first); qn of them are valid, 1..4 between turns
   int qn;
-  unsigned n0, n1, n2, n3; // the four words after the queue
+  unsigned n0, n1, n2, n3; // the four words after the queue (these and the ones below: in memory order, byte-swapped on their way into the queue)
 #if VC2_UNP_DEEP
   unsigned m0, m1, m2, m3; // and the four after those ...
 #if VC2_UNP_PAIR
@@ -1903,7 +1903,9 @@ struct Reader32 {
 #else
       const Dword4 v = *(const Dword4 *)(pay + off);
 #endif
-      a = __builtin_bswap32(v.x); b = __builtin_bswap32(v.y); c = __builtin_bswap32(v.z); d = __builtin_bswap32(v.w);
+      // (the words stay in memory order until they move into the queue -- skip() / init() swap them there: swapped here,
+      // four more instructions stand between the request and the wait the compiler puts behind it, in every refill)
+      a = v.x; b = v.y; c = v.z; d = v.w;
       off += 16;
       left -= 128;
     }
@@ -1914,15 +1916,17 @@ struct Reader32 {
     else if (left > 0 && off + 16u <= safe) {
       const Dword4 v = *(const Dword4 *)(pay + off);
       auto ones_from = [](int k) -> unsigned { return k >= 32 ? 0u : ~0u >> max(k, 0); }; // bits k.. of a word (k = its data bits)
-      a = __builtin_bswap32(v.x) | ones_from(left);
-      b = __builtin_bswap32(v.y) | ones_from(left - 32);
-      c = __builtin_bswap32(v.z) | ones_from(left - 64);
-      d = __builtin_bswap32(v.w) | ones_from(left - 96);
+      a = v.x | __builtin_bswap32(ones_from(left));
+      b = v.y | __builtin_bswap32(ones_from(left - 32));
+      c = v.z | __builtin_bswap32(ones_from(left - 64));
+      d = v.w | __builtin_bswap32(ones_from(left - 96));
       off += 16;
       left -= 128;
     }
 #endif
-    else { a = fetch1(pay); b = fetch1(pay); c = fetch1(pay); d = fetch1(pay); } // the slot's end (or no data left): word by word
+    else { // the slot's end (or no data left): word by word, back into memory order like the others
+      a = __builtin_bswap32(fetch1(pay)); b = __builtin_bswap32(fetch1(pay)); c = __builtin_bswap32(fetch1(pay)); d = __builtin_bswap32(fetch1(pay));
+    }
   }
   __device__ __forceinline__ void fetch4(const uint8_t *pay) { fetch4(pay, n0, n1, n2, n3); }
   // nbytes of data at byte offset pos of the payload
@@ -1931,9 +1935,9 @@ struct Reader32 {
     off = pos & ~3u;
     left = nbytes > 0 ? 8 * nbytes + lead : 0;
     fetch4(pay);
-    acc = (((unsigned long long)n0 << 32) | n1) << lead;
+    acc = (((unsigned long long)__builtin_bswap32(n0) << 32) | __builtin_bswap32(n1)) << lead;
     have = 64 - lead;
-    q0 = n2; q1 = n3; q2 = ~0u; q3 = ~0u; qn = 2;
+    q0 = __builtin_bswap32(n2); q1 = __builtin_bswap32(n3); q2 = ~0u; q3 = ~0u; qn = 2;
     fetch4(pay);
 #if VC2_UNP_DEEP
     fetch4(pay, m0, m1, m2, m3);
@@ -1959,16 +1963,16 @@ struct Reader32 {
       // requests per line, the same eight words or more between a request and its use.
 #if VC2_UNP_PAIR
       if (--qn == 0) {
-        q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4;
+        q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4;
         n0 = m0; n1 = m1; n2 = m2; n3 = m3;
         m0 = o0; m1 = o1; m2 = o2; m3 = o3;
         if ((pairs ^= 1) == 0) { fetch4(pay, m0, m1, m2, m3); fetch4(pay, o0, o1, o2, o3); }
       }
 #else
-      if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; n0 = m0; n1 = m1; n2 = m2; n3 = m3; fetch4(pay, m0, m1, m2, m3); }
+      if (--qn == 0) { q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4; n0 = m0; n1 = m1; n2 = m2; n3 = m3; fetch4(pay, m0, m1, m2, m3); }
 #endif
 #else
-      if (--qn == 0) { q0 = n0; q1 = n1; q2 = n2; q3 = n3; qn = 4; fetch4(pay); }
+      if (--qn == 0) { q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4; fetch4(pay); }
 #endif
     }
   }
