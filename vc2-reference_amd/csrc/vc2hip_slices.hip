@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(256) void k_hq_unpack(const UnpackParams p) {
 // [23:16] / [31:24] the values (int8).  No non-zero value: both slots store 0 at position 0 (a zero anyway); one: both
 // slots hold it.  0: the first token is a code longer than the index.
 #ifndef UNP_LOOKS
-#define UNP_LOOKS 3
+#define UNP_LOOKS 4 // look-ups per turn of k_hq_unpack16 (2: 0.570, 3: 0.545, 4: 0.535, 5: 0.538, 6: 0.550 ms per 32 UHD pictures; the fourth only with a whole index of unread bits left)
 #endif
 #ifndef VC2_UNP16_N
 #define VC2_UNP16_N 32
@@ -2083,7 +2083,7 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
 #if VC2_UNP_BRANCHLESS
         // Applied without a branch: an entry of 0 (no whole code in the window) rewrites the zero at st[cnt] and moves
         // nothing, and a lane whose row is full takes 0 for its entry -- three nested EXEC branches per look-up otherwise
-        if (look) e = cnt < room ? e : 0u;
+        if (look) e = (cnt < room && (look < 3 || used + UNP_LUT_BITS <= br.have)) ? e : 0u; // (a fourth look-up: only with a whole index of unread bits)
 #else
         if (e != 0 && (look == 0 || (used != 0 && cnt < room)))
 #endif
