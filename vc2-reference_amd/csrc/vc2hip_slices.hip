@@ -1865,7 +1865,7 @@ void vc2_upload_unpack_lut(hipStream_t s) {
 #define VC2_UNP_TAIL16 1
 #endif
 #ifndef VC2_UNP_PAIR
-#define VC2_UNP_PAIR 0 // (1:) the stream's requests two at a time, for 32 adjacent bytes (see Reader32::skip)
+#define VC2_UNP_PAIR 2 // the stream's requests FOUR at a time (64 adjacent bytes) on every fourth refill; 1: two on every second; 0: one per refill (see Reader32::skip)
 #endif
 struct Reader32 {
   unsigned long long acc;
@@ -1877,7 +1877,10 @@ struct Reader32 {
   unsigned m0, m1, m2, m3; // and the four after those ...
 #if VC2_UNP_PAIR
   unsigned o0, o1, o2, o3; // ... and four more: requests go out TWO AT A TIME, for 32 adjacent bytes (round 4, see skip())
-  int pairs;               // parity of the refills: the odd ones only shift
+  int pairs;               // parity of the refills: the odd ones only shift (VC2_UNP_PAIR == 2: their count mod 4)
+#if VC2_UNP_PAIR == 2
+  unsigned r0, r1, r2, r3, s0, s1, s2, s3; // FOUR requests (64 adjacent bytes) on every fourth refill
+#endif
 #endif
 #endif
   unsigned off;            // byte offset (from the payload base) of the word after those
@@ -1944,6 +1947,10 @@ struct Reader32 {
 #if VC2_UNP_PAIR
     fetch4(pay, o0, o1, o2, o3);
     pairs = 0;
+#if VC2_UNP_PAIR == 2
+    fetch4(pay, r0, r1, r2, r3);
+    fetch4(pay, s0, s1, s2, s3);
+#endif
 #endif
 #endif
   }
@@ -1961,7 +1968,21 @@ struct Reader32 {
       // to eight times (rocprofv3 FETCH_SIZE 3.2 - 3.9 x the payload).  Every second refill now requests the next 32
       // bytes at once (two adjacent loads, the second meets the first one's line), the others only shift: half the
       // requests per line, the same eight words or more between a request and its use.
-#if VC2_UNP_PAIR
+      // Round 4's end: what a request costs is not its traffic but the WAIT the compiler puts directly behind it (the
+      // results of the forms of request merge through temporary registers that are copied out at once): whenever any lane of a
+      // wavefront requests, the wavefront stands still for that trip to memory and for the stores of its last flush (the
+      // counter is in order).  So the fewer refills request at all, the better: one request per refill 0.536 ms per 32 UHD
+      // pictures, two on every second 0.468, four on every fourth 0.469 (cfg 4, whose streams are long: 0.326 / 0.265 / 0.243).
+#if VC2_UNP_PAIR == 2
+      if (--qn == 0) {
+        q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4;
+        n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+        m0 = o0; m1 = o1; m2 = o2; m3 = o3;
+        o0 = r0; o1 = r1; o2 = r2; o3 = r3;
+        r0 = s0; r1 = s1; r2 = s2; r3 = s3;
+        if (((++pairs) & 3) == 0) { fetch4(pay, m0, m1, m2, m3); fetch4(pay, o0, o1, o2, o3); fetch4(pay, r0, r1, r2, r3); fetch4(pay, s0, s1, s2, s3); }
+      }
+#elif VC2_UNP_PAIR
       if (--qn == 0) {
         q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4;
         n0 = m0; n1 = m1; n2 = m2; n3 = m3;
