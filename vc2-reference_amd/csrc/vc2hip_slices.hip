@@ -1980,7 +1980,20 @@ struct Reader32 {
         m0 = o0; m1 = o1; m2 = o2; m3 = o3;
         o0 = r0; o1 = r1; o2 = r2; o3 = r3;
         r0 = s0; r1 = s1; r2 = s2; r3 = s3;
-        if (((++pairs) & 3) == 0) { fetch4(pay, m0, m1, m2, m3); fetch4(pay, o0, o1, o2, o3); fetch4(pay, r0, r1, r2, r3); fetch4(pay, s0, s1, s2, s3); }
+        if (((++pairs) & 3) == 0) {
+          if (left >= 512) { // four whole pieces: one test for the four requests
+#ifdef VC2HIP_ABLATE
+            const uint8_t *at = pay + (off & dbg_mask);
+#else
+            const uint8_t *at = pay + off;
+#endif
+            const Dword4 a = *(const Dword4 *)at, b = *(const Dword4 *)(at + 16), c = *(const Dword4 *)(at + 32), d = *(const Dword4 *)(at + 48);
+            m0 = a.x; m1 = a.y; m2 = a.z; m3 = a.w; o0 = b.x; o1 = b.y; o2 = b.z; o3 = b.w;
+            r0 = c.x; r1 = c.y; r2 = c.z; r3 = c.w; s0 = d.x; s1 = d.y; s2 = d.z; s3 = d.w;
+            off += 64;
+            left -= 512;
+          } else { fetch4(pay, m0, m1, m2, m3); fetch4(pay, o0, o1, o2, o3); fetch4(pay, r0, r1, r2, r3); fetch4(pay, s0, s1, s2, s3); }
+        }
       }
 #elif VC2_UNP_PAIR
       if (--qn == 0) {
