@@ -43,6 +43,68 @@ KERNEL, DEPTH, U, A, Q, SCALAR = "DD97", 4, 1, 2, 16, 2
 PORT_VS_REFERENCE = 1.29
 
 
+class ClockSampler:
+    """The GPU's own clocks and socket power, read from the amdgpu hwmon files of the HIP device while a region runs
+    (freq1_input = sclk, freq2_input = mclk in Hz, power1_input in microwatts; no root, no subprocess).  VERDICT r4
+    item 2: the level-0 transforms run in one of two modes from box to box (DESIGN.md "Where the spread between runs comes
+    from"); this puts a clock / power reading next to every line so that the attribution is evidence."""
+
+    def __init__(self, pci_bus_id):
+        self.dir, self.samples, self._stop, self._thread = None, [], False, None
+        want = (pci_bus_id or "").lower()
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                addr = os.path.basename(os.path.realpath(d)).lower()
+            except OSError:
+                continue
+            hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
+            if hw and (addr == want or (not want and self.dir is None)):
+                self.dir = hw[0]
+                self.card = d
+                if addr == want:
+                    break
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def read(self):
+        if self.dir is None:
+            return None
+        return (self._read("freq1_input"), self._read("freq2_input"), self._read("power1_input"))
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], False
+
+        def run():
+            while not self._stop:
+                r = self.read()
+                if r is not None:
+                    self.samples.append(r)
+                time.sleep(0.0005)
+        if self.dir is not None:
+            self._thread = threading.Thread(target=run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        return self.summary(self.samples)
+
+    @staticmethod
+    def summary(samples):
+        def col(i, scale):
+            v = [s[i] / scale for s in samples if s[i] is not None]
+            return {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1)} if v else None
+        return {"samples": len(samples), "sclk_MHz": col(0, 1e6), "mclk_MHz": col(1, 1e6), "socket_power_W": col(2, 1e6)}
+
+
 def picture_shard(n_pictures, rank, world):
     """Pictures are independent: picture k belongs to rank k mod world."""
     return list(range(rank, n_pictures, world))
@@ -271,16 +333,23 @@ def main():
     for _ in range(2):
         step_one_launch()
     hip.sync()
-    w_steps = 3
     hip.profile_reset()
     hip.profile_enable(True)
-    for _ in range(w_steps):
+    for _ in range(3):
         step_one_launch()
     hip.sync()
     hip.profile_enable(False)
-    warm = {k: v for k, v in hip.profile().items() if v[0] > 0 and k != "fill"}
-    dom = max(warm, key=lambda k: warm[k][1]) if warm else None
+    pre = {k: v for k, v in hip.profile().items() if v[0] > 0 and k != "fill"}
+    # the candidates for the step's longest kernel: the four longest of this first look; all four carry their event pairs
+    # inside the timed region, and the table taken AFTER it (below) says which of them is the dominant one
+    cands = sorted(pre, key=lambda k: -pre[k][1])[:4]
     hip.profile_reset()
+    try:
+        bus = torch.cuda.get_device_properties(dev_index)
+        bus_id = "%04x:%02x:%02x.0" % (getattr(bus, "pci_domain_id", 0), bus.pci_bus_id, bus.pci_device_id)
+    except Exception:
+        bus_id = None
+    clk = ClockSampler(bus_id)
 
     # ---- warm-up of the timed configuration: W untimed steps over the whole batch on `streams` streams
     if args.streams > 1:
@@ -292,12 +361,40 @@ def main():
 
     # ---- timed region: exactly K steps; the dominant kernel's launches carry their event pairs (on the library's stream)
     hip.profile_reset()
-    hip.profile_only(dom)
+    hip.profile_only(",".join(cands))
+    clk_idle = clk.read()
+    clk.start()
     dt = timed(step, args.steps)
+    clocks = clk.stop()
     hip.sync()  # collects the event pairs; raises on any device-side error flag
     hip.profile_enable(False)
     hip.profile_only(None)
     prof = hip.profile()
+
+    # ---- the per-kernel table, taken AFTER the timed region on the warm GPU (the table of round 4 was
+    # taken from 3 steps right behind 2 warm launches and summed to 6 % more than the step it described): w_steps passes
+    # with an event pair on every launch, the clocks sampled the same way
+    if args.streams > 1:
+        hip.set_streams(1)
+    for _ in range(3):
+        step_one_launch()
+    hip.sync()
+    w_steps = 10
+    hip.profile_reset()
+    hip.profile_enable(True)
+    clk.start()
+    for _ in range(w_steps):
+        step_one_launch()
+    hip.sync()
+    clocks_table = clk.stop()
+    hip.profile_enable(False)
+    warm = {k: v for k, v in hip.profile().items() if v[0] > 0 and k != "fill"}
+    dom = max(warm, key=lambda k: warm[k][1] / warm[k][0]) if warm else None   # the longest single launch
+    if dom not in prof or prof[dom][0] == 0:   # (not among the candidates: the longest that was)
+        dom = max((k for k in warm if k in prof and prof[k][0] > 0), key=lambda k: warm[k][1] / warm[k][0])
+    hip.profile_reset()
+    if args.streams > 1:
+        hip.set_streams(args.streams)
 
     # ---- beside it (never `value`): the same region without the per-kernel events; the two halves on their own
     dt_noev = timed(step, args.steps)
@@ -457,10 +554,20 @@ def main():
                          "path_algorithmic_bytes_per_step": int(2 * alg_dir * B),
                          "path_traffic_bytes": path_traffic,
                          "path_traffic_ratio": ({k: round(v / (2 * alg_dir * B), 2) for k, v in path_traffic.items()} if path_traffic else None),
-                         "kernel_events": f"the {dom_launches} launches of `{dom}` inside the timed region",
+                         "kernel_events": f"the {dom_launches} launches of `{dom}` inside the timed region (the event pairs of "
+                                          f"{', '.join(cands)} ride in the timed region; the table after it names the longest)",
+                         "kernel_in_run_ms": {k: round(prof[k][1] / prof[k][0], 4) for k in cands if k in prof and prof[k][0]},
                          "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_step_ms.items())},
-                         "kernel_ms_per_step_source": f"event pairs on every launch of {w_steps} untimed one-stream passes over {n_launch} pictures (one launch's worth), "
-                                                      f"times {launches_per_step:g} launches per step: kernels alone, additive"},
+                         "kernel_ms_per_step_sum": round(sum(kern_step_ms.values()), 4),
+                         "launch_gap_ms": round(dt / args.steps * 1e3 - sum(kern_step_ms.values()), 4),
+                         "launch_gap_note": "ms_per_step of the timed region minus the sum of the table: what the step spends between its "
+                                            "kernels (negative: the kernels ran faster inside the timed region than in the table pass)",
+                         "kernel_ms_per_step_source": f"event pairs on every launch of {w_steps} untimed one-stream passes over {n_launch} pictures (one launch's worth) "
+                                                      f"run right AFTER the timed region on the warm GPU, times {launches_per_step:g} launches per step: kernels alone, additive"},
+            "clocks": {"timed_region": clocks, "table_pass": clocks_table,
+                       "idle_before": (ClockSampler.summary([clk_idle]) if clk_idle else None),
+                       "source": (f"{clk.dir}: freq1_input (sclk), freq2_input (mclk), power1_input, sampled every ~0.5 ms by a thread while the region runs"
+                                  if clk.dir else "no readable amdgpu hwmon files for this device")},
             "value_without_kernel_events": round(total_px / dt_noev / 1e6, 1),
             "parity_checked": parity,
             "e2e": e2e,

@@ -51,7 +51,7 @@ struct ProfEntry {
 };
 struct Launcher {
   bool on = false;
-  std::string only;               // non-empty: event pairs for the launches of this name only (vc2hip_profile_only)
+  std::string only;               // non-empty: event pairs for the launches of these names only (vc2hip_profile_only: "a" or "a,b,c")
   const char *last_name = nullptr;
   std::string launch_error;
   std::vector<ProfEntry> entries;
@@ -79,7 +79,8 @@ struct Launcher {
 void vc2_prof_begin(Launcher &L, const char *name, hipStream_t s) {
   (void)s;
   L.last_name = name;
-  if (!L.on || (!L.only.empty() && L.only != name)) return;
+  if (!L.on) return;
+  if (!L.only.empty() && ("," + L.only + ",").find(std::string(",") + name + ",") == std::string::npos) return; // (a comma-separated list of names)
   int idx = -1;
   for (size_t i = 0; i < L.entries.size(); ++i) if (L.entries[i].name == name) { idx = (int)i; break; }
   if (idx < 0) { L.entries.push_back(ProfEntry{name, 0, 0}); idx = (int)L.entries.size() - 1; }

@@ -17,6 +17,7 @@
 // lane8[64] = luma head, [65] = chroma head (U and V alike), [66] = luma runs, [67] = chroma runs per component
 static bool cbr16_plan(const CbrParams &p, unsigned *lane8) {
   if (!p.store16 || p.comp_n[1] != p.comp_n[2] || p.comp_n0[1] != p.comp_n0[2]) return false;
+  if ((p.slice_coefs & 7) || (p.store_stride & 7)) return false; // every record on a 16-byte boundary (the uint4 loads)
   for (int l = 0; l < 72; ++l) lane8[l] = 0;
   int heads[3], runs[3];
   for (int c = 0; c < 3; ++c) {

@@ -435,7 +435,11 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
 
   // four band values of the lane into the image row (band b, block row r); values beyond 16 bits go to the wide plane
   auto stage4 = [&](int b, int r, int sv, int a0, int a1, int a2, int a3) __attribute__((always_inline)) {
+#ifdef VC2_STREAM_DIRECT // experiment: the lane's four values straight into the slice record (8 / 16 bytes per lane), no LDS image, no flush
+    ST *d = store + mul24z(sv * p.xs + sp.sx0 + si, p.slice_coefs) + run0 + (b - b0) * bn + r * bsw + cc;
+#else
     ST *d = stg + ((size_t)((b - b0) * bsh + r) * rs + si * bsw + cc);
+#endif
     if constexpr (S_::narrow) {
       const int mx = max(max(a0, a1), max(a2, a3)), mn = min(min(a0, a1), min(a2, a3));
       if (mx > 32767 || mn < -32767) {
@@ -450,6 +454,9 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   };
   // the image of one block row of slices to the slice records: 16-byte pieces of each slice's contiguous run
   auto flush = [&](int sv) __attribute__((always_inline)) {
+#ifdef VC2_STREAM_DIRECT
+    return;
+#endif
     wave_sync();
     constexpr int EP = 16 / (int)sizeof(ST);             // elements per piece
     const int lpb = ilog2d(bn) - ilog2d(EP);             // log2 pieces per band block (bn >= EP: host check)
@@ -1051,7 +1058,15 @@ size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool i
     size_t img;
     if (!inverse) img = (p.ll_to_store ? 4 : 3) * (size_t)bsh * rs * elem;
     else img = 16; // the inverse kernel reads the records directly
+#ifdef VC2_STREAM_DIRECT
+    img = 16;
+#endif
     lds = std::max(lds, img);
+  }
+  { // (ablation build: extra LDS per wavefront -- what the kernels lose with fewer resident wavefronts)
+    static const int pad4[4] = {vc2_tune_int("VC2HIP_STREAM_LDSPAD_FF", 0), vc2_tune_int("VC2HIP_STREAM_LDSPAD_FL", 0),
+                                vc2_tune_int("VC2HIP_STREAM_LDSPAD_IF", 0), vc2_tune_int("VC2HIP_STREAM_LDSPAD_IL", 0)};
+    lds += (size_t)pad4[(inverse ? 2 : 0) + (edge ? 0 : 1)];
   }
   if (lds > 40 * 1024 || lds * VC2_STREAM_WG_WAVES > 144 * 1024) return 0;
   // Segments: whole rows of slices, `nseg` per strip, the same for every component; segment g of a strip covers the

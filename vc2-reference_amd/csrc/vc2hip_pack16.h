@@ -59,11 +59,14 @@ static void fill_vlc_lut_s(unsigned *host) {
 // a reciprocal of zero (indices beyond the table quantise to zero)
 __device__ uint4 g_p16_qt[128];
 void vc2_upload_p16_tables(const QuantTables &t, hipStream_t s) {
-  static uint4 host[128]; // (written by whichever context comes first: the values are the same for all)
-  for (int q = 0; q < 128; ++q) {
-    if (q < 120) { union { float f; unsigned u; } w; w.f = t.inv4[q]; host[q] = make_uint4(t.magic[q], (unsigned)t.shift[q], (unsigned)t.qf[q], w.u); }
-    else host[q] = make_uint4(0u, 0u, 0x40000000u, 0u);
-  }
+  static uint4 host[128]; // (contexts are created concurrently: filled once, every context only copies it; the values are the same for all)
+  static std::once_flag once;
+  std::call_once(once, [&t] {
+    for (int q = 0; q < 128; ++q) {
+      if (q < 120) { union { float f; unsigned u; } w; w.f = t.inv4[q]; host[q] = make_uint4(t.magic[q], (unsigned)t.shift[q], (unsigned)t.qf[q], w.u); }
+      else host[q] = make_uint4(0u, 0u, 0x40000000u, 0u);
+    }
+  });
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_p16_qt), host, sizeof host, 0, hipMemcpyHostToDevice, s);
 }
 static void vc2_upload_vlc_lut_s(hipStream_t s) {
@@ -81,6 +84,7 @@ static void vc2_upload_vlc_lut_s(hipStream_t s) {
 // (the offsets of a lane's coefficients follow from those six numbers by arithmetic: no load in front of the record loads)
 static bool pack16_plan(const PackParams &p, unsigned *lane16) {
   if (!p.store16 || !p.quantise || p.lookback || p.tile_slices) return false;
+  if ((p.slice_coefs & 7) || (p.store_stride & 7)) return false; // every record on a 16-byte boundary (the uint4 loads)
   const int lo[3] = {0, 32, 48}, width[3] = {32, 16, 16};
   for (int l = 0; l < 128; ++l) lane16[l] = 0;
   int body_lanes = 0;
@@ -145,10 +149,12 @@ __device__ __forceinline__ void p16_group(const uint4 w, const float f, const un
 }
 
 // OR the first `keep` of the n <= 63 right-aligned bits of G into the image at bit position pos (0 <= keep <= n; what a
-// bounded write drops beyond the component's length are the '1's of trailing zeros, VLC.cpp:151-156).  No special cases:
-// n - keep and 64 - keep stay inside a 64-bit shift's range except keep == 0, where G >> n is already zero.
+// bounded write drops beyond the component's length are the '1's of trailing zeros, VLC.cpp:151-156).  No special cases
+// and no branch: with keep == 0 the value is zero and the three words it is OR-ed into may lie up to ~70 bytes behind the
+// wavefront's image (a run wholly beyond the component's room) -- the next wavefront's image or, for the last one, the
+// guard the launcher allocates behind the images (P16_GUARD_BYTES).
 __device__ __forceinline__ void p16_put(unsigned *img, int pos, unsigned long long G, int n, int keep) {
-  const unsigned long long v = (G >> (n - keep)) << (64 - keep); // left aligned
+  const unsigned long long v = (G >> (n - keep)) << ((64 - keep) & 63); // left aligned (keep == 0: G >> n is zero, the count 0)
   const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
   unsigned *at = img + (pos >> 5);
   const unsigned bo = (unsigned)pos; // (v_alignbit takes the low five bits)
@@ -376,6 +382,7 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
 //   lane16[195 + c] = body lanes of component c
 static bool pack16w_plan(const PackParams &p, unsigned *lane16) {
   if (!p.store16 || !p.quantise || p.lookback || p.tile_slices) return false;
+  if ((p.slice_coefs & 7) || (p.store_stride & 7)) return false; // every record on a 16-byte boundary (the uint4 loads)
   for (int l = 0; l < 200; ++l) lane16[l] = 0;
   int body_lanes = 0;
   for (int c = 0; c < 3; ++c) {
@@ -548,11 +555,12 @@ __global__ __launch_bounds__(192) void k_hq_pack16w(const PackParams p) {
   }
 }
 
+constexpr size_t P16_GUARD_BYTES = 128; // behind the last image: where p16_put's zero words of an all-zero tail may land
 static size_t pack16w_lds(int prefix, int scalar) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
-  return img_q * 16 + P16_LUT_N * 4 + 128 * 16;
+  return img_q * 16 + P16_LUT_N * 4 + 128 * 16 + P16_GUARD_BYTES;
 }
 static size_t pack16_lds(int prefix, int scalar) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
-  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 16;
+  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 16 + P16_GUARD_BYTES;
 }
