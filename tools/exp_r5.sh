@@ -17,5 +17,43 @@ e12)
   run VC2HIP_LIB=$A VC2HIP_STREAM_LDSPAD_IF=19000
   run VC2HIP_LIB=$A VC2HIP_STREAM_LDSPAD_FL=7000 VC2HIP_STREAM_LDSPAD_IL=13000
   ;;
+pair1)
+  R=$PWD/vc2-reference_amd/libvc2hip.so
+  run VC2HIP_LIB=$R VC2HIP_NO_PAIR=1
+  run VC2HIP_LIB=$R
+  run VC2HIP_LIB=$R VC2HIP_NO_PAIR=1
+  run VC2HIP_LIB=$R
+  ;;
+pair2)
+  run VC2HIP_LIB=$A VC2HIP_NO_PAIR=1
+  run VC2HIP_LIB=$A
+  run VC2HIP_LIB=$A VC2HIP_PAIR_WHOLE_SIMDS=0
+  run VC2HIP_LIB=$A VC2HIP_PAIR_OUT=56
+  run VC2HIP_LIB=$A VC2HIP_PAIR_OUT=56 VC2HIP_PAIR_WHOLE_SIMDS=0
+  run VC2HIP_LIB=$A VC2HIP_PAIR_NSEG=5
+  run VC2HIP_LIB=$A VC2HIP_PAIR_NSEG=6
+  run VC2HIP_LIB=$A VC2HIP_PAIR_NSEG=8
+  ;;
+pair3)
+  run VC2HIP_LIB=$A
+  for t in w3p1 w2p2 w2p1; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
+  run VC2HIP_LIB=$A
+  for t in w3p1 w2p2 w2p1; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
+  ;;
+pair4)
+  run VC2HIP_LIB=$A VC2HIP_PAIR_DEBUG=1
+  for k in 8 16 24 32 56; do run VC2HIP_LIB=$A VC2HIP_DEBUG_SKIP=$k; done
+  run VC2HIP_LIB=$A
+  ;;
+pair5)
+  run VC2HIP_LIB=$A VC2HIP_PAIR_DEBUG=1
+  run VC2HIP_LIB=$A VC2HIP_NO_PAIR=1
+  run VC2HIP_LIB=$A VC2HIP_PAIR_GROUP=1
+  run VC2HIP_LIB=$A VC2HIP_PAIR_GROUP=2
+  run VC2HIP_LIB=$A
+  ;;
+pair6)
+  for k in 0 64 128 192 256 448 16 8 24; do run VC2HIP_LIB=$A VC2HIP_DEBUG_SKIP=$k; done
+  ;;
 esac
 cat $O

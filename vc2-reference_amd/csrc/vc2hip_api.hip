@@ -30,6 +30,10 @@ void vc2_upload_tables_stream(const QuantTables &t, hipStream_t s);
 size_t vc2_stream_level_applicable(LevelParams &p, int kernel, bool edge, bool inverse, bool store16, int n_pictures);
 int vc2_launch_forward_stream(Launcher &L, int kernel, bool first, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s);
 int vc2_launch_inverse_stream(Launcher &L, int kernel, bool final_level, const LevelParams &p, int n, bool store16, size_t lds, hipStream_t s);
+size_t vc2_pair_applicable(PairParams &pp, int kernel, bool edge, bool inverse, bool store16, int n_pictures);
+int vc2_launch_forward_pair(Launcher &L, int kernel, bool first, const PairParams &pp, int n, bool store16, size_t lds, hipStream_t s);
+int vc2_launch_inverse_pair(Launcher &L, int kernel, bool final_level, const PairParams &pp, int n, bool store16, size_t lds, hipStream_t s);
+void vc2_upload_tables_pair(const QuantTables &t, hipStream_t s);
 int vc2_launch_plane_transform(Launcher &L, int kernel, int32_t *plane, long long plane_stride, int ph, int pw, int depth, bool inverse,
                                int n, hipStream_t s);
 void vc2_launch_plane_ingest(Launcher &L, const void *raw, long long raw_stride, int pic_h, int pic_w, int word_bytes, int bit_depth,
@@ -138,6 +142,7 @@ struct vc2hip_ctx {
   bool allow_heads = true;  // record heads for the levels below them (A/B and test switch VC2HIP_NO_HEADS)
   bool allow_cbr_index = true; // decode of HQ_CBR pictures: offsets from the budgets, verified (VC2HIP_NO_CBR_INDEX=1: always the general index)
   bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
+  bool allow_pair = true;     // VC2HIP_NO_PAIR=1: one launch per transform level (vc2hip_dwt_pair.hip off; tests, A/B)
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
   // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
   // sub-batches overlap: the tail of one launch is filled by the next stream's work.
@@ -305,6 +310,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
   { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_STREAM"); c->allow_stream = !(e && e[0] == '1'); }
+  { const char *e = getenv("VC2HIP_NO_PAIR"); c->allow_pair = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_BANDPLANES"); c->allow_planes = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_HEADS"); c->allow_heads = !(e && e[0] == '1'); }
   { const char *e = getenv("VC2HIP_NO_CBR_INDEX"); c->allow_cbr_index = !(e && e[0] == '1'); }
@@ -325,6 +331,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   vc2_upload_tables(t, c->stream);
   vc2_upload_tables_slices(t, c->stream);
   vc2_upload_tables_fast(t, c->stream);
+  vc2_upload_tables_pair(t, c->stream);
   vc2_upload_tables_stream(t, c->stream);
   vc2_upload_vlc_lut(c->stream);
   vc2_upload_unpack_lut(c->stream);
@@ -674,8 +681,7 @@ static void fill_level(LevelParams &p, const Geom &g, int level, int kernel, con
 static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const void *const src[3],
                        const long long src_stride[3], bool src_raw, const vc2hip_picture_format *f,
                        void *store, const LLPlanes &ll, bool s16 = false, int32_t *store_wide = nullptr) {
-  for (int level = 0; level < g.depth; ++level) {
-    LevelParams p;
+  auto level_params = [&](LevelParams &p, int level) {
     memset(&p, 0, sizeof p);
     fill_level(p, g, level, kernel, nullptr);
     p.store = store; p.store_stride = (long long)g.ys * g.xs * g.slice_coefs;
@@ -695,6 +701,26 @@ static int run_forward(vc2hip_ctx *c, const Geom &g, int kernel, int n, const vo
       const int cd = f->chroma_bit_depth ? f->chroma_bit_depth : f->bit_depth;
       p.sample_shift_c = 8 * f->word_bytes - cd;
       p.sample_offset_c = 1 << (cd - 1);
+    }
+  };
+  for (int level = 0; level < g.depth; ++level) {
+    LevelParams p;
+    level_params(p, level);
+    const bool first = (level == 0) && src_raw;
+    // two levels in one launch (vc2hip_dwt_pair.hip): level + 1's input plane is never written
+    if (!c->force_generic && c->allow_stream && c->allow_pair && level + 1 < g.depth) {
+      PairParams pp;
+      memset(&pp, 0, sizeof pp);
+      pp.a = p;
+      pp.a.debug_skip = c->debug_skip;
+      level_params(pp.b, level + 1);
+      const size_t lds = vc2_pair_applicable(pp, kernel, first, false, s16, n);
+      if (lds) {
+        int rc = vc2_launch_forward_pair(c->L, kernel, first, pp, n, s16, lds, c->stream);
+        if (rc) return set_err(c, rc, "invalid wavelet kernel");
+        ++level;
+        continue;
+      }
     }
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;
@@ -732,8 +758,7 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
                        unsigned *fast_mask = nullptr) {
   if (stream_mask) *stream_mask = 0;
   if (fast_mask) *fast_mask = 0;
-  for (int level = g.depth - 1; level >= 0; --level) {
-    LevelParams p;
+  auto level_params = [&](LevelParams &p, int level) {
     memset(&p, 0, sizeof p);
     fill_level(p, g, level, kernel, qm);
     if (hs && level >= head_level) // the deep levels' coefficients live in the record heads (HeadSplit)
@@ -745,7 +770,7 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
     p.ll_from_store = (level == g.depth - 1) && !ll_ready;
     const bool fin = (level == 0) && dst_raw;
     for (int k = 0; k < 3; ++k) {
-      if (level == 0) { p.plane[k] = dst[k]; p.plane_stride[k] = dst_stride[k]; }
+      if (level == 0) { p.plane[k] = dst ? dst[k] : nullptr; p.plane_stride[k] = dst_stride ? dst_stride[k] : 0; }
       else { p.plane[k] = ll.p[level][k]; p.plane_wide[k] = ll.w[level][k]; p.plane_stride[k] = ll.stride[level][k]; }
       p.ll[k] = ll.p[level + 1][k]; p.ll_wide[k] = ll.w[level + 1][k]; p.ll_stride[k] = ll.stride[level + 1][k];
     }
@@ -755,6 +780,27 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
       p.sample_offset = 1 << (f->bit_depth - 1);
       p.clip_lo = -(1 << (f->bit_depth - 1));
       p.clip_hi = (1 << (f->bit_depth - 1)) - 1;
+    }
+  };
+  for (int level = g.depth - 1; level >= 0; --level) {
+    LevelParams p;
+    level_params(p, level);
+    const bool fin = (level == 0) && dst_raw;
+    // levels `level` and `level - 1` in one launch (vc2hip_dwt_pair.hip): the plane between them is never written
+    if (!stream_mask && !c->force_generic && c->allow_stream && c->allow_pair && level >= 1) {
+      PairParams pp;
+      memset(&pp, 0, sizeof pp);
+      level_params(pp.a, level - 1);
+      pp.b = p;
+      pp.a.debug_skip = c->debug_skip;
+      const bool fin_a = (level - 1 == 0) && dst_raw;
+      const size_t lds = vc2_pair_applicable(pp, kernel, fin_a, true, s16, n);
+      if (lds) {
+        int rc = vc2_launch_inverse_pair(c->L, kernel, fin_a, pp, n, s16, lds, c->stream);
+        if (rc) return set_err(c, rc, "invalid wavelet kernel");
+        --level;
+        continue;
+      }
     }
     LevelParams pf = p;
     pf.debug_skip = c->debug_skip;

@@ -125,6 +125,20 @@ struct LevelParams {
   long long bp_base[3];
 };
 
+// Two consecutive levels in one launch (vc2hip_dwt_pair.hip): `a` is the finer level exactly as the one-level kernels see
+// it (its st_* fields describe the wavefronts: a lane holds 8 samples of level a's input plane), `b` the level below it
+// (fill_level of level + 1: the same lanes hold 4 samples of ITS input, which never leave the registers).
+struct PairParams {
+  LevelParams a, b;
+  int spl[3];        // slices per lane: 1, or 2 when a slice footprint at level a is 4 samples wide (then st_llps = 0)
+  int img_b;         // LDS images of level b: byte offset behind level a's (forward)
+  int grp_a;         // forward: slice rows per burst of stores = images of level a (a power of two); level b has grp_a + 1
+  int sz_a, sz_b;    // forward: elements of one image of level a / b
+  int ring_ll, n_ll; // forward: byte offset and rows (a power of two) of the ring of level b's LL rows
+  int ss_a[3], ss_b[3]; // forward: elements from one slice's run to the next in the LDS images (padded against bank conflicts)
+  int piece_a[3], piece_b[3]; // forward: bytes per flush piece (16, 8 or 4)
+};
+
 // Tuning knobs (lanes per slice, wavefronts per workgroup, segments per strip ...) are compile-time decisions of the
 // release library; the environment can override them only in the -DVC2HIP_ABLATE build (A/B measurements on one box).
 #include <stdlib.h>
