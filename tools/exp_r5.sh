@@ -55,5 +55,14 @@ pair5)
 pair6)
   for k in 0 64 128 192 256 448 16 8 24; do run VC2HIP_LIB=$A VC2HIP_DEBUG_SKIP=$k; done
   ;;
+v)
+  shift
+  for t in "$@"; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
+  for t in "$@"; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
+  ;;
+inv1)
+  L=$PWD/vc2-reference_amd/libvc2hip_exp_i2.so
+  for k in 0 8 16 64 80 128 256 464; do run VC2HIP_LIB=$L VC2HIP_DEBUG_SKIP=$k; done
+  ;;
 esac
 cat $O

@@ -794,7 +794,12 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
       pp.b = p;
       pp.a.debug_skip = c->debug_skip;
       const bool fin_a = (level - 1 == 0) && dst_raw;
-      const size_t lds = vc2_pair_applicable(pp, kernel, fin_a, true, s16, n);
+      // The pair that ends with the picture's samples keeps its two launches: measured on 32 UHD pictures, k_inv_pair over
+      // levels 1 + 0 takes 0.68 ms where the two one-level kernels take 0.47 + 0.16 -- level a alone runs at four
+      // wavefronts per SIMD and at the memory system's pace (0.455 ms in this kernel's frame), with level b's engine in its
+      // registers it runs at two and at the pace its instruction stream issues.  The deeper pairs gain.
+      static const int inv_final = vc2_tune_int("VC2HIP_PAIR_INV_FINAL", 0);
+      const size_t lds = (fin_a && !inv_final) ? 0 : vc2_pair_applicable(pp, kernel, fin_a, true, s16, n);
       if (lds) {
         int rc = vc2_launch_inverse_pair(c->L, kernel, fin_a, pp, n, s16, lds, c->stream);
         if (rc) return set_err(c, rc, "invalid wavelet kernel");

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
       int mx = v[0], mn = v[0];
 #pragma unroll
       for (int j = 1; j < 12; ++j) { mx = max(mx, v[j]); mn = min(mn, v[j]); }
-      if (mx > 32767 || mn < -32767) escapes(v, IC<3>(), IC<4>(), sv, run0A, bnA, r * bswA, cl * 4);
+      if (__builtin_expect(mx > 32767 || mn < -32767, 0)) escapes(v, IC<3>(), IC<4>(), sv, run0A, bnA, r * bswA, cl * 4);
     }
     ST *d = img + baseA + r * bswA;
 #pragma unroll
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
 #pragma unroll
       for (int j = 3; j < 8; ++j) { mx = max(mx, v[j]); mn = min(mn, v[j]); }
       if (b_last) { mx = max(mx, max(v[0], v[1])); mn = min(mn, min(v[0], v[1])); }
-      if (mx > 32767 || mn < -32767) {
+      if (__builtin_expect(mx > 32767 || mn < -32767, 0)) {
         if (b_last) escapes(v, IC<4>(), IC<2>(), sv, run0B, bnB, r * bswB, cl * 2);
         else escapes(v + 2, IC<3>(), IC<2>(), sv, run0B, bnB, r * bswB, cl * 2);
       }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
     wave_sync();
     due = false;
   };
-  auto deferred = [&]() __attribute__((always_inline)) { if (due) burst(); };
+  auto deferred = [&]() __attribute__((always_inline)) { if (__builtin_expect(due, 0)) burst(); }; // (cold: placed out of the walk's straight line)
   // the pair k1 of level b that engB has just completed at phase UB
   auto emitB = [&](auto UBc, int k1) __attribute__((always_inline)) {
     constexpr int UB = decltype(UBc)::value;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
         if (!b_last) { // the LL row into its ring (beyond 16 bits: the wide plane at once, the sentinel into the ring)
           int a0 = oe[0], a1 = oe[1];
           if constexpr (S_::narrow) {
-            if (own && (!S_::fits(a0) || !S_::fits(a1))) {
+            if (__builtin_expect(own && (!S_::fits(a0) || !S_::fits(a1)), 0)) {
               int32_t *w = llp_w + mul24z(k1, owB);
               if (!S_::fits(a0)) { w[0] = a0; a0 = VC2_ST_SENTINEL; }
               if (!S_::fits(a1)) { w[1] = a1; a1 = VC2_ST_SENTINEL; }
@@ -473,8 +473,17 @@ __device__ __forceinline__ int dequant_fullp(int v, int qf, int off) { // scale(
 // k1 = m / 2, is -- after the horizontal inverse lifting and the rounding -- the LL rows of level a's pairs m and m + 1.
 // Above the walk's first pair level b runs a prologue of its own (its filter run-in); in the last block of a walk that
 // ends with the plane, level b is already below ITS last pair.
-template <int K, bool FINAL, class ST>
-__global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
+#ifndef VC2_PAIR_WPE_INV
+#define VC2_PAIR_WPE_INV 2
+#endif
+#ifndef VC2_PAIR_PFI
+#define VC2_PAIR_PFI 2
+#endif
+constexpr int PFQ = VC2_PAIR_PFI; // row pairs of level a's bands prefetched ahead (inverse)
+// SPL2: some component's slices are 4 samples wide at level a (a lane spans two slices): its own instantiation, so that
+// the common one (every BASELINE configuration's two finest levels) carries none of that code
+template <int K, bool FINAL, class ST, bool SPL2>
+__global__ __launch_bounds__(64, (K == VC2HIP_DD137 || SPL2 ? 2 : VC2_PAIR_WPE_INV)) void k_inv_pair(const PairParams pp) {
   using S_ = St<ST>;
   using EA = VEng<K, true, 4>;
   using EB = VEng<K, true, 2>;
@@ -482,6 +491,11 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   constexpr int OFFL = T::OFFL, SD = T::sum_dmin();
   constexpr int ACC = WT<K>::accuracy;
   __shared__ int qtab[360]; // quant_factor / quant_offset / fast-path limit by adjusted index (as k_inv_stream)
+  __shared__ int rare[12 * 64]; // the rare paths' values, per lane (escapes of the 16-bit store; values beyond the dequantiser's fast domain)
+  // Level b's engine is used in every second iteration; between its steps its rows wait in LDS (VEng::park): its ~36
+  // registers are what separates this kernel from three wavefronts per SIMD
+  constexpr bool PARK = !SPL2 && VC2_PAIR_WPE_INV >= 3;
+  __shared__ __attribute__((aligned(16))) int parked[PARK ? VEng<K, true, 2>::park_rows() * 64 * 4 : 4];
 #define p pp.a
 #define pb pp.b
   const int lane = threadIdx.x & 63;
@@ -495,8 +509,13 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   }
   wave_sync();
   // (every member of the argument read once, here: see k_fwd_pair)
-  const int spl = pp.spl[comp];
+  const int spl = SPL2 ? pp.spl[comp] : 1;
   const int xs = p.xs, st_prio = p.st_prio, dequant = p.dequant;
+#ifdef VC2HIP_ABLATE // timing experiments (VC2HIP_DEBUG_SKIP): 8 level b not at all, 16 its values not unpacked / dequantised, 64 not loaded, 128 no vertical step, 256 no horizontal lifting
+  const int dskip = p.debug_skip;
+#else
+  constexpr int dskip = 0;
+#endif
   const int out_h = p.in_h[comp], out_w = p.in_w[comp], npA = out_h >> 1, npB = npA >> 1, owA = out_w >> 1, owB = out_w >> 2;
   const int chunk = min(sp.c0 + lane, (out_w >> 3) - 1);
   const bool own = lane >= sp.lo && lane < sp.hi;
@@ -513,12 +532,19 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   const ST *store = (const ST *)p.store + (size_t)pic * p.store_stride;
   const int32_t *wide = S_::narrow ? p.store_wide + (size_t)pic * p.store_stride : nullptr;
   const int32_t *qidx = p.qidx ? p.qidx + (size_t)pic * p.ys * xs : nullptr;
-  const ST *llp = nullptr;
+  // Addresses: a wave-uniform base (the picture's store, plane, output) plus a 32-bit byte offset per lane -- the memory
+  // instructions then take the base from scalar registers and one register of offset instead of a 64-bit pointer per lane
+  // (the host admits this kernel only where a picture's store and planes stay below 4 GiB)
+  const ST *llp = nullptr;     // level b's LL plane (this picture)
   const int32_t *llp_w = nullptr;
   if (!b_last) {
-    llp = (const ST *)pb.ll[comp] + (size_t)pic * pb.ll_stride[comp] + (size_t)chunk * 2;
-    if constexpr (S_::narrow) llp_w = pb.ll_wide[comp] + (size_t)pic * pb.ll_stride[comp] + (size_t)chunk * 2;
+    llp = (const ST *)pb.ll[comp] + (size_t)pic * pb.ll_stride[comp];
+    if constexpr (S_::narrow) llp_w = pb.ll_wide[comp] + (size_t)pic * pb.ll_stride[comp];
   }
+  auto ldq = [&](const void *base, unsigned elem, auto tag) __attribute__((always_inline)) {
+    using Q = decltype(tag);
+    return *(const Q *)((const char *)base + (size_t)(elem * (unsigned)sizeof(ST)));
+  };
   const int qmA = p.band, qmB = pb.band; // band index of HL at the level (quantisation matrix)
   const int qm0 = p.qmatrix[0];
   int qmxA[3], qmxB[3];
@@ -528,29 +554,30 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   // ---- input.  Element index (from the picture's store) of the lane's coefficients of band b (1..3; 0 = LL at the last
   // level) in band row m: in the level's band planes simply row m, the lane's columns; in the records / heads the block
   // row of the lane's slice (the second half of the lane's columns is the NEXT slice's when spl == 2)
-  auto atA = [&](int m, int b) __attribute__((always_inline)) -> size_t {
-    if (bpA >= 0) return (size_t)bpA + (size_t)mul24z((b - 1) * npA + m, owA) + (size_t)chunk * 4;
+  const unsigned bpA32 = (unsigned)bpA + (unsigned)chunk * 4, bpB32 = (unsigned)bpB + (unsigned)chunk * 2;
+  auto atA = [&](int m, int b) __attribute__((always_inline)) -> unsigned {
+    if (bpA >= 0) return bpA32 + __umul24((unsigned)((b - 1) * npA + m), (unsigned)owA);
     const int sv = m >> lbshA, r = m & (bshA - 1);
-    return mul24z(sv * xs + sx, rsA) + run0A + (b - 1) * bnA + r * bswA;
+    return __umul24((unsigned)(sv * xs + sx), (unsigned)rsA) + (unsigned)(run0A + (b - 1) * bnA + r * bswA);
   };
-  auto atB = [&](int m1, int b) __attribute__((always_inline)) -> size_t {
-    if (bpB >= 0 && b > 0) return (size_t)bpB + (size_t)mul24z((b - 1) * npB + m1, owB) + (size_t)chunk * 2;
+  auto atB = [&](int m1, int b) __attribute__((always_inline)) -> unsigned {
+    if (bpB >= 0 && b > 0) return bpB32 + __umul24((unsigned)((b - 1) * npB + m1), (unsigned)owB);
     const int sv = m1 >> lbshB, r = m1 & (bshB - 1);
-    return mul24z(sv * xs + sx, rsB) + run0B + (b - (b_last ? 0 : 1)) * bnB + r * bswB;
+    return __umul24((unsigned)(sv * xs + sx), (unsigned)rsB) + (unsigned)(run0B + (b - (b_last ? 0 : 1)) * bnB + r * bswB);
   };
   typedef typename std::conditional<S_::narrow, uint2, uint4>::type Q4;    // four store elements
   typedef typename std::conditional<S_::narrow, unsigned, uint2>::type Q2; // two
   typedef typename std::conditional<S_::narrow, unsigned short, unsigned>::type Q1;
-  Q4 bqA[PFI][3];
+  Q4 bqA[PFQ][3];
   Q2 bqB[4]; // [0] = LL
   const bool splitA = spl == 2 && bpA < 0, splitB = spl == 2 && bpB < 0; // the lane's columns lie in two slices' records
   auto fetchA = [&](int m, int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 1; b < 4; ++b) {
-      const ST *q = store + atA(m, b);
-      if (!splitA) bqA[slot][b - 1] = *(const Q4 *)q;
+      const unsigned q = atA(m, b);
+      if (!splitA) bqA[slot][b - 1] = ldq(store, q, Q4());
       else {
-        const Q2 lo = *(const Q2 *)q, hi = *(const Q2 *)(q + rsA);
+        const Q2 lo = ldq(store, q, Q2()), hi = ldq(store, q + (unsigned)rsA, Q2());
         if constexpr (S_::narrow) bqA[slot][b - 1] = make_uint2(lo, hi);
         else bqA[slot][b - 1] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
@@ -559,12 +586,12 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   auto fetchB = [&](int m1) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (b == 0 && !b_last) { bqB[0] = *(const Q2 *)(llp + mul24z(m1, owB)); continue; }
-      const ST *q = store + atB(m1, b);
+      if (b == 0 && !b_last) { bqB[0] = ldq(llp, __umul24((unsigned)m1, (unsigned)owB) + (unsigned)chunk * 2, Q2()); continue; }
+      const unsigned q = atB(m1, b);
       const bool split = b == 0 ? spl == 2 : splitB;
-      if (!split) bqB[b] = *(const Q2 *)q;
+      if (!split) bqB[b] = ldq(store, q, Q2());
       else {
-        const Q1 lo = *(const Q1 *)q, hi = *(const Q1 *)(q + rsB);
+        const Q1 lo = ldq(store, q, Q1()), hi = ldq(store, q + (unsigned)rsB, Q1());
         if constexpr (S_::narrow) bqB[b] = (unsigned)lo | ((unsigned)hi << 16);
         else bqB[b] = make_uint2(lo, hi);
       }
@@ -573,7 +600,17 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   // quantiser constants of the lane's slice(s) in a slice row: level a keeps factor / offset / fast-path limit of its three
   // bands in registers (one slice per lane); everything else -- level b, and lanes that span two slices -- looks them up
   // in the LDS table by adjusted index at each use
-  int qfA[3], qoA[3], qlA[3];
+  constexpr int NS = SPL2 ? 2 : 1; // sets of constants: the lane's first / second slice (equal where the lane lies in one slice)
+  // Where they live: in the common instantiation in LDS, a row of 28 dwords per lane (level a: factors, offsets, limits of
+  // its three bands as three 16-byte reads per iteration; level b: of LL + three bands, read per pair) -- the 21 registers
+  // they would take are what separates this kernel from three wavefronts per SIMD, and its time is its instruction stream
+  // at the rate its wavefronts issue.  (28: the lanes' rows then start in different banks.)
+  constexpr bool QL = false; // (measured: the constants' registers are not where the pressure peaks -- 190 registers either way)
+  constexpr int QROW = 28;
+  __shared__ __attribute__((aligned(16))) int qrow[QL ? QROW * 64 : 4];
+  int *const qmine = qrow + (QL ? lane * QROW : 0);
+  int qfA[NS][3], qoA[NS][3], qlA[NS][3];
+  int qfB[NS][4], qoB[NS][4], qlB[NS][4]; // level b: [0] = LL (the last level), then HL, LH, HH
   int qsA[2] = {0, 0}, qsB[2] = {0, 0}; // quantiser index of the lane's first / second slice in level a's / b's current slice row
   int svA_have = -1, svB_have = -1;
   auto check_q = [&](int q, int qm) __attribute__((always_inline)) { if (dequant && q - qm > 119) atomicOr(p.err, VC2_DEVERR_QINDEX); };
@@ -583,23 +620,80 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       check_q(max(qsA[0], qsA[1]), qmxA[b]);
-      const int aq = min(max(qsA[0] - qmxA[b], 0), 119);
-      qfA[b] = qtab[aq]; qoA[b] = qtab[120 + aq]; qlA[b] = qtab[240 + aq];
+#pragma unroll
+      for (int h = 0; h < NS; ++h) {
+        const int aq = min(max(qsA[h] - qmxA[b], 0), 119);
+        if constexpr (QL) { qmine[b] = qtab[aq]; qmine[4 + b] = qtab[120 + aq]; qmine[8 + b] = qtab[240 + aq]; }
+        else { qfA[h][b] = qtab[aq]; qoA[h][b] = qtab[120 + aq]; qlA[h][b] = qtab[240 + aq]; }
+      }
+    }
+  };
+  auto fetch_qA = [&]() __attribute__((always_inline)) { // (QL) this iteration's copy of level a's constants
+    if constexpr (QL) {
+      const int4 f = *(const int4 *)qmine, o = *(const int4 *)(qmine + 4), l = *(const int4 *)(qmine + 8);
+      qfA[0][0] = f.x; qfA[0][1] = f.y; qfA[0][2] = f.z; qoA[0][0] = o.x; qoA[0][1] = o.y; qoA[0][2] = o.z;
+      qlA[0][0] = l.x; qlA[0][1] = l.y; qlA[0][2] = l.z;
+    }
+  };
+  auto fetch_qB = [&]() __attribute__((always_inline)) {
+    if constexpr (QL) {
+      const int4 f = *(const int4 *)(qmine + 12), o = *(const int4 *)(qmine + 16), l = *(const int4 *)(qmine + 20);
+      qfB[0][0] = f.x; qfB[0][1] = f.y; qfB[0][2] = f.z; qfB[0][3] = f.w; qoB[0][0] = o.x; qoB[0][1] = o.y; qoB[0][2] = o.z; qoB[0][3] = o.w;
+      qlB[0][0] = l.x; qlB[0][1] = l.y; qlB[0][2] = l.z; qlB[0][3] = l.w;
     }
   };
   auto load_qB = [&](int sv) __attribute__((always_inline)) {
     qsB[0] = dequant ? qidx[sv * xs + sx] : 0;
     qsB[1] = dequant && spl == 2 ? qidx[sv * xs + sx + 1] : qsB[0];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) check_q(max(qsB[0], qsB[1]), qmxB[b]);
-    if (b_last) check_q(max(qsB[0], qsB[1]), qm0);
+    for (int b = 0; b < 4; ++b) {
+      const int qm = b == 0 ? qm0 : qmxB[b - 1];
+      if (b > 0 || b_last) check_q(max(qsB[0], qsB[1]), qm);
+#pragma unroll
+      for (int h = 0; h < NS; ++h) {
+        const int aq = min(max(qsB[h] - qm, 0), 119);
+        if constexpr (QL) { qmine[12 + b] = qtab[aq]; qmine[16 + b] = qtab[120 + aq]; qmine[20 + b] = qtab[240 + aq]; }
+        else { qfB[h][b] = qtab[aq]; qoB[h][b] = qtab[120 + aq]; qlB[h][b] = qtab[240 + aq]; }
+      }
+    }
   };
-  auto deq_lds = [&](int v, int q, int qm) __attribute__((always_inline)) -> int {
-    const int aq = min(max(q - qm, 0), 119);
-    return dequant_fullp(v, qtab[aq], qtab[120 + aq]);
+  // The lane's values of one load.  Hot path: unpack, ONE test for escapes of the 16-bit store (the sentinel is the smallest
+  // 16-bit value) and for the dequantiser's fast domain, five instructions per value.  Everything else -- an escape (its value
+  // is in the wide array at the element's own index), a value beyond the fast domain, lanes that span two slices -- takes the
+  // rare path: the values go through an LDS row per lane and a ROLLED loop with scale() literally (the unrolled form of these
+  // paths was two thirds of the kernel's code, and the walk's unrolled block no longer fitted the instruction cache).
+  auto rare_path = [&](int *v, auto NVc, auto atf, int m, const int *qs, int band0) __attribute__((always_inline)) {
+    constexpr int NV = decltype(NVc)::value, N = 3 * NV + (NV == 2 ? 2 : 0); // values per band; values in all
+#pragma unroll
+    for (int k = 0; k < N; ++k) rare[k * 64 + lane] = v[k];
+    wave_sync();
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+      const int b = NV == 2 ? k / 2 : k / 4 + 1, j = k % NV; // band (0 = level b's LL), value inside the lane's load
+      int x = rare[k * 64 + lane];
+      if (NV == 2 && b == 0 && !b_last) { // level b's LL from its plane
+        if constexpr (S_::narrow) if (x == VC2_ST_SENTINEL) x = llp_w[mul24z(m, owB) + (size_t)chunk * 2 + j];
+      } else {
+        const bool split = NV == 2 ? (b == 0 ? spl == 2 : splitB) : splitA; // the lane's second half in the next slice's record
+        if constexpr (S_::narrow) if (x == VC2_ST_SENTINEL) {
+          const int32_t *wq = wide + atf(m, b);
+          x = split && j >= NV / 2 ? wq[(NV == 2 ? rsB : rsA) + j - NV / 2] : wq[j];
+        }
+        if (dequant) {
+          const int qm = b == 0 ? qm0 : p.qmatrix[band0 + b - 1];
+          const int aq = min(max(qs[spl == 2 ? j / (NV / 2) : 0] - qm, 0), 119);
+          x = dequant_fullp(x, qtab[aq], qtab[120 + aq]);
+        }
+      }
+      rare[k * 64 + lane] = x;
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = rare[k * 64 + lane];
   };
-  // the lane's values of one load: sentinel test (escapes of the 16-bit store: the wide array at the element's own index)
   auto unpackA = [&](int m, int slot, int (&v)[12]) __attribute__((always_inline)) {
+    bool hot = true;
+    if (dequant) fetch_qA();
     if constexpr (S_::narrow) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
@@ -609,14 +703,7 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
       int lowest = v[0];
 #pragma unroll
       for (int k = 1; k < 12; ++k) lowest = min(lowest, v[k]);
-      if (lowest == VC2_ST_SENTINEL) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const int32_t *wq = wide + atA(m, b + 1);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (v[4 * b + k] == VC2_ST_SENTINEL) v[4 * b + k] = (splitA && k >= 2 ? wq + rsA - 2 : wq)[k];
-        }
-      }
+      hot = lowest != VC2_ST_SENTINEL;
     } else {
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
@@ -625,72 +712,72 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
       }
     }
     if (dequant) {
-      if (spl == 1) {
-        bool fast = true;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const int mx = max(max(v[4 * b], v[4 * b + 1]), max(v[4 * b + 2], v[4 * b + 3]));
-          const int mn = min(min(v[4 * b], v[4 * b + 1]), min(v[4 * b + 2], v[4 * b + 3]));
-          fast &= mx <= qlA[b] && mn >= -qlA[b];
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { // (the lane's first / second pair of columns: one slice's limit each when it spans two)
+          const int mx = max(v[4 * b + 2 * h], v[4 * b + 2 * h + 1]), mn = min(v[4 * b + 2 * h], v[4 * b + 2 * h + 1]);
+          hot &= mx <= qlA[h % NS][b] && mn >= -qlA[h % NS][b];
         }
-        if (fast) {
-#pragma unroll
-          for (int k = 0; k < 12; ++k) {
-            const int x = v[k], sg = min(max(x, -1), 1);
-            const unsigned t = (__umul24((unsigned)__mul24(x, sg), (unsigned)qfA[k >> 2]) + (unsigned)(qoA[k >> 2] + 2)) >> 2;
-            v[k] = __mul24((int)t, sg);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 12; ++k) v[k] = dequant_fullp(v[k], qfA[k >> 2], qoA[k >> 2]);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = deq_lds(v[k], qsA[(k >> 1) & 1], qmxA[k >> 2]);
-      }
     }
+    if (__builtin_expect(hot, 1)) {
+      if (dequant) { // scale(), Quantisation.cpp:86-95, inside its domain: sign(v) * ((|v| * factor + offset + 2) >> 2)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          const int x = v[k], sg = min(max(x, -1), 1);
+          const unsigned t = (__umul24((unsigned)__mul24(x, sg), (unsigned)qfA[((k >> 1) & 1) % NS][k >> 2]) + (unsigned)(qoA[((k >> 1) & 1) % NS][k >> 2] + 2)) >> 2;
+          v[k] = __mul24((int)t, sg);
+        }
+      }
+    } else rare_path(v, IC<4>(), atA, m, qsA, qmA);
   };
   auto unpackB = [&](int m1, int (&v)[8]) __attribute__((always_inline)) { // [0..1] LL, then HL, LH, HH
+    bool hot = true;
+    if (dequant) fetch_qB();
     if constexpr (S_::narrow) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) { v[2 * b] = vc2_lo16(bqB[b]); v[2 * b + 1] = vc2_hi16(bqB[b]); }
       int lowest = v[0];
 #pragma unroll
       for (int k = 1; k < 8; ++k) lowest = min(lowest, v[k]);
-      if (lowest == VC2_ST_SENTINEL) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const bool plane = b == 0 && !b_last;
-          const int32_t *wq = plane ? llp_w + mul24z(m1, owB) : wide + atB(m1, b);
-          const bool split = plane ? false : (b == 0 ? spl == 2 : splitB);
-          if (v[2 * b] == VC2_ST_SENTINEL) v[2 * b] = wq[0];
-          if (v[2 * b + 1] == VC2_ST_SENTINEL) v[2 * b + 1] = split ? wq[rsB] : wq[1];
-        }
-      }
+      hot = lowest != VC2_ST_SENTINEL;
     } else {
 #pragma unroll
       for (int b = 0; b < 4; ++b) { v[2 * b] = (int)bqB[b].x; v[2 * b + 1] = (int)bqB[b].y; }
     }
     if (dequant) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k < 2 && !b_last) continue;
-        v[k] = deq_lds(v[k], qsB[k & 1], k < 2 ? qm0 : qmxB[(k >> 1) - 1]);
+      for (int b = 0; b < 4; ++b) {
+        if (b == 0 && !b_last) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) hot &= v[2 * b + h] <= qlB[h % NS][b] && v[2 * b + h] >= -qlB[h % NS][b];
       }
     }
+    if (__builtin_expect(hot, 1)) {
+      if (dequant) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (k < 2 && !b_last) continue;
+          const int x = v[k], sg = min(max(x, -1), 1);
+          const unsigned t = (__umul24((unsigned)__mul24(x, sg), (unsigned)qfB[(k & 1) % NS][k >> 1]) + (unsigned)(qoB[(k & 1) % NS][k >> 1] + 2)) >> 2;
+          v[k] = __mul24((int)t, sg);
+        }
+      }
+    } else rare_path(v, IC<2>(), atB, m1, qsB, qmB);
   };
 
   // ---- output rows of level a (as k_inv_stream)
   const int lim_h = FINAL ? p.pic_h[comp] : out_h;
   const int clip_lo = p.clip_lo, clip_hi = p.clip_hi, sample_offset = p.sample_offset, sample_shift = p.sample_shift;
-  uint8_t *rawo = nullptr;
+  uint8_t *rawo = nullptr; // (this picture's output plane; the lane's columns are part of the offset)
   ST *lvl = nullptr;
   int32_t *lvl_w = nullptr;
-  if constexpr (FINAL) rawo = (uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 16;
+  if constexpr (FINAL) rawo = (uint8_t *)p.plane[comp] + (size_t)pic * p.plane_stride[comp];
   else {
-    lvl = (ST *)p.plane[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 8;
-    if constexpr (S_::narrow) lvl_w = p.plane_wide[comp] + (size_t)pic * p.plane_stride[comp] + (size_t)chunk * 8;
+    lvl = (ST *)p.plane[comp] + (size_t)pic * p.plane_stride[comp];
+    if constexpr (S_::narrow) lvl_w = p.plane_wide[comp] + (size_t)pic * p.plane_stride[comp];
   }
+  const unsigned ocol = (unsigned)chunk * 8; // first output column of the lane
   constexpr int OW = (FINAL || S_::narrow) ? 4 : 8;
   struct Pend { unsigned w[OW]; };
   auto make_out = [&](int y, RowT<4> &r, Pend &o) __attribute__((always_inline)) {
@@ -713,9 +800,9 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
     } else if constexpr (S_::narrow) {
       const int mx = max(max(max(s[0], s[1]), max(s[2], s[3])), max(max(s[4], s[5]), max(s[6], s[7])));
       const int mn = min(min(min(s[0], s[1]), min(s[2], s[3])), min(min(s[4], s[5]), min(s[6], s[7])));
-      if ((mx > 32767 || mn < -32767) && own && y < lim_h) {
+      if (__builtin_expect((mx > 32767 || mn < -32767) && own && y < lim_h, 0)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (!S_::fits(s[k])) { lvl_w[mul24z(y, out_w) + k] = s[k]; s[k] = VC2_ST_SENTINEL; }
+        for (int k = 0; k < 8; ++k) if (!S_::fits(s[k])) { lvl_w[mul24z(y, out_w) + ocol + k] = s[k]; s[k] = VC2_ST_SENTINEL; }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) o.w[k] = vc2_pack16(s[2 * k], s[2 * k + 1]);
@@ -726,11 +813,12 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   };
   auto put_out = [&](int y, const Pend &o) __attribute__((always_inline)) {
     if (!own || y >= lim_h) return;
-    if constexpr (FINAL) *(uint4 *)(rawo + mul24z(y, out_w) * 2) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
-    else if constexpr (S_::narrow) *(uint4 *)(lvl + mul24z(y, out_w)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    const unsigned e = __umul24((unsigned)y, (unsigned)out_w) + ocol; // element (sample) index inside the plane
+    if constexpr (FINAL) *(uint4 *)(rawo + (size_t)(e * 2u)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    else if constexpr (S_::narrow) *(uint4 *)((char *)lvl + (size_t)(e * 2u)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
     else {
-      *(uint4 *)(lvl + mul24z(y, out_w)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
-      *(uint4 *)(lvl + mul24z(y, out_w) + 4) = make_uint4(o.w[OW - 4], o.w[OW - 3], o.w[OW - 2], o.w[OW - 1]);
+      *(uint4 *)((char *)lvl + (size_t)(e * 4u)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+      *(uint4 *)((char *)lvl + (size_t)(e * 4u + 16u)) = make_uint4(o.w[OW - 4], o.w[OW - 3], o.w[OW - 2], o.w[OW - 1]);
     }
   };
 
@@ -739,6 +827,10 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
   EB engB;
   engA.clear();
   engB.clear();
+  if constexpr (PARK) {
+#pragma unroll
+    for (int r = 0; r < EB::park_rows(); ++r) *(int4 *)(parked + (r * 64 + lane) * 4) = make_int4(0, 0, 0, 0);
+  }
   const int kA = sp.kA, kB = sp.kB;
   const int wantA = kA + SD;                       // first pair of level a the segment's rows depend on ...
   const int wantB = (wantA >> 1) + SD;             // ... and of level b (its completed pair wantA / 2 gives level a's LL rows)
@@ -761,20 +853,24 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
     RowT<2> re1, ro1;
     if constexpr (MODE != 2) {
       const int ml = min(max(m1, 0), mloadB), sv = ml >> lbshB;
-      if (sv != svB_have) { load_qB(sv); svB_have = sv; }
-      int v[8];
-      unpackB(ml, v);
+      if (__builtin_expect(sv != svB_have, 0)) { load_qB(sv); svB_have = sv; }
+      int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (!(dskip & 16)) unpackB(ml, v);
       re1[0] = v[0]; re1[1] = v[1]; re1[2] = v[2]; re1[3] = v[3];
       ro1[0] = v[4]; ro1[1] = v[5]; ro1[2] = v[6]; ro1[3] = v[7];
-      if (prefetch) fetchB(min(max(m1 + 1, 0), mloadB));
+      if (prefetch && !(dskip & 64)) fetchB(min(max(m1 + 1, 0), mloadB));
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { re1[j] = 0; ro1[j] = 0; }
     }
-    engB.template step<UB, MODE, D>(m1, npB, re1, ro1);
+    if constexpr (PARK) engB.template unpark<((UB + 3) & 3)>(parked, lane);
+    if (!(dskip & 128)) engB.template step<UB, MODE, D>(m1, npB, re1, ro1);
     RowT<2> oe = engB.template out<UB>(false), oo = engB.template out<UB>(true);
-    h_lift<K, true, 2>(oe, redge);
-    h_lift<K, true, 2>(oo, redge);
+    if constexpr (PARK) engB.template park<UB>(parked, lane);
+    if (!(dskip & 256)) {
+      h_lift<K, true, 2>(oe, redge);
+      h_lift<K, true, 2>(oo, redge);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int a = oe[j], b = oe[2 + j], c = oo[j], d = oo[2 + j];
@@ -796,7 +892,12 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
         constexpr int J = U0 / 2, UB = (J + OFFL) & 3;
         constexpr int DB = J + OFFL - 4; // (last block) pairs below level b's last
         constexpr int MODEB = (BM == 1 && J + OFFL < 4) ? 1 : (BM == 3 && DB >= 0) ? 2 : 0;
-        stepB(IC<UB>(), IC<MODEB>(), IC<(MODEB == 2 ? DB : UB)>(), (mb >> 1) + J + OFFL, true, ll);
+#ifdef VC2_PAIR_NO_B // (timing experiment: level a alone in this kernel's frame)
+        ll[0] = ll[1] = ll[2] = ll[3] = 0;
+#else
+        if (!(dskip & 8)) stepB(IC<UB>(), IC<MODEB>(), IC<(MODEB == 2 ? DB : UB)>(), (mb >> 1) + J + OFFL, true, ll);
+        else { ll[0] = ll[1] = ll[2] = ll[3] = 0; }
+#endif
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) ll[j] = llO[j];
@@ -804,14 +905,14 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
       RowT<4> re, ro;
       if constexpr (!DRAIN) {
         const int ml = min(m, mloadA), sv = ml >> lbshA;
-        if (sv != svA_have) { load_qA(sv); svA_have = sv; }
+        if (__builtin_expect(sv != svA_have, 0)) { load_qA(sv); svA_have = sv; }
         int v[12];
-        unpackA(ml, U0 % PFI, v);
+        unpackA(ml, U0 % PFQ, v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { re[j] = ll[j]; re[4 + j] = v[j]; ro[j] = v[4 + j]; ro[4 + j] = v[8 + j]; }
       }
       if (pend_k >= 0) { put_out(2 * pend_k, pe); put_out(2 * pend_k + 1, po); }
-      if constexpr (!DRAIN) fetchA(min(m + PFI, mloadA), U0 % PFI);
+      if constexpr (!DRAIN) fetchA(min(m + PFQ, mloadA), U0 % PFQ);
       engA.template step<UA, MODEA, (DRAIN ? U0 : UA)>(m, npA, re, ro);
       const int k = m - OFFL;
       if (k >= kA && k < kB) {
@@ -850,8 +951,8 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
     fetchB(min((m0 >> 1) + OFFL, mloadB));
   }
 #pragma unroll
-  for (int u = 0; u < PFI; ++u) fetchA(min(m0 + u, mloadA), u);
-  static_assert(8 % PFI == 0, "the prefetch ring shares the unrolled walk");
+  for (int u = 0; u < PFQ; ++u) fetchA(min(m0 + u, mloadA), u);
+  static_assert(8 % PFQ == 0, "the prefetch ring shares the unrolled walk");
   if (top) {
     block(IC<1>(), BC<false>());
     mb += 8;
@@ -876,14 +977,21 @@ __global__ __launch_bounds__(64, 2) void k_inv_pair(const PairParams pp) {
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-template <int K, bool EDGE, bool INV, class ST> const void *pair_fn() {
-  if constexpr (!pair_kernel<K>()) return nullptr;
-  else if constexpr (INV) return (const void *)k_inv_pair<K, EDGE, ST>;
+#ifdef VC2_PAIR_ONLY_INV // (quick compiles)
+#define VC2_PAIR_HAS(INV) (INV)
+#elif defined(VC2_PAIR_ONLY_FWD)
+#define VC2_PAIR_HAS(INV) (!(INV))
+#else
+#define VC2_PAIR_HAS(INV) true
+#endif
+template <int K, bool EDGE, bool INV, class ST> const void *pair_fn(bool SPL2) {
+  if constexpr (!pair_kernel<K>() || !VC2_PAIR_HAS(INV)) return nullptr;
+  else if constexpr (INV) return SPL2 ? (const void *)k_inv_pair<K, EDGE, ST, true> : (const void *)k_inv_pair<K, EDGE, ST, false>;
   else return (const void *)k_fwd_pair<K, EDGE, ST>;
 }
 template <int K, bool EDGE, bool INV, class ST>
 int launch_pair(Launcher &L, const PairParams &pp, int n_pictures, size_t lds, hipStream_t s) {
-  if constexpr (!pair_kernel<K>()) return VC2HIP_EINVAL;
+  if constexpr (!pair_kernel<K>() || !VC2_PAIR_HAS(INV)) return VC2HIP_EINVAL;
   else {
     const LevelParams &p = pp.a;
     const int cols = (p.st_strips[0] + p.st_strips[1] + p.st_strips[2]) * n_pictures;
@@ -891,7 +999,8 @@ int launch_pair(Launcher &L, const PairParams &pp, int n_pictures, size_t lds, h
     dim3 grid(gx), block(64);
     if constexpr (INV) {
       vc2_prof_begin(L, EDGE ? "idwt_pair_final" : "idwt_pair", s);
-      VC2_LAUNCH(L, (k_inv_pair<K, EDGE, ST>), grid, block, 0, s, pp);
+      if (pp.spl[0] == 2 || pp.spl[1] == 2 || pp.spl[2] == 2) VC2_LAUNCH(L, (k_inv_pair<K, EDGE, ST, true>), grid, block, 0, s, pp);
+      else VC2_LAUNCH(L, (k_inv_pair<K, EDGE, ST, false>), grid, block, 0, s, pp);
     } else {
       vc2_prof_begin(L, EDGE ? "dwt_pair_first" : "dwt_pair", s);
       vc2_allow_lds((const void *)k_fwd_pair<K, EDGE, ST>, std::max<size_t>(64 * 1024, lds));
@@ -904,7 +1013,7 @@ int launch_pair(Launcher &L, const PairParams &pp, int n_pictures, size_t lds, h
 template <int K, bool EDGE, bool INV, class ST> int pair_slots_of(size_t lds) {
   int nb = 0, dev = 0;
   hipDeviceProp_t prop;
-  const void *fn = pair_fn<K, EDGE, INV, ST>();
+  const void *fn = pair_fn<K, EDGE, INV, ST>(false); // (both forms of the inverse kernel take the same registers)
   if (!fn) return 0;
   if (!INV) vc2_allow_lds(fn, std::max<size_t>(64 * 1024, lds));
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||

@@ -209,6 +209,37 @@ template <int K, bool INV, int NP = 4> struct VEng {
     else { put<U>(rw[0], re, MODE == 1 && U == 0); put<U>(rw[1], ro, MODE == 1 && U == 0); }
     pos<U, 0, MODE, D>(m, np);
   }
+  // Parking (vc2hip_dwt_pair.hip, level b of the inverse kernel): between two steps only the rows inside the sequences'
+  // windows are alive -- len_raw / len_x rows back from each sequence's newest.  park<U>() after the step of phase U
+  // writes exactly those slots to an LDS area of park_rows() rows (row r of lane l at (r * 64 + l) * 2 NP dwords),
+  // unpark<U>() before the next step reads them back: in between the engine holds no register.
+  static constexpr int park_rows() { int n = T::len_raw(false) + T::len_raw(true); for (int p = 0; p < T::N; ++p) n += T::len_x(p); return n; }
+  template <int U, bool STORE> __device__ __forceinline__ void park_io(int *area, int lane) {
+    int r = 0;
+    auto io = [&](Row &row) __attribute__((always_inline)) {
+      int *q = area + (r * 64 + lane) * 2 * NP;
+      ++r;
+      static_assert(NP == 2 || NP == 4, "16- or 32-byte rows");
+      if constexpr (STORE) {
+        *(int4 *)q = make_int4(row.v[0], row.v[1], row.v[2], row.v[3]);
+        if constexpr (NP == 4) *(int4 *)(q + 4) = make_int4(row.v[4], row.v[5], row.v[6], row.v[7]);
+      } else {
+        const int4 a = *(const int4 *)q;
+        row.v[0] = a.x; row.v[1] = a.y; row.v[2] = a.z; row.v[3] = a.w;
+        if constexpr (NP == 4) { const int4 b = *(const int4 *)(q + 4); row.v[4] = b.x; row.v[5] = b.y; row.v[6] = b.z; row.v[7] = b.w; }
+      }
+    };
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) if (j < T::len_raw(par == 1)) io(rw[par][sl(U - j)]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) if (p < T::N && j < T::len_x(p < T::N ? p : 0)) io(x[p][sl(U - T::off(p < T::N ? p : 0) - j)]);
+  }
+  template <int U> __device__ __forceinline__ void park(int *area, int lane) { park_io<U, true>(area, lane); }
+  template <int U> __device__ __forceinline__ void unpark(int *area, int lane) { park_io<U, false>(area, lane); }
   // the completed pair m - OFFL: its even / odd row in the latest version
   template <int U> __device__ __forceinline__ const Row &out(bool odd_row) const {
     constexpr int N = T::N, s = sl(U - T::OFFL);
