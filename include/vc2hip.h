@@ -21,6 +21,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* libvc2hip.so is built with hidden visibility: the declarations below are its whole export list */
+#endif
 
 typedef struct vc2hip_ctx vc2hip_ctx; /* one per GPU: stream, device scratch, error state */
 
@@ -52,6 +55,19 @@ enum {
  * context
  * ------------------------------------------------------------------------------------------- */
 int vc2hip_create(int device, vc2hip_ctx **out);
+/* The same with switches that select, for tests and A/B measurements, between two correct paths of the library (each
+ * flag takes the slower / more general one; 0 = vc2hip_create).  The release library reads no environment variable. */
+#define VC2HIP_FLAG_STORE32         0x001u /* int32 coefficient elements instead of 16-bit + escape */
+#define VC2HIP_FLAG_NO_STREAM       0x002u /* LDS tile kernels instead of the streaming transform kernels */
+#define VC2HIP_FLAG_NO_PAIR         0x004u /* one launch per transform level (no two-level kernels) */
+#define VC2HIP_FLAG_NO_BANDPLANES   0x008u /* the decoder keeps every band in the slice records */
+#define VC2HIP_FLAG_NO_HEADS        0x010u /* no side-by-side record heads for the deep levels */
+#define VC2HIP_FLAG_NO_CBR_INDEX    0x020u /* HQ_CBR decode always through the general slice index */
+#define VC2HIP_FLAG_GENERIC_DWT     0x040u /* generic transform kernels only */
+#define VC2HIP_FLAG_SINGLE_PASS_VBR 0x080u /* VBR packing with decoupled look-back instead of slots + scan + compaction */
+#define VC2HIP_FLAG_CBR_GENERAL     0x100u /* HQ_CBR quantiser search without the register kernels */
+#define VC2HIP_FLAG_LD_DIAGONALS    0x200u /* LD index search: one launch per slice anti-diagonal instead of one launch */
+int vc2hip_create_with_flags(int device, unsigned flags, vc2hip_ctx **out);
 /* same, but launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int vc2hip_create_on_stream(int device, void *hip_stream, vc2hip_ctx **out);
 void vc2hip_destroy(vc2hip_ctx *ctx);
@@ -238,6 +254,9 @@ int vc2hip_profile_count(vc2hip_ctx *ctx);
 int vc2hip_profile_get(vc2hip_ctx *ctx, int i, const char **name, int *launches, double *total_ms);
 int vc2hip_profile_reset(vc2hip_ctx *ctx);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

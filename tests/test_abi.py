@@ -32,6 +32,34 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/vc2hip.h but not exported"
 
 
+def test_nothing_but_the_header_is_exported(lib):
+    """the library is built with hidden visibility; `nm -D` must list the functions of
+    include/vc2hip.h as its only defined text symbols (round 4 exported 73 internal C++ launchers beside them)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    text = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TtWw")
+    assert text == sorted(_declared()), sorted(set(text) ^ set(_declared()))
+
+
+def test_release_library_reads_no_environment():
+    """the switches between two correct paths are vc2hip_create_with_flags bits; getenv appears in the
+    library's sources only inside -DVC2HIP_ABLATE / -DVC2HIP_STAMPS blocks (tools builds)."""
+    import glob
+    import re
+    for f in sorted(glob.glob(os.path.join(ROOT, "vc2-reference_amd", "csrc", "*.h*"))):
+        depth = []   # stack of (is_tools_block)
+        for n, line in enumerate(open(f), 1):
+            t = line.strip()
+            if t.startswith("#if"):
+                depth.append(bool(re.search(r"VC2HIP_ABLATE|VC2HIP_STAMPS", t)) and not t.startswith("#ifndef"))
+            elif t.startswith("#else") and depth:
+                depth[-1] = False if depth[-1] else depth[-1]
+            elif t.startswith("#endif") and depth:
+                depth.pop()
+            elif "getenv(" in t and not t.startswith("//"):
+                assert any(depth), f"{os.path.basename(f)}:{n}: getenv outside a tools-only block: {t[:100]}"
+
+
 def test_binding_covers_header():
     import vc2hip_py
     assert sorted(vc2hip_py.EXPORTS) == [n for n in _declared() if n in vc2hip_py.EXPORTS]

@@ -130,13 +130,9 @@ def test_hq_pack_vbr_matches_oracle(hip, oracle, prefix, scalar):
 
 
 def test_hq_pack_single_pass_option(oracle):
-    # VC2HIP_SINGLE_PASS_VBR=1: slice offsets by decoupled look-back inside the pack kernel
+    # VC2HIP_FLAG_SINGLE_PASS_VBR: slice offsets by decoupled look-back inside the pack kernel
     import vc2hip_py
-    os.environ["VC2HIP_SINGLE_PASS_VBR"] = "1"
-    try:
-        h2 = vc2hip_py.Vc2Hip(0)
-    finally:
-        del os.environ["VC2HIP_SINGLE_PASS_VBR"]
+    h2 = vc2hip_py.Vc2Hip(0, flags=vc2hip_py.FLAGS["SINGLE_PASS_VBR"])
     depth, ys, xs = 3, 9, 7
     (y, u, v), qidx, _ = _quantised_planes(oracle, 26, (ys * 8, xs * 16), (ys * 8, xs * 8), depth, ys, xs, "DD97", 8)
     for prefix, scalar in ((0, 1), (3, 2)):

@@ -13,25 +13,18 @@ from vc2lib import KERNELS, make_params
 pytestmark = pytest.mark.gpu
 
 
-def _ctx(env):
-    """a context created under the given environment switches (read once, at vc2hip_create)"""
-    from vc2hip_py import Vc2Hip
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return Vc2Hip()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _ctx(*flags):
+    """a context with the given vc2hip_create_with_flags switches (round 5: the release library reads no environment)"""
+    from vc2hip_py import FLAGS, Vc2Hip
+    return Vc2Hip(flags=sum(FLAGS[f] for f in flags))
 
 
 @pytest.fixture(scope="module")
 def variants():
-    return {"default": _ctx({}), "store32": _ctx({"VC2HIP_STORE32": "1"}), "tiles": _ctx({"VC2HIP_NO_STREAM": "1"}),
-            "records": _ctx({"VC2HIP_NO_BANDPLANES": "1"})}
+    """default = everything on (two-level kernels, streaming kernels, 16-bit store, band planes, record heads); the others
+    each take ONE of them away, so that every alternative path runs the same cases"""
+    return {"default": _ctx(), "store32": _ctx("STORE32"), "tiles": _ctx("NO_STREAM"), "records": _ctx("NO_BANDPLANES"),
+            "levels": _ctx("NO_PAIR")}
 
 
 def _fmt_cp(hip, w, h, cf, bits, kernel, depth, u, a, **kw):
@@ -215,12 +208,10 @@ def test_cbr_search_register_kernel_and_hand_back(variants, oracle, amp, budget,
         try:
             got = hip.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
         except Exception as e:      # a device error flag (index / length byte out of range): the general kernel raises the same
-            os.environ["VC2HIP_CBR_GENERAL"] = "1"
-            try:
-                with pytest.raises(type(e)):
-                    hip.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
-            finally:
-                del os.environ["VC2HIP_CBR_GENERAL"]
+            general = _ctx("CBR_GENERAL")
+            with pytest.raises(type(e)):
+                general.cbr_qindices(ty, tu, tv, depth, qm, sb, scalar)
+            general.close()
             continue
         assert np.array_equal(got, want), name
 

@@ -104,3 +104,59 @@ def test_reference_quant_indices_constq_builds_against_host_headers(tmp_path):
     exe = str(tmp_path / "constq")
     subprocess.check_call(CXX + ["-I" + str(tmp_path), "-o", exe, str(tmp_path / "tu.cpp")] + HOSTSRC)
     assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "ok"
+
+
+def _reference_quant_tool(tmp_path):
+    """quant_factor, quant, quant_offset and scale (/root/reference/src/Library/src/Quantisation.cpp:40-95: four functions
+    over the standard library only) cut into the pytest temp directory at test time and compiled as they stand; the
+    driver around them prints `what q v result` lines for every index 0..119 and a set of values."""
+    import re
+    text = open(os.path.join(REF, "src/Library/src/Quantisation.cpp")).read()
+    m = re.search(r"^const int quant_factor\(int q\) \{.*?^const int scale\(int value, int q\) \{.*?^}\n", text, re.S | re.M)
+    assert m, "quant_factor .. scale not found in the reference"
+    (tmp_path / "quant_region.inc").write_text(m.group(0))
+    (tmp_path / "quant_tu.cpp").write_text(
+        '#include <cstdio>\n#include <cstdlib>\n#include <stdexcept>\n#include "quant_region.inc"\n'
+        "int main() {\n"
+        "  static const int vals[] = {0, 1, 2, 3, 5, 12, 100, 511, 512, 1023, 4095, 32767, 65534, 100000, 1000000};\n"
+        "  for (int q = 0; q < 120; ++q) {\n"
+        '    std::printf("factor %d 0 %d\\noffset %d 0 %d\\n", q, quant_factor(q), q, quant_offset(q));\n'
+        "    for (int v : vals) for (int s = -1; s <= 1; s += 2) {\n"
+        '      std::printf("quant %d %d %d\\n", q, s * v, quant(s * v, q));\n'
+        "      if ((long long)v * (unsigned)quant_factor(q) < (1ll << 31) - (1ll << 30))\n"   # scale() inside int arithmetic (the reference's own domain)
+        '        std::printf("scale %d %d %d\\n", q, s * v, scale(s * v, q));\n'
+        "    }\n  }\n"
+        '  try { quant_factor(120); std::puts("nothrow"); } catch (const std::logic_error &e) { std::printf("throws %s\\n", e.what()); }\n'
+        "  return 0;\n}\n")
+    exe = str(tmp_path / "quanttool")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-I" + str(tmp_path), "-o", exe, str(tmp_path / "quant_tu.cpp")])
+    return subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()
+
+
+@needs_reference
+def test_reference_quant_scale_functions_agree_with_the_oracle(tmp_path):
+    """moves quant_offset / scale (the dequantiser) from "digest only" to "reference code" in DESIGN
+    section 2's table: the oracle's vc2o_quant_factor / vc2o_quant / vc2o_scale against the reference's own functions
+    compiled from where they lie, all 120 indices, both signs, values up to the 32-bit code limit and beyond."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from vc2lib import load_oracle
+    oracle = load_oracle()
+    lines = _reference_quant_tool(tmp_path)
+    assert lines[-1] == "throws quantization index exceeds maximum implemented value."
+    n = 0
+    for line in lines[:-1]:
+        what, q, v, want = line.split()
+        q, v, want = int(q), int(v), int(want)
+        if what == "factor":
+            assert oracle.quant_factor(q) == want, line
+        elif what == "offset":   # quant_offset: what scale() adds to a non-zero product -- seen through scale(1, q)
+            f = oracle.quant_factor(q)
+            if f > 0 and want > 0 and f + want + 2 < (1 << 31):   # (indices 116..119: the factor's int is negative; beyond 2^31 the int sum wraps: both outside the domain of scale())
+                assert oracle.scale(1, q) == (f + want + 2) // 4, line
+        elif what == "quant":
+            assert oracle.quant(v, q) == want, line
+        else:
+            assert oracle.scale(v, q) == want, line
+        n += 1
+    assert n > 120 * 40

@@ -4,7 +4,8 @@ chroma formats, bit depths, kernels, depths, slice sizes, modes.  Prints the fai
   python tools/fuzz_geometry.py <seed> <cases> [wide]
 
 wide: planes of 512 ... 2560 samples across and a few slice rows, so that levels go through the streaming transform
-kernels and the decoder's band planes (the default sizes stay below them), mixed with tile-kernel levels underneath."""
+kernels and the decoder's band planes (the default sizes stay below them), mixed with tile-kernel levels underneath.
+tall: such planes with 3 ... 33 slice rows (round 5: the segments of the streaming and the two-level kernels)."""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vc2-reference_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,9 +15,11 @@ from vc2lib import load_oracle, make_params, KERNELS
 from synth import synth, noise_frame
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "tall")
+tall = len(sys.argv) > 3 and sys.argv[3] == "tall"   # wide planes with MANY slice rows: the streaming / pair kernels' segments (top, middle, bottom walks)
 rnd = random.Random(seed)
 hip = vc2hip_py.Vc2Hip(0)
+hip.profile_enable(True)   # (only to count, at the end, which transform kernels the cases went through)
 oracle = load_oracle()
 bad = 0
 done = 0
@@ -36,6 +39,9 @@ while done < count:
         xs = max(1, rnd.choice([512, 640, 768, 1024, 1536, 2560]) // (a * unit))
         ys = rnd.choice([1, 2, 3])
         u = rnd.choice([1, 2, 4]) * (2 if cf == "420" else 1)
+        if tall:
+            xs = max(1, rnd.choice([256, 512, 640, 1024]) // (a * unit))
+            ys = rnd.choice([3, 5, 6, 7, 9, 12, 17, 24, 33])
     ph, pw = ys * u * unit, xs * a * unit
     # unpadded size: up to one unit less than padded (keeps chroma consistent: even crops)
     h = ph - rnd.choice([0, 0, 2, unit - 2 if unit > 2 else 0])
@@ -86,3 +92,8 @@ while done < count:
         bad += 1
         print("EXCEPTION", desc, str(e)[:120])
 print(f"seed {seed}: {done} cases, {bad} bad, {skipped_ld} refused by the LD encoder's documented limit")
+try:
+    hip.sync()
+    print("transform launches:", {k: v[0] for k, v in sorted(hip.profile().items()) if "dwt" in k})
+except Exception:
+    pass

@@ -142,7 +142,10 @@ struct vc2hip_ctx {
   bool allow_heads = true;  // record heads for the levels below them (A/B and test switch VC2HIP_NO_HEADS)
   bool allow_cbr_index = true; // decode of HQ_CBR pictures: offsets from the budgets, verified (VC2HIP_NO_CBR_INDEX=1: always the general index)
   bool allow_stream = true;   // VC2HIP_NO_STREAM=1: tile kernels instead of the streaming level kernels (tests, A/B)
-  bool allow_pair = true;     // VC2HIP_NO_PAIR=1: one launch per transform level (vc2hip_dwt_pair.hip off; tests, A/B)
+  bool allow_pair = true;     // VC2HIP_FLAG_NO_PAIR: one launch per transform level (vc2hip_dwt_pair.hip off; tests, A/B)
+  bool cbr_general = false;   // VC2HIP_FLAG_CBR_GENERAL: the HQ_CBR search without the register kernels
+  bool ld_diagonals = false;  // VC2HIP_FLAG_LD_DIAGONALS: the LD index search with one launch per slice anti-diagonal
+  unsigned flags = 0;
   // vc2hip_set_streams(k > 1): device-resident batches are cut into k contiguous sub-batches, each on its own
   // stream and workspace (a child context), forked from / joined to `stream` with events.  The kernels of the
   // sub-batches overlap: the tail of one launch is filled by the next stream's work.
@@ -300,24 +303,38 @@ static void make_tables(QuantTables &t) {
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------
-static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **out) {
+static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **out, unsigned flags = 0) {
   if (!out) return VC2HIP_EINVAL;
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VC2HIP_EHIP;
   vc2hip_ctx *c = new vc2hip_ctx;
   c->device = device;
-  { const char *e = getenv("VC2HIP_GENERIC_DWT"); c->force_generic = e && e[0] == '1'; }
-  { const char *e = getenv("VC2HIP_STORE32"); c->allow_store16 = !(e && e[0] == '1'); }
-  { const char *e = getenv("VC2HIP_NO_STREAM"); c->allow_stream = !(e && e[0] == '1'); }
-  { const char *e = getenv("VC2HIP_NO_PAIR"); c->allow_pair = !(e && e[0] == '1'); }
-  { const char *e = getenv("VC2HIP_NO_BANDPLANES"); c->allow_planes = !(e && e[0] == '1'); }
-  { const char *e = getenv("VC2HIP_NO_HEADS"); c->allow_heads = !(e && e[0] == '1'); }
-  { const char *e = getenv("VC2HIP_NO_CBR_INDEX"); c->allow_cbr_index = !(e && e[0] == '1'); }
+  // the switches between two correct paths (vc2hip_create_with_flags); only the ablation build (tools/, never the product
+  // path) also takes them from the environment, so that its A/B runs need no code
 #ifdef VC2HIP_ABLATE
-  { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
+  {
+    static const struct { const char *name; unsigned flag; } env[] = {
+      {"VC2HIP_STORE32", VC2HIP_FLAG_STORE32}, {"VC2HIP_NO_STREAM", VC2HIP_FLAG_NO_STREAM}, {"VC2HIP_NO_PAIR", VC2HIP_FLAG_NO_PAIR},
+      {"VC2HIP_NO_BANDPLANES", VC2HIP_FLAG_NO_BANDPLANES}, {"VC2HIP_NO_HEADS", VC2HIP_FLAG_NO_HEADS},
+      {"VC2HIP_NO_CBR_INDEX", VC2HIP_FLAG_NO_CBR_INDEX}, {"VC2HIP_GENERIC_DWT", VC2HIP_FLAG_GENERIC_DWT},
+      {"VC2HIP_SINGLE_PASS_VBR", VC2HIP_FLAG_SINGLE_PASS_VBR}, {"VC2HIP_CBR_GENERAL", VC2HIP_FLAG_CBR_GENERAL}};
+    for (const auto &e : env) { const char *v = getenv(e.name); if (v && v[0] == '1') flags |= e.flag; }
+    { const char *v = getenv("VC2HIP_LD_ROWS"); if (v && v[0] == '0') flags |= VC2HIP_FLAG_LD_DIAGONALS; }
+    { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
+  }
 #endif
-  { const char *e = getenv("VC2HIP_SINGLE_PASS_VBR"); c->two_pass_vbr = !(e && e[0] == '1'); }
+  c->force_generic = (flags & VC2HIP_FLAG_GENERIC_DWT) != 0;
+  c->allow_store16 = !(flags & VC2HIP_FLAG_STORE32);
+  c->allow_stream = !(flags & VC2HIP_FLAG_NO_STREAM);
+  c->allow_pair = !(flags & VC2HIP_FLAG_NO_PAIR);
+  c->allow_planes = !(flags & VC2HIP_FLAG_NO_BANDPLANES);
+  c->allow_heads = !(flags & VC2HIP_FLAG_NO_HEADS);
+  c->allow_cbr_index = !(flags & VC2HIP_FLAG_NO_CBR_INDEX);
+  c->two_pass_vbr = !(flags & VC2HIP_FLAG_SINGLE_PASS_VBR);
+  c->cbr_general = (flags & VC2HIP_FLAG_CBR_GENERAL) != 0;
+  c->ld_diagonals = (flags & VC2HIP_FLAG_LD_DIAGONALS) != 0;
+  c->flags = flags;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VC2HIP_EHIP; }
   if (own) { if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VC2HIP_EHIP; } }
   c->stream = stream;
@@ -340,6 +357,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   return VC2HIP_OK;
 }
 extern "C" int vc2hip_create(int device, vc2hip_ctx **out) { return create_common(device, nullptr, true, out); }
+extern "C" int vc2hip_create_with_flags(int device, unsigned flags, vc2hip_ctx **out) { return create_common(device, nullptr, true, out, flags); }
 extern "C" int vc2hip_create_on_stream(int device, void *s, vc2hip_ctx **out) { return create_common(device, (hipStream_t)s, false, out); }
 extern "C" void vc2hip_destroy(vc2hip_ctx *c) {
   if (!c) return;
@@ -404,7 +422,7 @@ extern "C" int vc2hip_set_streams(vc2hip_ctx *c, int k) {
   for (int i = 0; i < k; ++i) {
     vc2hip_ctx *l = c;
     if (i > 0) {
-      const int rc = vc2hip_create(c->device, &l);
+      const int rc = vc2hip_create_with_flags(c->device, c->flags, &l);
       if (rc) return set_err(c, rc);
       l->L.on = c->L.on;
     }
@@ -503,7 +521,9 @@ static int need(vc2hip_ctx *c, int which, size_t bytes, void **out) {
     HIPCHK(c, hipMalloc(&b.p, cap));
     b.cap = cap;
 #ifdef VC2HIP_ABLATE
+#ifdef VC2HIP_ABLATE
     if (getenv("VC2HIP_DEBUG_ALLOC")) fprintf(stderr, "vc2hip alloc: buffer %d at %p, %zu bytes\n", which, b.p, cap);
+#endif
 #endif
   }
   *out = b.p;
@@ -1284,6 +1304,7 @@ extern "C" int vc2hip_cbr_qindices(vc2hip_ctx *c, const int32_t *y, const int32_
   p.n_slices = ns; p.slice_coefs = g.slice_coefs;
   fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
   p.scalar = scalar; p.err = c->d_err;
+  p.general_only = c->cbr_general;
   for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm[b];
   p.n_bands = 3 * g.depth + 1;
   vc2_launch_cbr(c->L, p, 1, c->stream);
@@ -1348,6 +1369,7 @@ static int fill_ld_enc(vc2hip_ctx *c, LdEncParams &p, const Geom &g, int32_t *d_
     p.bh[k] = (g.c[k].ph >> g.depth) / g.ys; p.bw[k] = (g.c[k].pw >> g.depth) / g.xs;
   }
   p.ys = g.ys; p.xs = g.xs; p.n_slices = ns; p.slice_coefs = g.slice_coefs;
+  p.diagonals = c->ld_diagonals;
   p.depth = g.depth;
   p.rs_ints = 0;
   for (int k = 0; k < 3; ++k) if (g.c[k].ph) p.rs_ints += (p.bh[k] + 1) * (p.bw[k] + 1);
@@ -1553,6 +1575,7 @@ extern "C" int vc2hip_encode_batch_dev(vc2hip_ctx *c, const void *d_raw, int n, 
     p.n_slices = ns; p.slice_coefs = g.slice_coefs;
     fill_comp_arrays(g, p.comp_n, p.comp_off, p.comp_n0);
     p.scalar = cp->scalar; p.err = c->d_err;
+    p.general_only = c->cbr_general;
     for (int b = 0; b < 3 * g.depth + 1; ++b) p.qmatrix[b] = qm[b];
     p.n_bands = 3 * g.depth + 1;
     vc2_launch_cbr(c->L, p, n, c->stream);

@@ -350,16 +350,22 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
               if (!S_::fits(a0)) { w[0] = a0; a0 = VC2_ST_SENTINEL; }
               if (!S_::fits(a1)) { w[1] = a1; a1 = VC2_ST_SENTINEL; }
             }
+#if !(defined(VC2_PAIR_X) && (VC2_PAIR_X & 2)) // (timing experiments: compile-time removal of one part of level b's output path)
             ring_ll[(k1 & (nll - 1)) * 64 + lane] = vc2_pack16(a0, a1);
+#endif
           } else *(uint2 *)(ring_ll + ((k1 & (nll - 1)) * 64 + lane) * 2) = make_uint2((unsigned)a0, (unsigned)a1);
           dnL = k1 + 1;
         }
+#if !(defined(VC2_PAIR_X) && (VC2_PAIR_X & 1))
         if (own) stageB(imgB + slotBs * szB, r, sv, oe, oo);
+#endif
+#if !(defined(VC2_PAIR_X) && (VC2_PAIR_X & 4))
         if (r == bshB - 1) {
           dnB = sv + 1;
           slotBs = slotBs == grpA ? 0 : slotBs + 1;
           if (sv + 1 == sv1) due = true; // (level b's last slice row of the segment: nothing of level a is left to wait for)
         }
+#endif
       }
     }
   };
@@ -977,21 +983,29 @@ __global__ __launch_bounds__(64, (K == VC2HIP_DD137 || SPL2 ? 2 : VC2_PAIR_WPE_I
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-#ifdef VC2_PAIR_ONLY_INV // (quick compiles)
-#define VC2_PAIR_HAS(INV) (INV)
-#elif defined(VC2_PAIR_ONLY_FWD)
-#define VC2_PAIR_HAS(INV) (!(INV))
+// Which instantiations exist.  The inverse pair that ends with the picture's samples is not used by the library (measured
+// slower than its two one-level kernels, vc2hip_api.hip run_inverse): only the tools' build carries it, for A/B runs
+// (VC2HIP_PAIR_INV_FINAL=1).  VC2_PAIR_ONLY_*: quick compiles while working on this file.
+#ifdef VC2HIP_ABLATE
+#define VC2_PAIR_INV_EDGE true
 #else
-#define VC2_PAIR_HAS(INV) true
+#define VC2_PAIR_INV_EDGE false
+#endif
+#ifdef VC2_PAIR_ONLY_INV
+#define VC2_PAIR_HAS(INV, EDGE) ((INV) && (!(EDGE) || VC2_PAIR_INV_EDGE))
+#elif defined(VC2_PAIR_ONLY_FWD)
+#define VC2_PAIR_HAS(INV, EDGE) (!(INV))
+#else
+#define VC2_PAIR_HAS(INV, EDGE) (!(INV) || !(EDGE) || VC2_PAIR_INV_EDGE)
 #endif
 template <int K, bool EDGE, bool INV, class ST> const void *pair_fn(bool SPL2) {
-  if constexpr (!pair_kernel<K>() || !VC2_PAIR_HAS(INV)) return nullptr;
+  if constexpr (!pair_kernel<K>() || !VC2_PAIR_HAS(INV, EDGE)) return nullptr;
   else if constexpr (INV) return SPL2 ? (const void *)k_inv_pair<K, EDGE, ST, true> : (const void *)k_inv_pair<K, EDGE, ST, false>;
   else return (const void *)k_fwd_pair<K, EDGE, ST>;
 }
 template <int K, bool EDGE, bool INV, class ST>
 int launch_pair(Launcher &L, const PairParams &pp, int n_pictures, size_t lds, hipStream_t s) {
-  if constexpr (!pair_kernel<K>() || !VC2_PAIR_HAS(INV)) return VC2HIP_EINVAL;
+  if constexpr (!pair_kernel<K>() || !VC2_PAIR_HAS(INV, EDGE)) return VC2HIP_EINVAL;
   else {
     const LevelParams &p = pp.a;
     const int cols = (p.st_strips[0] + p.st_strips[1] + p.st_strips[2]) * n_pictures;

@@ -251,6 +251,7 @@ struct CbrParams {
   int qmatrix[VC2_MAX_BANDS];
   unsigned *err;
   int only_marked;            // set by the launcher: search only the slices whose index is VC2_CBR_MARK
+  int general_only;           // VC2HIP_FLAG_CBR_GENERAL: no register kernel (tests, A/B)
   float inv_scalar;           // set by the launcher
   int qm_min;                 // set by the launcher: the smallest matrix entry
   union {
@@ -373,6 +374,7 @@ struct LdEncParams {
   int rs_ints;                // LDS ints per wavefront for the LL blocks with their halo: sum of (bh + 1) * (bw + 1)
   int qmatrix[VC2_MAX_BANDS];
   int search;
+  int diagonals;              // VC2HIP_FLAG_LD_DIAGONALS: one launch per slice anti-diagonal instead of the single-launch search
   int *tab;                   // device scratch for the search tables (LD_TAB_INTS ints)
   int img_words;              // LDS words of one slice image (pack)
   uint8_t *payload;

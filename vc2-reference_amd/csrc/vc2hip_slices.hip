@@ -1496,8 +1496,8 @@ void vc2_launch_cbr(Launcher &L, const CbrParams &p0, int n_pictures, hipStream_
   for (int b = 1; b < p.n_bands; ++b) p.qm_min = std::min(p.qm_min, p.qmatrix[b]);
   p.inv_scalar = 1.0f / (float)p.scalar; // the smallest float >= 1 / scalar
   if ((double)p.inv_scalar < 1.0 / (double)p.scalar) p.inv_scalar = nextafterf(p.inv_scalar, INFINITY);
-  static const bool no_reg = [] { const char *e = getenv("VC2HIP_CBR_GENERAL"); return e && e[0] == '1'; }(); // A/B and test switch: the general kernel only
-  const bool reg = !no_reg && p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32 &&
+  // (general_only = VC2HIP_FLAG_CBR_GENERAL: A/B and test switch, the general kernel only)
+  const bool reg = !p.general_only && p.comp_n[0] <= 512 && p.comp_n[1] <= 256 && p.comp_n[1] == p.comp_n[2] && p.n_bands <= 32 &&
                    p.comp_n[0] % 8 == 0 && p.comp_n[1] % 8 == 0 && (p.store_stride % 8) == 0 && (p.slice_coefs % 8) == 0 &&
                    p.comp_off[1] % 8 == 0 && p.comp_off[2] % 8 == 0;
   if (reg) { // the register kernel, then the general one over the slices it handed back (usually none: a small grid)
@@ -3760,7 +3760,7 @@ void vc2_launch_ld_quantise(Launcher &L, const LdEncParams &p, int n_pictures, h
     const int reach = small ? 128 : 256;
     const bool dual = p.comp_n[0] <= reach && 2 * p.comp_n[1] <= reach; // half a wavefront covers a stream
     VC2_LAUNCH(L, k_ld_tables, dim3(1), dim3(256), 0, s, p);
-    static const int rows = [] { const char *e = getenv("VC2HIP_LD_ROWS"); return e ? atoi(e) : 1; }();
+    const int rows = !p.diagonals; // (VC2HIP_FLAG_LD_DIAGONALS)
 #ifdef VC2HIP_ABLATE
     LdEncParams pd = p;
     { const char *e = getenv("VC2HIP_DEBUG_LD_DEAD_ROW"); pd.debug_dead_row = e ? atoi(e) : -1; }

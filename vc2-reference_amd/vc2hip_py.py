@@ -13,6 +13,10 @@ LIB_PATH = os.environ.get("VC2HIP_LIB") or os.path.join(HERE, "libvc2hip.so")   
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
+# vc2hip_create_with_flags (include/vc2hip.h: each flag selects the slower / more general of two correct paths)
+FLAGS = {"STORE32": 0x001, "NO_STREAM": 0x002, "NO_PAIR": 0x004, "NO_BANDPLANES": 0x008, "NO_HEADS": 0x010, "NO_CBR_INDEX": 0x020,
+         "GENERIC_DWT": 0x040, "SINGLE_PASS_VBR": 0x080, "CBR_GENERAL": 0x100, "LD_DIAGONALS": 0x200}
+
 KERNELS = {"DD97": 0, "LeGall": 1, "DD137": 2, "Haar0": 3, "Haar1": 4, "Fidelity": 5, "Daub97": 6}
 CF = {"444": 0, "422": 1, "420": 2}
 MODES = {"HQ_ConstQ": 0, "HQ_CBR": 1, "LD": 2}
@@ -42,7 +46,7 @@ class Vc2HipError(RuntimeError):
 
 
 EXPORTS = [
-    "vc2hip_create", "vc2hip_create_on_stream", "vc2hip_destroy", "vc2hip_last_error",
+    "vc2hip_create", "vc2hip_create_with_flags", "vc2hip_create_on_stream", "vc2hip_destroy", "vc2hip_last_error",
     "vc2hip_error_string", "vc2hip_sync", "vc2hip_padded_size", "vc2hip_slice_size_is_valid",
     "vc2hip_quant_matrix", "vc2hip_slice_bytes", "vc2hip_dwt_forward", "vc2hip_dwt_inverse",
     "vc2hip_quantise_np", "vc2hip_dequantise_np", "vc2hip_dequantise_ld", "vc2hip_hq_pack",
@@ -70,6 +74,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.vc2hip_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.vc2hip_create_with_flags.argtypes = [C.c_int, C.c_uint, C.POINTER(vp)]
     lib.vc2hip_create_on_stream.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.vc2hip_destroy.argtypes = [vp]
     lib.vc2hip_destroy.restype = None
@@ -145,10 +150,12 @@ def coding_params(lib, fmt, kernel, depth, u, a, mode="HQ_ConstQ", q=0, s=0, pre
 class Vc2Hip:
     """One context (= one GPU, one stream)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, flags=0):
         self.lib = load_library()
         h = C.c_void_p()
-        if stream is None:
+        if stream is None and flags:
+            rc = self.lib.vc2hip_create_with_flags(device, C.c_uint(flags), C.byref(h))
+        elif stream is None:
             rc = self.lib.vc2hip_create(device, C.byref(h))
         else:
             rc = self.lib.vc2hip_create_on_stream(device, C.c_void_p(stream), C.byref(h))
