@@ -57,8 +57,10 @@ pair6)
   ;;
 v)
   shift
-  for t in "$@"; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
-  for t in "$@"; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
+  for rep in 1 2; do
+    run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip.so
+    for t in "$@"; do run VC2HIP_LIB=$PWD/vc2-reference_amd/libvc2hip_exp_$t.so; done
+  done
   ;;
 inv1)
   L=$PWD/vc2-reference_amd/libvc2hip_exp_i2.so

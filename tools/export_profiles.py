@@ -15,6 +15,8 @@ SHORT = {'k_hq_unpack': 'hq_unpack', 'k_hq_pack': 'hq_pack', 'k_inv_fast<0, true
          'k_inv_fast<0, false': 'idwt_level', 'k_fwd_fast<0, true': 'dwt_level_first', 'k_fwd_fast<0, false': 'dwt_level',
          'k_inv_stream<0, true': 'idwt_level_final', 'k_inv_stream<0, false': 'idwt_level',
          'k_fwd_stream<0, true': 'dwt_level_first', 'k_fwd_stream<0, false': 'dwt_level',
+         'k_fwd_pair<0, true': 'dwt_pair_first', 'k_fwd_pair<0, false': 'dwt_pair',          # round 5: two levels per launch
+         'k_inv_pair<0, true': 'idwt_pair_final', 'k_inv_pair<0, false': 'idwt_pair',
          'k_compact': 'slice_compact', 'k_scan_sizes': 'slice_offsets_scan', 'k_index_tables_nx': 'slice_index_tables',
          'k_index_group': 'slice_index_chain(group)', 'k_index_chain': 'slice_index_chain(chain)', 'k_index_emit': 'slice_index_emit'}
 
