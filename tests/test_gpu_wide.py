@@ -484,3 +484,29 @@ def test_ld_corrupt_slice_headers_like_the_reference(hip, oracle, what):
     want, n = oracle.decode_stream(p, head + pay + tail, 1)
     assert n == 1
     assert hip.decode_picture(pay + tail, fmt, cp) == want   # (the reference's reader sees what follows the data unit too)
+
+
+def test_two_level_kernels_are_the_path_taken(variants, oracle):
+    """Round 5: a UHD-like geometry (planes from 192 samples wide, 32 x 16 slices, DD97 depth 4, 4:2:2) must go through
+    k_fwd_pair / k_inv_pair -- seen in the library's own launch profile, so that the parity tests of this geometry are tests
+    of those kernels -- and through the one-level kernels in the `levels` variant; both bit-exact with the oracle."""
+    w, h = 1536, 256   # (chroma planes of levels 2 + 3: 192 samples wide, the narrowest the streaming kernels take)
+    raw = synth(w, h, "422", 10, 77)
+    p = make_params(w, h, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    seen = {}
+    for name in ("default", "levels"):
+        hip = variants[name]
+        fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+        hip.profile_reset(); hip.profile_enable(True)
+        payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+        out = hip.decode_picture(payload, fmt, cp)
+        hip.sync()
+        hip.profile_enable(False)
+        seen[name] = {k for k, v in hip.profile().items() if v[0] > 0}
+        assert payload == stream[-13 - len(payload):-13] and out == dec, name
+    assert {"dwt_pair_first", "dwt_pair", "idwt_pair"} <= seen["default"], seen["default"]
+    assert "dwt_level_first" not in seen["default"]
+    assert not any("pair" in k for k in seen["levels"]), seen["levels"]
+    assert {"dwt_level_first", "dwt_level", "idwt_level", "idwt_level_final"} <= seen["levels"]
