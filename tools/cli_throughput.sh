@@ -25,8 +25,9 @@ for dev in $devs; do
   s=$(date +%s.%N); $D --devices $dev /dev/shm/vc2_out.vc2 /dev/shm/vc2_dec.raw 2> /dev/shm/vc2_d.err > /dev/null; e=$(date +%s.%N)
   echo "--devices $dev DecodeStream (new output file): whole process $(python3 -c "print(round($n/($e-$s),1))") frames/s;  $(grep stats /dev/shm/vc2_d.err)"
   # again over the file of the first run: its pages exist (a NEW file in /dev/shm is filled at 4 - 6 GB/s however many threads
-  # write it -- tools/probe/pagetouch.c -- which is 120 - 190 UHD frames/s whatever the decoder does)
-  s=$(date +%s.%N); $D --devices $dev /dev/shm/vc2_out.vc2 /dev/shm/vc2_dec.raw 2> /dev/shm/vc2_d.err > /dev/null; e=$(date +%s.%N)
+  # write it -- tools/probe/pagetouch.c -- which is 120 - 190 UHD frames/s whatever the decoder does).  Round 5: the tool empties
+  # an existing output file up front unless VC2_DECODESTREAM_REUSE=1 asks for the reuse (a killed run must not leave old frames)
+  s=$(date +%s.%N); VC2_DECODESTREAM_REUSE=1 $D --devices $dev /dev/shm/vc2_out.vc2 /dev/shm/vc2_dec.raw 2> /dev/shm/vc2_d.err > /dev/null; e=$(date +%s.%N)
   echo "--devices $dev DecodeStream (over an existing file): whole process $(python3 -c "print(round($n/($e-$s),1))") frames/s;  $(grep stats /dev/shm/vc2_d.err)"
   [ "$dev" = "0" ] && cp /dev/shm/vc2_out.vc2 /dev/shm/vc2_out0.vc2 && sha256sum /dev/shm/vc2_dec.raw | cut -c1-16 > /dev/shm/vc2_dec0.sha
   cmp -s /dev/shm/vc2_out.vc2 /dev/shm/vc2_out0.vc2 || echo "STREAMS DIFFER between --devices 0 and $dev"

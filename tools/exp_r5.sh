@@ -66,5 +66,8 @@ inv1)
   L=$PWD/vc2-reference_amd/libvc2hip_exp_i2.so
   for k in 0 8 16 64 80 128 256 464; do run VC2HIP_LIB=$L VC2HIP_DEBUG_SKIP=$k; done
   ;;
+prio)
+  for rep in 1 2; do for pr in 1 2 3 4 0; do run VC2HIP_LIB=$A VC2HIP_PAIR_PRIO=$pr; done; done
+  ;;
 esac
 cat $O

@@ -15,8 +15,9 @@ from vc2lib import load_oracle, make_params, KERNELS
 from synth import synth, noise_frame
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "tall")
-tall = len(sys.argv) > 3 and sys.argv[3] == "tall"   # wide planes with MANY slice rows: the streaming / pair kernels' segments (top, middle, bottom walks)
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "tall", "pair")
+pairm = len(sys.argv) > 3 and sys.argv[3] == "pair"   # geometries the two-level kernels take: short filters, depth 2 - 4, every plane from 192 samples wide at the pair's level
+tall = len(sys.argv) > 3 and sys.argv[3] in ("tall", "pair")   # wide planes with MANY slice rows: the streaming / pair kernels' segments (top, middle, bottom walks)
 rnd = random.Random(seed)
 hip = vc2hip_py.Vc2Hip(0)
 hip.profile_enable(True)   # (only to count, at the end, which transform kernels the cases went through)
@@ -42,6 +43,13 @@ while done < count:
         if tall:
             xs = max(1, rnd.choice([256, 512, 640, 1024]) // (a * unit))
             ys = rnd.choice([3, 5, 6, 7, 9, 12, 17, 24, 33])
+        if pairm:
+            depth = rnd.choice([2, 3, 4]); unit = 1 << depth
+            kernel = rnd.choice(["DD97", "LeGall", "DD137", "Haar0", "Haar1"])
+            a = rnd.choice([1, 2, 4]) * (1 if cf == "444" else 2)
+            u = rnd.choice([1, 2]) * (2 if cf == "420" else 1)
+            xs = max(1, rnd.choice([1536, 2048, 3072]) // (a * unit))
+            ys = rnd.choice([4, 6, 7, 9, 12, 17, 24, 40])
     ph, pw = ys * u * unit, xs * a * unit
     # unpadded size: up to one unit less than padded (keeps chroma consistent: even crops)
     h = ph - rnd.choice([0, 0, 2, unit - 2 if unit > 2 else 0])

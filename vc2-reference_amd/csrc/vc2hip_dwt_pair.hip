@@ -45,6 +45,17 @@ namespace {
 
 #include "vc2hip_stream_eng.h"
 
+// Issue priority in turn (prio_turn, vc2hip_stream_eng.h), for kernels with TWO wavefronts per SIMD.  The four-level
+// rotation of the one-level kernels gives the second wavefront of a SIMD the higher priority in three turns of four
+// ((t + 1) & 3 > t & 3); mode: 1 = that rotation, 2 = strict alternation (3 / 0), a turn = one block of eight row pairs;
+// >= 3: alternation with turns of 2^(mode - 2) blocks
+__device__ __forceinline__ void pair_prio(int mode, int prio0, int block) {
+  if (mode == 1) { prio_turn(prio0 + block); return; }
+  const int t = mode == 2 ? block : block >> (mode - 2);
+  if ((prio0 + t) & 1) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 template <int V> using IC = std::integral_constant<int, V>;
 template <bool V> using BC = std::integral_constant<bool, V>;
 
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
   }
   const int prio0 = (int)(blockIdx.x >> 10);
   for (; mb < mend; mb += 8) {
-    if (st_prio) prio_turn(prio0 + (mb >> 3));
+    if (st_prio) pair_prio(st_prio, prio0, mb >> 3);
     block(IC<0>(), BC<false>());
   }
   if (bottom) {
@@ -966,7 +977,7 @@ __global__ __launch_bounds__(64, (K == VC2HIP_DD137 || SPL2 ? 2 : VC2_PAIR_WPE_I
   const int prio0 = (int)(blockIdx.x >> 10);
   const int mlast = bottom ? npA - 8 : mend; // (a bottom walk's last block has its own form)
   for (; mb < mlast; mb += 8) {
-    if (st_prio) prio_turn(prio0 + (mb >> 3));
+    if (st_prio) pair_prio(st_prio, prio0, mb >> 3);
     block(IC<0>(), BC<false>());
   }
   if (bottom) {
@@ -1222,7 +1233,8 @@ size_t vc2_pair_applicable(PairParams &pp, int kernel, bool edge, bool inverse, 
   for (int c = 0; c < 3; ++c) if (p.st_strips[c]) p.st_segs[c] = nseg;
   p.st_segmax = nseg;
   p.st_npic = n_pictures;
-  p.st_prio = 2;
+  static const int prio = vc2_tune_int("VC2HIP_PAIR_PRIO", 1); // (measured: rotation 0.552 - 0.561, alternation 0.542 - 0.558, longer turns 0.549 - 0.569, none 0.574 - 0.583 ms)
+  p.st_prio = prio; // (wavefronts take turns at the highest issue priority, a new turn every block: as the one-level kernels)
   p.st_lds = (int)lds;
 #ifdef VC2HIP_ABLATE
   if (getenv("VC2HIP_PAIR_DEBUG")) fprintf(stderr, "pair: kernel %d edge %d lds %zu (img a %zu) slots %d cols %d nseg %d runin %d\n", kernel, (int)edge, lds, imgA, slots, cols, nseg, runin);

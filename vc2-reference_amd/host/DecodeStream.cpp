@@ -141,6 +141,13 @@ int main(int argc, char *argv[]) {
       ofd = outFileName == "-" ? 1 : ::open(outFileName.c_str(), O_WRONLY | O_CREAT, 0666);
       if (ofd < 0) { perror((string("Failed to open output file \"") + outFileName + "\"").c_str()); return EXIT_FAILURE; }
       outSeekable = outFileName != "-" && fstat(ofd, &st) == 0 && S_ISREG(st.st_mode);
+      // ... but whatever ends this process early (a signal, std::terminate from a worker, a watchdog) would then leave a longer
+      // old file's frames behind the new ones, and they look valid.  So an existing file IS emptied up front
+      // unless the caller asks for the reuse (VC2_DECODESTREAM_REUSE=1: tools/cli_throughput.sh's "over an existing file" rows).
+      if (outSeekable && st.st_size > 0 && getenv("VC2_DECODESTREAM_REUSE") == nullptr && ftruncate(ofd, 0) != 0) {
+        perror((string("Failed to truncate output file \"") + outFileName + "\"").c_str());
+        return EXIT_FAILURE;
+      }
     }
     auto writeAt = [&](const unsigned char *p, std::size_t n, long long at) {
       while (n) {
@@ -179,9 +186,13 @@ int main(int argc, char *argv[]) {
     std::mutex writeMutex; // pwrites of several threads to one file queue behind its inode lock and take longer than one after the other (pagetouch.c)
     long long doneBytes = 0; // end of the last frame written in order
     // the size of a regular output file: the frames written in order (on every way out of this block)
+    bool fileFinished = false; // (once: the guard below runs again after the explicit call and the ::close behind it)
     auto finishFile = [&]() {
       workers.reset(); // (joins the workers: none of them is still writing)
-      if (outSeekable && ofd > 1) { if (ftruncate(ofd, (off_t)doneBytes) != 0) {} }
+      if (fileFinished) return;
+      fileFinished = true;
+      if (outSeekable && ofd > 1 && ftruncate(ofd, (off_t)doneBytes) != 0)
+        perror((string("Failed to cut output file \"") + outFileName + "\" to the frames written").c_str());
     };
     struct FileGuard { std::function<void()> f; ~FileGuard() { f(); } } fileGuard{finishFile};
     const bool stats = getenv("VC2_TOOL_STATS") != nullptr; // steady-state rate on stderr, as in EncodeStream
