@@ -24,7 +24,7 @@ def variants():
     """default = everything on (two-level kernels, streaming kernels, 16-bit store, band planes, record heads); the others
     each take ONE of them away, so that every alternative path runs the same cases"""
     return {"default": _ctx(), "store32": _ctx("STORE32"), "tiles": _ctx("NO_STREAM"), "records": _ctx("NO_BANDPLANES"),
-            "levels": _ctx("NO_PAIR")}
+            "levels": _ctx("NO_PAIR"), "bytes": _ctx("PLANES8_ALWAYS"), "words": _ctx("PLANES8_NEVER")}
 
 
 def _fmt_cp(hip, w, h, cf, bits, kernel, depth, u, a, **kw):
@@ -487,10 +487,10 @@ def test_ld_corrupt_slice_headers_like_the_reference(hip, oracle, what):
 
 
 def test_two_level_kernels_are_the_path_taken(variants, oracle):
-    """Round 5: a UHD-like geometry (planes from 192 samples wide, 32 x 16 slices, DD97 depth 4, 4:2:2) must go through
+    """Round 5: a UHD-like geometry (planes from 256 samples wide at level 2, 32 x 16 slices, DD97 depth 4, 4:2:2) must go through
     k_fwd_pair / k_inv_pair -- seen in the library's own launch profile, so that the parity tests of this geometry are tests
     of those kernels -- and through the one-level kernels in the `levels` variant; both bit-exact with the oracle."""
-    w, h = 1536, 256   # (chroma planes of levels 2 + 3: 192 samples wide, the narrowest the streaming kernels take)
+    w, h = 2048, 256   # (chroma planes of level 3: 128 samples wide, the narrowest that keeps the 16-bit store, which the pairs need)
     raw = synth(w, h, "422", 10, 77)
     p = make_params(w, h, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
     stream = oracle.encode_stream(p, raw, 1)

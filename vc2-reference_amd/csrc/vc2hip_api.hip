@@ -138,6 +138,17 @@ struct vc2hip_ctx {
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
   bool allow_planes = true; // decode: band planes for the streaming levels (A/B and test switch VC2HIP_NO_BANDPLANES)
+  // Byte band planes (BandPlanes::bytes8): 0 = by what the previous batch looked like (its payload bits per sample, its
+  // escapes), 1 = always, 2 = never (VC2HIP_FLAG_PLANES8_ALWAYS / _NEVER).  The choice never changes a result: a value that
+  // does not fit a byte escapes to the wide array; it decides between half the band-plane bytes and many escapes.
+  int planes8_mode = 0;
+  bool planes8_on = false;             // the adaptive state: off until a batch has shown small coefficients
+  unsigned long long *d_stat = nullptr; // device: [0] pieces with an escape from a byte plane (k_hq_unpack16<true>)
+  unsigned long long *h_stat = nullptr; // pinned: [0] that count, [1..] the batch's payload lengths (first 60 pictures)
+  hipEvent_t stat_ev = nullptr;
+  bool stat_pending = false, stat_was8 = false;
+  int stat_n = 0;                      // lengths copied
+  double stat_samples = 0;             // samples per picture of that batch
   int ld_batch = 1;         // pictures of the LD batch being encoded (fill_ld_enc sizes the scratch array with it)
   bool allow_heads = true;  // record heads for the levels below them (A/B and test switch VC2HIP_NO_HEADS)
   bool allow_cbr_index = true; // decode of HQ_CBR pictures: offsets from the budgets, verified (VC2HIP_NO_CBR_INDEX=1: always the general index)
@@ -318,7 +329,8 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
       {"VC2HIP_STORE32", VC2HIP_FLAG_STORE32}, {"VC2HIP_NO_STREAM", VC2HIP_FLAG_NO_STREAM}, {"VC2HIP_NO_PAIR", VC2HIP_FLAG_NO_PAIR},
       {"VC2HIP_NO_BANDPLANES", VC2HIP_FLAG_NO_BANDPLANES}, {"VC2HIP_NO_HEADS", VC2HIP_FLAG_NO_HEADS},
       {"VC2HIP_NO_CBR_INDEX", VC2HIP_FLAG_NO_CBR_INDEX}, {"VC2HIP_GENERIC_DWT", VC2HIP_FLAG_GENERIC_DWT},
-      {"VC2HIP_SINGLE_PASS_VBR", VC2HIP_FLAG_SINGLE_PASS_VBR}, {"VC2HIP_CBR_GENERAL", VC2HIP_FLAG_CBR_GENERAL}};
+      {"VC2HIP_SINGLE_PASS_VBR", VC2HIP_FLAG_SINGLE_PASS_VBR}, {"VC2HIP_CBR_GENERAL", VC2HIP_FLAG_CBR_GENERAL},
+      {"VC2HIP_PLANES8_ALWAYS", VC2HIP_FLAG_PLANES8_ALWAYS}, {"VC2HIP_PLANES8_NEVER", VC2HIP_FLAG_PLANES8_NEVER}};
     for (const auto &e : env) { const char *v = getenv(e.name); if (v && v[0] == '1') flags |= e.flag; }
     { const char *v = getenv("VC2HIP_LD_ROWS"); if (v && v[0] == '0') flags |= VC2HIP_FLAG_LD_DIAGONALS; }
     { const char *e = getenv("VC2HIP_DEBUG_SKIP"); c->debug_skip = e ? atoi(e) : 0; }
@@ -329,6 +341,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   c->allow_stream = !(flags & VC2HIP_FLAG_NO_STREAM);
   c->allow_pair = !(flags & VC2HIP_FLAG_NO_PAIR);
   c->allow_planes = !(flags & VC2HIP_FLAG_NO_BANDPLANES);
+  c->planes8_mode = (flags & VC2HIP_FLAG_PLANES8_NEVER) ? 2 : (flags & VC2HIP_FLAG_PLANES8_ALWAYS) ? 1 : 0;
   c->allow_heads = !(flags & VC2HIP_FLAG_NO_HEADS);
   c->allow_cbr_index = !(flags & VC2HIP_FLAG_NO_CBR_INDEX);
   c->two_pass_vbr = !(flags & VC2HIP_FLAG_SINGLE_PASS_VBR);
@@ -341,7 +354,10 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   c->own_stream = own;
   if (hipMalloc((void **)&c->d_err, 256 + 4096) != hipSuccess || // error word, then the LD search tables
      
-      hipHostMalloc((void **)&c->h_err, sizeof(unsigned)) != hipSuccess) { delete c; return VC2HIP_EHIP; }
+      hipHostMalloc((void **)&c->h_err, sizeof(unsigned)) != hipSuccess ||
+      hipMalloc((void **)&c->d_stat, 64) != hipSuccess || hipHostMalloc((void **)&c->h_stat, 64 * 8) != hipSuccess ||
+      hipEventCreateWithFlags(&c->stat_ev, hipEventDisableTiming) != hipSuccess) { delete c; return VC2HIP_EHIP; }
+  (void)hipMemsetAsync(c->d_stat, 0, 64, c->stream);
   (void)hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream);
   QuantTables t;
   make_tables(t);
@@ -372,6 +388,9 @@ extern "C" void vc2hip_destroy(vc2hip_ctx *c) {
   for (auto &b : c->buf) if (b.p) (void)hipFree(b.p);
   if (c->d_err) (void)hipFree(c->d_err);
   if (c->h_err) (void)hipHostFree(c->h_err);
+  if (c->h_stat) (void)hipHostFree(c->h_stat);
+  if (c->d_stat) (void)hipFree(c->d_stat);
+  if (c->stat_ev) (void)hipEventDestroy(c->stat_ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -775,7 +794,8 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
                        const long long dst_stride[3], bool dst_raw, const vc2hip_picture_format *f,
                        bool s16 = false, int32_t *store_wide = nullptr, const BandPlanes *bp = nullptr,
                        long long store_stride = 0, unsigned *stream_mask = nullptr, const HeadSplit *hs = nullptr, int head_level = 1 << 30,
-                       unsigned *fast_mask = nullptr) {
+                       unsigned *fast_mask = nullptr, unsigned *tail_mask = nullptr) {
+  if (tail_mask) *tail_mask = 0;
   if (stream_mask) *stream_mask = 0;
   if (fast_mask) *fast_mask = 0;
   auto level_params = [&](LevelParams &p, int level) {
@@ -785,6 +805,7 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
       for (int k = 0; k < 3; ++k) if (g.c[k].ph) { p.rec_stride[k] = hs->n[k]; p.coef_off[k] = (int)hs->base[k]; }
     p.store = store; p.store_stride = store_stride ? store_stride : (long long)g.ys * g.xs * g.slice_coefs;
     for (int k = 0; k < 3; ++k) p.bp_base[k] = (bp && level < bp->levels && g.c[k].ph) ? bp->base[k][level] : -1;
+    p.bp8 = bp && level < bp->levels && bp->bytes8;
     p.store_wide = store_wide;
     p.qidx = qidx; p.err = c->d_err; p.dequant = dequant;
     p.ll_from_store = (level == g.depth - 1) && !ll_ready;
@@ -833,7 +854,7 @@ static int run_inverse(vc2hip_ctx *c, const Geom &g, int kernel, int n, void *st
       LevelParams ps = p;
       const size_t lds = vc2_stream_level_applicable(ps, kernel, fin, true, s16, n);
       if (lds) {
-        if (stream_mask) { *stream_mask |= 1u << level; continue; }
+        if (stream_mask) { *stream_mask |= 1u << level; if (tail_mask && ps.st_tail) *tail_mask |= 1u << level; continue; }
         int rc = vc2_launch_inverse_stream(c->L, kernel, fin, ps, n, s16, lds, c->stream);
         if (rc) return set_err(c, rc, "invalid wavelet kernel");
         continue;
@@ -1616,7 +1637,9 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     unsigned mask = 0;
     LLPlanes none;
     memset(&none, 0, sizeof none);
-    (void)run_inverse(c, g, cp->kernel, n, nullptr, nullptr, qm, true, ld, none, dst, ds, true, f, s16, nullptr, nullptr, 0, &mask);
+    unsigned tails = 0;
+    (void)run_inverse(c, g, cp->kernel, n, nullptr, nullptr, qm, true, ld, none, dst, ds, true, f, s16, nullptr, nullptr, 0, &mask, nullptr, 1 << 30,
+                      nullptr, &tails);
     for (int k = 0; k < 3; ++k) bp.from[k] = g.c[k].ph ? g.c[k].sh * g.c[k].sw : 0;
     for (int l = 0; l < VC2_BP_MAX && l < g.depth - 1 && (mask >> l & 1); ++l) {
       bool ok = true;
@@ -1641,6 +1664,26 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
       bp.levels = l + 1;
     }
     if (sstride >= (1ll << 31)) { memset(&bp, 0, sizeof bp); sstride = (long long)ns * g.slice_coefs; } // 32-bit element offsets
+    // One byte per plane coefficient?  What the previous batch of this context looked like decides (its lengths and its
+    // escape count arrive through pinned memory behind an event: no wait here): small coefficients <=> few payload bits per
+    // sample.  The planes keep their places and their wide elements: only the bytes of a plane's narrow elements halve.
+    if (bp.levels) {
+      if (c->stat_pending && hipEventQuery(c->stat_ev) == hipSuccess) {
+        c->stat_pending = false;
+        double bytes = 0;
+        for (int k = 0; k < c->stat_n; ++k) bytes += (double)c->h_stat[1 + k];
+        const double bits = c->stat_n ? 8.0 * bytes / (c->stat_n * c->stat_samples) : 99.0;
+        const double esc = (double)c->h_stat[0] * 8.0 / (std::max(1, c->stat_n) * c->stat_samples); // (pieces of eight coefficients)
+#ifdef VC2HIP_ABLATE
+        if (getenv("VC2HIP_PLANES8_DEBUG")) fprintf(stderr, "planes8: previous batch %d pictures, %.2f payload bits per sample, %s planes, escape pieces %.4f%%\n", c->stat_n, bits, c->stat_was8 ? "byte" : "16-bit", 100 * esc);
+#endif
+        if (c->stat_was8 && esc > 0.005) c->planes8_on = false;       // more than 0.5 % of the pieces carried an escape
+        else if (!c->stat_was8 || esc < 0.002) c->planes8_on = bits < (c->planes8_on ? 6.5 : 6.0);
+      }
+      bool b8 = c->planes8_mode == 1 || (c->planes8_mode == 0 && c->planes8_on);
+      for (int l = 0; l < bp.levels; ++l) if (tails >> l & 1) b8 = false; // (the TAIL instantiations read 16-bit planes only)
+      bp.bytes8 = b8;
+    }
   }
   // Record heads (HeadSplit, vc2hip_internal.h): the levels below the streaming ones, when all of them run on the tile
   // kernels, read their coefficients from dense per-component arrays behind the records (and band planes)
@@ -1711,7 +1754,20 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
     p.prefix = cp->prefix; p.scalar = cp->scalar; p.err = c->d_err;
     p.bp = bp; p.hs = hs; p.xs = g.xs;
+    p.stats = c->d_stat;
+    const bool track = bp.levels && c->planes8_mode == 0 && !c->stat_pending;
+    if (track) HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 8, c->stream));
     vc2_launch_unpack(c->L, p, n, c->stream);
+    if (track) { // this batch's escape count and payload lengths for the next call's choice
+      c->stat_n = std::min(n, 60);
+      c->stat_samples = 0;
+      for (int k = 0; k < 3; ++k) c->stat_samples += (double)g.c[k].h * g.c[k].w;
+      c->stat_was8 = bp.bytes8 != 0;
+      HIPCHK(c, hipMemcpyAsync(c->h_stat, c->d_stat, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_stat + 1, d_lens, (size_t)c->stat_n * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->stat_ev, c->stream));
+      c->stat_pending = true;
+    }
   } else {
     // DecodeStream.cpp:312, :331-333: per-slice sizes from the picture byte budget
     int32_t *d_sb; uint32_t *d_so; uint64_t total;

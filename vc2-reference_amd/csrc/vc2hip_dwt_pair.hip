@@ -1075,8 +1075,9 @@ int pair_slots(int kernel, bool edge, bool inverse, bool store16, size_t lds) {
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int v;
-  if (inverse) v = store16 ? pair_slots_dispatch<true, int16_t>(kernel, edge, lds) : pair_slots_dispatch<true, int32_t>(kernel, edge, lds);
-  else v = store16 ? pair_slots_dispatch<false, int16_t>(kernel, edge, lds) : pair_slots_dispatch<false, int32_t>(kernel, edge, lds);
+  if (!store16) v = 0;
+  else if (inverse) v = pair_slots_dispatch<true, int16_t>(kernel, edge, lds);
+  else v = pair_slots_dispatch<false, int16_t>(kernel, edge, lds);
   cache[key] = v;
   return v;
 }
@@ -1129,6 +1130,8 @@ size_t vc2_pair_applicable(PairParams &pp, int kernel, bool edge, bool inverse, 
   const LevelParams &pb = pp.b;
   const int elem = store16 ? 2 : 4;
   const bool b_last = inverse ? pb.ll_from_store != 0 : pb.ll_to_store != 0;
+  if (inverse && (p.bp8 || pb.bp8)) return 0; // (byte band planes: read by the one-level kernels only)
+  if (!store16) return 0; // (the int32 store -- fine-grained calls, the STORE32 test variant -- keeps one launch per level: half of this file's compile time)
   size_t imgA = 16, imgB = 16;
   p.st_tail = 0;
   p.st_segmax = 0;
@@ -1242,8 +1245,8 @@ size_t vc2_pair_applicable(PairParams &pp, int kernel, bool edge, bool inverse, 
   return lds;
 }
 int vc2_launch_forward_pair(Launcher &L, int kernel, bool first, const PairParams &pp, int n, bool store16, size_t lds, hipStream_t s) {
-  return store16 ? pair_dispatch<false, int16_t>(L, kernel, first, pp, n, lds, s) : pair_dispatch<false, int32_t>(L, kernel, first, pp, n, lds, s);
+  return store16 ? pair_dispatch<false, int16_t>(L, kernel, first, pp, n, lds, s) : VC2HIP_EINVAL;
 }
 int vc2_launch_inverse_pair(Launcher &L, int kernel, bool final_level, const PairParams &pp, int n, bool store16, size_t lds, hipStream_t s) {
-  return store16 ? pair_dispatch<true, int16_t>(L, kernel, final_level, pp, n, lds, s) : pair_dispatch<true, int32_t>(L, kernel, final_level, pp, n, lds, s);
+  return store16 ? pair_dispatch<true, int16_t>(L, kernel, final_level, pp, n, lds, s) : VC2HIP_EINVAL;
 }

@@ -292,9 +292,13 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
   return v < 0 ? (int)(0u - (unsigned)a) : a;
 }
 
-template <int K, bool FINAL, class ST, bool TAIL = false>
+// BP8 (round 5): the level's band planes hold ONE BYTE per coefficient (vc2hip_internal.h BandPlanes::bytes8: quantised
+// coefficients are small; -128 is the sentinel, the value then sits in the wide array at the element's index as for the
+// 16-bit sentinel).  This kernel runs at the memory system's pace: its band rows are half of what it reads.
+template <int K, bool FINAL, class ST, bool TAIL = false, bool BP8 = false>
 __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) void k_inv_stream(const LevelParams p) {
   using S_ = St<ST>;
+  static_assert(!BP8 || (S_::narrow && !TAIL), "byte planes: with the 16-bit store, whole blocks");
   using VE = VEng<K, true>;
   using T = typename VE::T;
   constexpr int RL = RLK<K>;
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   // slower -- 0.75 against 0.55 ms per 16 UHD pictures: its 17 KiB image per wavefront halves the occupancy, and this
   // kernel lives on occupancy.)
   typedef typename std::conditional<S_::narrow, uint2, uint4>::type Q4; // four store elements
-  Q4 bq[PFI][4];
+  Q4 bq[PFI][BP8 ? 1 : 4];
+  unsigned bq8[PFI][BP8 ? 4 : 1]; // (BP8) the four bytes of bands 1..3
   // element index of the lane's four coefficients of band b in band row m: in the slice records (a slice's band block
   // row is bsw coefficients: neighbouring lanes read neighbouring 8 / 16 bytes of it, then the next slice's record), or,
   // when the decoder laid this level's bands out as planes (BandPlanes), simply row m, column 4 * chunk of plane b
@@ -353,7 +358,9 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (b == 0 && !p.ll_from_store) bq[slot][0] = *(const Q4 *)(llp + mul24z(m, ow));
-      else bq[slot][b] = *(const Q4 *)(store + rec_at(m, b));
+      else if constexpr (BP8) { // byte address of element e of a plane that starts at element bp: 2 bp + (e - bp)
+        if (b > 0) bq8[slot][b] = *(const unsigned *)((const char *)store + rec_at(m, b) + (size_t)bp);
+      } else bq[slot][b] = *(const Q4 *)(store + rec_at(m, b));
     }
   };
   // quantiser constants of the lane's slice in block row sv, per band
@@ -373,8 +380,16 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   auto band4 = [&](int m, int slot, int b) __attribute__((always_inline)) -> int4 {
     const bool from_plane = b == 0 && !p.ll_from_store;
     int v[4];
-    if constexpr (S_::narrow) {
-      const uint2 w = bq[slot][b];
+    if (BP8 && b > 0) {
+      const unsigned w = bq8[slot][b];
+      v[0] = __builtin_amdgcn_sbfe((int)w, 0, 8); v[1] = __builtin_amdgcn_sbfe((int)w, 8, 8); v[2] = __builtin_amdgcn_sbfe((int)w, 16, 8); v[3] = (int)w >> 24;
+      if (min(min(v[0], v[1]), min(v[2], v[3])) == -128) {
+        const int32_t *wq = wide + rec_at(m, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (v[k] == -128) v[k] = wq[k];
+      }
+    } else if constexpr (S_::narrow) {
+      const uint2 w = bq[slot][BP8 ? 0 : b];
       v[0] = vc2_lo16(w.x); v[1] = vc2_hi16(w.x); v[2] = vc2_lo16(w.y); v[3] = vc2_hi16(w.y);
       if (min(min(v[0], v[1]), min(v[2], v[3])) == VC2_ST_SENTINEL) {
         const int32_t *wq = from_plane ? llp_w + mul24z(m, ow) : wide + rec_at(m, b);
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
         for (int k = 0; k < 4; ++k) if (v[k] == VC2_ST_SENTINEL) v[k] = wq[k];
       }
     } else {
-      const uint4 w = bq[slot][b];
+      const uint4 w = bq[slot][BP8 ? 0 : b];
       v[0] = (int)w.x; v[1] = (int)w.y; v[2] = (int)w.z; v[3] = (int)w.w;
     }
     if (p.dequant && !from_plane) {
@@ -404,7 +419,28 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   // the lane's four coefficients of all four bands of row m (escapes resolved, dequantised): ONE test for escapes and
   // ONE for the dequantiser's fast domain over the sixteen values -- a branch per band cost more than the arithmetic
   auto bands16 = [&](int m, int slot, int (&v)[16]) __attribute__((always_inline)) {
-    if constexpr (S_::narrow) {
+    if constexpr (BP8) { // LL: 16-bit elements of its plane (sentinel -32768); the bands: bytes (sentinel -128)
+      const uint2 w0 = bq[slot][0];
+      v[0] = vc2_lo16(w0.x); v[1] = vc2_hi16(w0.x); v[2] = vc2_lo16(w0.y); v[3] = vc2_hi16(w0.y);
+#pragma unroll
+      for (int b = 1; b < 4; ++b) {
+        const unsigned w = bq8[slot][b];
+        v[4 * b] = __builtin_amdgcn_sbfe((int)w, 0, 8); v[4 * b + 1] = __builtin_amdgcn_sbfe((int)w, 8, 8);
+        v[4 * b + 2] = __builtin_amdgcn_sbfe((int)w, 16, 8); v[4 * b + 3] = (int)w >> 24;
+      }
+      int low0 = min(min(v[0], v[1]), min(v[2], v[3])), low = v[4];
+#pragma unroll
+      for (int k = 5; k < 16; ++k) low = min(low, v[k]);
+      if (low0 == VC2_ST_SENTINEL || low == -128) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bool from_plane = b == 0 && !p.ll_from_store;
+          const int32_t *wq = from_plane ? llp_w + mul24z(m, ow) : wide + rec_at(m, b);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (v[4 * b + k] == (b == 0 ? VC2_ST_SENTINEL : -128)) v[4 * b + k] = wq[k];
+        }
+      }
+    } else if constexpr (S_::narrow) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const uint2 w = bq[slot][b];
@@ -422,7 +458,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
           for (int k = 0; k < 4; ++k) if (v[4 * b + k] == VC2_ST_SENTINEL) v[4 * b + k] = wq[k];
         }
       }
-    } else {
+    } else if constexpr (!BP8) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const uint4 w = bq[slot][b];
@@ -617,6 +653,14 @@ void launch_stream(Launcher &L, const LevelParams &p, int n_pictures, size_t lds
 #endif
   if constexpr (INV) {
     vc2_prof_begin(L, EDGE ? "idwt_level_final" : "idwt_level", s);
+    if constexpr (std::is_same<ST, int16_t>::value && !TAIL) {
+      if (pw.bp8) {
+        vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST, TAIL, true>, std::max<size_t>(64 * 1024, lds_wg));
+        VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST, TAIL, true>), grid, block, lds_wg, s, pw);
+        vc2_prof_end(L, s);
+        return;
+      }
+    }
     vc2_allow_lds((const void *)k_inv_stream<K, EDGE, ST, TAIL>, std::max<size_t>(64 * 1024, lds_wg));
     VC2_LAUNCH(L, (k_inv_stream<K, EDGE, ST, TAIL>), grid, block, lds_wg, s, pw);
   } else {

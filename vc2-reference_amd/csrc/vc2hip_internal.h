@@ -123,6 +123,7 @@ struct LevelParams {
   // inverse, streaming kernels: element offset (from the picture's store) of this level's HL band plane, LH and HH behind
   // it, when the decoder keeps the level's bands as planes (BandPlanes below); -1: in the slice records
   long long bp_base[3];
+  int bp8;                      // those planes hold one byte per coefficient (BandPlanes::bytes8)
 };
 
 // Two consecutive levels in one launch (vc2hip_dwt_pair.hip): `a` is the finer level exactly as the one-level kernels see
@@ -200,6 +201,9 @@ struct PackParams {
 constexpr int VC2_BP_MAX = 3;
 struct BandPlanes {
   int levels;                       // finest levels kept as planes (0: none)
+  int bytes8;                       // round 5: a plane element is ONE BYTE (quantised coefficients are small; -128 = escape: the value is in
+                                    // the wide array at the element's index, like the 16-bit sentinel's).  A plane that starts at element
+                                    // `base` of the picture's store keeps its start; element e of it lives at byte 2 * base + (e - base).
   int from[3];                      // first coefficient of a component record that lives in a plane
   long long base[3][VC2_BP_MAX];    // element offset, from the picture's store, of band 1 (HL) of level l; LH, HH follow
   int ow[3][VC2_BP_MAX], np[3][VC2_BP_MAX];     // width / height of a band plane
@@ -234,6 +238,7 @@ struct UnpackParams {
   BandPlanes bp;
   HeadSplit hs;
   int xs;                     // slices across
+  unsigned long long *stats;  // [0]: pieces that carried an escape from a byte plane (k_hq_unpack16<true>; feedback for the next batch's layout)
   int debug_skip;             // timing experiments only (VC2HIP_DEBUG_UNPACK, -DVC2HIP_ABLATE): 1 stream reads from a hot 16 KiB window, 2 no stores
 };
 

@@ -2015,13 +2015,15 @@ struct Reader32 {
 // Where coefficient j of a component record lives when the finest levels are kept as band planes (BandPlanes):
 // level l (0 = finest) holds the last 3 * 4^-l ... of the record; inside it band, block row, column.  Returns the element
 // offset from the picture's store of (slice sy, sx)'s coefficient, or -1 for the slice record.
-__device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int n, int j, int sy, int sx, int &lw, int &ow) {
+__device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int n, int j, int sy, int sx, int &lw, int &ow, int *lbase = nullptr) {
   lw = ow = 0;
+  if (lbase) *lbase = 0;
   if (j < bp.from[comp]) return -1;
   int l = 0, start = n - (3 << (bp.lbsh[comp][0] + bp.lbsw[comp][0]));
   while (j < start) { ++l; start -= 3 << (bp.lbsh[comp][l] + bp.lbsw[comp][l]); }
   const int lh = bp.lbsh[comp][l], e = j - start;
   lw = bp.lbsw[comp][l]; ow = bp.ow[comp][l];
+  if (lbase) *lbase = (int)bp.base[comp][l]; // (byte planes: element e of the plane lives at byte 2 * base + (e - base) = e + base)
   const int b = e >> (lh + lw), rem = e & ((1 << (lh + lw)) - 1), r = rem >> lw, c = rem & ((1 << lw) - 1);
   return (int)bp.base[comp][l] + (b * bp.np[comp][l] + (sy << lh) + r) * ow + (sx << lw) + c; // (a picture's store is < 2^31 elements)
 }
@@ -2032,6 +2034,34 @@ __device__ __forceinline__ int band_plane_at(const BandPlanes &bp, int comp, int
 #ifndef VC2_UNP_BRANCHLESS
 #define VC2_UNP_BRANCHLESS 1
 #endif
+// Eight coefficients of a staging row (four dwords of 16-bit pairs) as the eight bytes of a byte plane (BandPlanes::bytes8).
+// A value outside -127 .. 127 leaves the sentinel -128 and its value in the wide array at the element's index `at`; the
+// 16-bit sentinel (a value beyond 16 bits) has its wide value already (escape()) and only changes sentinels.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+// (wide: the picture's wide array; at: the element index of the piece's first coefficient; row2: 0, or -- a piece of two block
+// rows of four -- the distance of its second row; the address arithmetic stays in the rare path)
+__device__ __forceinline__ uint2 unp_bytes8(int4 v, int32_t *wide, int at, int row2, unsigned long long *stats) {
+  auto as2 = [](int x) -> us2_t { union { int i; us2_t u; } c; c.i = x; return c.u; };
+  const us2_t k = {127, 127};
+  const us2_t m = __builtin_elementwise_max(__builtin_elementwise_max(as2(v.x) + k, as2(v.y) + k), __builtin_elementwise_max(as2(v.z) + k, as2(v.w) + k));
+  if (__builtin_expect(max((unsigned)m.x, (unsigned)m.y) > 254u, 0)) {
+    if (stats) atomicAdd(stats, 1ull); // (feedback for the next batch's choice of layout: vc2hip_api.hip)
+    int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      int32_t *wq = wide + (size_t)at + (row2 && d >= 2 ? row2 - 4 : 0) + 2 * d;
+      int lo = vc2_lo16((unsigned)w[d]), hi = vc2_hi16((unsigned)w[d]);
+      if ((unsigned)(lo + 127) > 254u) { if (lo != VC2_ST_SENTINEL) wq[0] = lo; lo = -128; }
+      if ((unsigned)(hi + 127) > 254u) { if (hi != VC2_ST_SENTINEL) wq[1] = hi; hi = -128; }
+      w[d] = (int)vc2_pack16(lo, hi);
+    }
+    v = make_int4(w[0], w[1], w[2], w[3]);
+  }
+  // the low bytes of the four 16-bit pairs
+  return make_uint2(__builtin_amdgcn_perm((unsigned)v.y, (unsigned)v.x, 0x06040200u), __builtin_amdgcn_perm((unsigned)v.w, (unsigned)v.z, 0x06040200u));
+}
+
+template <bool BP8>
 __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const UnpackParams p) {
   constexpr int UNP_N = VC2_UNP16_N, UNP_PITCH = UNP_N + 8, PR = UNP_N / 8; // shorts per staging row (8 of slack), 16-byte aligned rows; pieces per row
   __shared__ __attribute__((aligned(16))) short stage[VC2_UNP16_WAVES][64 * UNP_PITCH];
@@ -2196,8 +2226,8 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
         const int j0 = base + 8 * q;
         if (8 * q >= room) break;
         if (j0 < p.bp.from[comp]) { ++q; continue; }
-        int lw, ow;
-        int at = band_plane_at(p.bp, comp, n, j0, sy, sx, lw, ow); // (lw, ow: the same in every lane)
+        int lw, ow, lbase;
+        int at = band_plane_at(p.bp, comp, n, j0, sy, sx, lw, ow, &lbase); // (lw, ow, lbase: the same in every lane)
         if (!active) at = -1;
         lw = __builtin_amdgcn_readfirstlane(lw);
         const int lp = lw - 3, P = lw >= 4 ? 1 << lp : 1; // pieces per block row
@@ -2207,15 +2237,33 @@ __global__ __launch_bounds__(64 * VC2_UNP16_WAVES) void k_hq_unpack16(const Unpa
             const int at_t = __shfl(at, sl);
             if (at_t >= 0) {
               const int4 v = *(const int4 *)(sw + sl * UNP_PITCH + 8 * (q + pp));
+              if constexpr (BP8) {
+                const uint2 b8 = unp_bytes8(v, p.store_wide + (size_t)pic * p.store_stride, at_t + 8 * pp, 0, p.stats);
+                const v2i vb = {(int)b8.x, (int)b8.y};
+                char *dst = (char *)((int16_t *)p.store + (size_t)pic * p.store_stride) + (size_t)(at_t + 8 * pp) + (size_t)lbase;
+                __builtin_nontemporal_store(vb, (__attribute__((address_space(1))) v2i *)(size_t)dst);
+              } else {
               const v4i vv = {v.x, v.y, v.z, v.w};
               int16_t *dst = (int16_t *)p.store + (size_t)pic * p.store_stride + (size_t)(at_t + 8 * pp);
               __builtin_nontemporal_store(vv, (__attribute__((address_space(1))) v4i *)(size_t)dst);
+              }
             }
           }
           q += P;
           continue;
         }
-        if (at >= 0) {
+        if (BP8 && at >= 0) {
+          const int4 v = *(const int4 *)(st + 8 * q);
+          char *dst = (char *)((int16_t *)p.store + (size_t)pic * p.store_stride) + (size_t)at + (size_t)lbase;
+          const uint2 b8 = unp_bytes8(v, p.store_wide + (size_t)pic * p.store_stride, at, lw >= 3 ? 0 : ow, p.stats);
+          if (lw >= 3) {
+            const v2i vb = {(int)b8.x, (int)b8.y};
+            __builtin_nontemporal_store(vb, (__attribute__((address_space(1))) v2i *)(size_t)dst);
+          } else { // two rows of 4
+            __builtin_nontemporal_store((int)b8.x, (__attribute__((address_space(1))) int *)(size_t)dst);
+            __builtin_nontemporal_store((int)b8.y, (__attribute__((address_space(1))) int *)(size_t)(dst + ow));
+          }
+        } else if (at >= 0) {
           int16_t *dst = (int16_t *)p.store + (size_t)pic * p.store_stride + (size_t)at;
           const int4 v = *(const int4 *)(st + 8 * q);
           if (lw >= 3) {
@@ -2251,10 +2299,13 @@ void vc2_launch_unpack(Launcher &L, const UnpackParams &p0, int n_pictures, hipS
   if (p.store16) {
     constexpr int T = 64 * VC2_UNP16_WAVES;
     const int nblk = (p.n_slices + T - 1) / T;
+    const bool b8 = p.bp.levels && p.bp.bytes8;
 #if VC2_UNP_ORDER == 2
-    VC2_LAUNCH(L, k_hq_unpack16, dim3(nblk, n_pictures, 3), dim3(T), 0, s, p);
+    if (b8) VC2_LAUNCH(L, k_hq_unpack16<true>, dim3(nblk, n_pictures, 3), dim3(T), 0, s, p);
+    else VC2_LAUNCH(L, k_hq_unpack16<false>, dim3(nblk, n_pictures, 3), dim3(T), 0, s, p);
 #else
-    VC2_LAUNCH(L, k_hq_unpack16, dim3(((nblk + 7) / 8) * 8 * 3, n_pictures), dim3(T), 0, s, p);
+    if (b8) VC2_LAUNCH(L, k_hq_unpack16<true>, dim3(((nblk + 7) / 8) * 8 * 3, n_pictures), dim3(T), 0, s, p);
+    else VC2_LAUNCH(L, k_hq_unpack16<false>, dim3(((nblk + 7) / 8) * 8 * 3, n_pictures), dim3(T), 0, s, p);
 #endif
     vc2_prof_end(L, s);
     return;
