@@ -1864,6 +1864,15 @@ void vc2_upload_unpack_lut(hipStream_t s) {
 #ifndef VC2_UNP_TAIL16
 #define VC2_UNP_TAIL16 1
 #endif
+#ifndef VC2_UNP_SELECT
+// 0: the round-4 refill.  1: the requested words selected in place instead of shifted down a piece per refill.  2: and the
+// request and its wait written as asm (Reader32::skip's first form), which does move the wait from two instructions behind
+// the request to the next refill of any lane -- and is SLOWER: 32 UHD pictures 0.446 -> 0.466 ms, 4 UHD-2 0.253 -> 0.267,
+// 32 HD 0.155 -> 0.166 (same box, alternating; 1: 0.434 -> 0.492, ten more registers and a wavefront less per SIMD).  At six
+// wavefronts per SIMD the others fill a wavefront's wait; the twelve selections and two wave-uniform tests per refill cost
+// more than it.  Kept as the record of VERDICT round 4, item 4; bit-exact (tests/test_gpu_parity.py, test_gpu_wide.py).
+#define VC2_UNP_SELECT 0
+#endif
 #ifndef VC2_UNP_PAIR
 #define VC2_UNP_PAIR 2 // the stream's requests FOUR at a time (64 adjacent bytes) on every fourth refill; 1: two on every second; 0: one per refill (see Reader32::skip)
 #endif
@@ -1880,6 +1889,10 @@ struct Reader32 {
   int pairs;               // parity of the refills: the odd ones only shift (VC2_UNP_PAIR == 2: their count mod 4)
 #if VC2_UNP_PAIR == 2
   unsigned r0, r1, r2, r3, s0, s1, s2, s3; // FOUR requests (64 adjacent bytes) on every fourth refill
+#if VC2_UNP_SELECT == 2
+  typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+  u4_t M, O, R, S; // (the same sixteen words as whole pieces: the destinations of the requests written in skip(); m0 .. s3 unused)
+#endif
 #endif
 #endif
 #endif
@@ -1950,11 +1963,71 @@ struct Reader32 {
 #if VC2_UNP_PAIR == 2
     fetch4(pay, r0, r1, r2, r3);
     fetch4(pay, s0, s1, s2, s3);
+#if VC2_UNP_SELECT == 2
+    M = u4_t{m0, m1, m2, m3}; O = u4_t{o0, o1, o2, o3}; R = u4_t{r0, r1, r2, r3}; S = u4_t{s0, s1, s2, s3};
+#endif
 #endif
 #endif
 #endif
   }
   __device__ __forceinline__ unsigned top() const { return (unsigned)(acc >> 32); }
+#if VC2_UNP_SELECT == 2 && VC2_UNP_PAIR == 2 && VC2_UNP_DEEP
+  // Round 5: request and wait written as asm, at the top level of the turn (the round-4 form below says what the queue
+  // is).  Left to the compiler, the loads of a request go to temporary registers that are copied into the queue's behind
+  // s_waitcnt vmcnt(0), two instructions behind the request: the wavefront stood still for the whole trip to memory whenever
+  // one of its lanes requested.  Here the sixteen requested words stay where the loads put them (four pieces M, O, R, S; the
+  // next four words are SELECTED by the count of refills instead of shifted down), the asm statements take the pieces as
+  // read-write operands -- the compiler knows nothing of a pending load and has no copy to make -- and the wait stands in
+  // front of the only reader, the selection at any lane's next refill: about a turn behind the request.  The requesting
+  // lanes are an EXEC mask inside the statement; the statements themselves stand under wave-uniform tests only.
+  // (The compiler's own counted waits stay right: the counter is in order, and its count of the operations behind one of
+  // its own loads can only be too small with these four among them -- it waits longer, never shorter.)
+  __device__ __forceinline__ void skip(const uint8_t *pay, int n) { // n <= 32
+    acc <<= n;
+    have -= n;
+    bool refill = false;
+    if (have <= 32) {
+      acc |= (unsigned long long)q0 << (32 - have);
+      have += 32;
+      q0 = q1; q1 = q2; q2 = q3;
+      refill = --qn == 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(refill) == 0ull) return; // (wave-uniform)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(M), "+v"(O), "+v"(R), "+v"(S));
+    bool request = false;
+    if (refill) {
+      q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4;
+      // (two bit tests per word: a chain of comparisons with 0, 1, 2 becomes a table in scratch memory)
+      const bool b0 = pairs & 1, b1 = pairs & 2;
+      auto pick = [&](unsigned m, unsigned o, unsigned r, unsigned s) -> unsigned { const unsigned lo = b0 ? o : m, hi = b0 ? s : r; return b1 ? hi : lo; };
+      n0 = pick(M.x, O.x, R.x, S.x); n1 = pick(M.y, O.y, R.y, S.y); n2 = pick(M.z, O.z, R.z, S.z); n3 = pick(M.w, O.w, R.w, S.w);
+      request = ((++pairs) & 3) == 0;
+    }
+    const bool whole = request && left >= 512; // four whole pieces: one test for the four requests
+    const unsigned long long wmask = __builtin_amdgcn_ballot_w64(whole);
+    if (wmask) { // (wave-uniform)
+#ifdef VC2HIP_ABLATE
+      const unsigned o_ = off & dbg_mask;
+#else
+      const unsigned o_ = off;
+#endif
+      unsigned long long saved;
+      asm volatile("s_and_saveexec_b64 %4, %7\n\t"
+                   "global_load_dwordx4 %0, %5, %6\n\tglobal_load_dwordx4 %1, %5, %6 offset:16\n\t"
+                   "global_load_dwordx4 %2, %5, %6 offset:32\n\tglobal_load_dwordx4 %3, %5, %6 offset:48\n\t"
+                   "s_mov_b64 exec, %4"
+                   : "+v"(M), "+v"(O), "+v"(R), "+v"(S), "=&s"(saved) : "v"(o_), "s"(pay), "s"(wmask) : "scc");
+    }
+    if (whole) { off += 64; left -= 512; }
+    else if (request) { // the stream's end: piece by piece (fetch4's other forms)
+      unsigned a, b, c, d;
+      fetch4(pay, a, b, c, d); M = u4_t{a, b, c, d};
+      fetch4(pay, a, b, c, d); O = u4_t{a, b, c, d};
+      fetch4(pay, a, b, c, d); R = u4_t{a, b, c, d};
+      fetch4(pay, a, b, c, d); S = u4_t{a, b, c, d};
+    }
+  }
+#else
   __device__ __forceinline__ void skip(const uint8_t *pay, int n) { // n <= 32
     acc <<= n;
     have -= n;
@@ -1976,10 +2049,19 @@ struct Reader32 {
 #if VC2_UNP_PAIR == 2
       if (--qn == 0) {
         q0 = __builtin_bswap32(n0); q1 = __builtin_bswap32(n1); q2 = __builtin_bswap32(n2); q3 = __builtin_bswap32(n3); qn = 4;
+#if VC2_UNP_SELECT
+        {
+          // (two bit tests per word: a chain of comparisons with 0, 1, 2 becomes a table in scratch memory)
+          const bool b0 = pairs & 1, b1 = pairs & 2;
+          auto pick = [&](unsigned m, unsigned o, unsigned r, unsigned s) -> unsigned { const unsigned lo = b0 ? o : m, hi = b0 ? s : r; return b1 ? hi : lo; };
+          n0 = pick(m0, o0, r0, s0); n1 = pick(m1, o1, r1, s1); n2 = pick(m2, o2, r2, s2); n3 = pick(m3, o3, r3, s3);
+        }
+#else
         n0 = m0; n1 = m1; n2 = m2; n3 = m3;
         m0 = o0; m1 = o1; m2 = o2; m3 = o3;
         o0 = r0; o1 = r1; o2 = r2; o3 = r3;
         r0 = s0; r1 = s1; r2 = s2; r3 = s3;
+#endif
         if (((++pairs) & 3) == 0) {
           if (left >= 512) { // four whole pieces: one test for the four requests
 #ifdef VC2HIP_ABLATE
@@ -2010,6 +2092,7 @@ struct Reader32 {
 #endif
     }
   }
+#endif
 };
 
 // Where coefficient j of a component record lives when the finest levels are kept as band planes (BandPlanes):
