@@ -55,9 +55,6 @@ static bool cbr16_plan(const CbrParams &p, unsigned *lane8) {
   return runs[0] >= 40 && runs[1] >= 20; // (small slices: the lanes would idle; k_cbr_search_reg)
 }
 
-#ifndef VC2_CBR16_MULTI
-#define VC2_CBR16_MULTI 1
-#endif
 #ifndef VC2_CBR16_WPE
 #define VC2_CBR16_WPE 1
 #endif
@@ -171,77 +168,7 @@ __global__ __launch_bounds__(256, VC2_CBR16_WPE) void k_cbr_search16(const CbrPa
     return (long long)__builtin_amdgcn_readlane(lo, 63) + ((long long)__builtin_amdgcn_readlane(hi, 63) << 24) - (64ll << 35);
   };
 
-#if VC2_CBR16_MULTI
-  // Round 5: THREE neighbouring indices per measurement.  A slice's search is a chain of about five
-  // dependent measurements -- each two scans deep, with readlanes and ballots behind them -- and the next index depends on
-  // the last answer; most slices end within one index of their predecessor's threshold.  Three indices measured side by
-  // side are independent chains the SIMD interleaves: the bracket usually closes in one pass, and so does the refinement.
-  // (Measured three at a time, an index the serial search would not have tried can raise `bad` -- a length beyond 255, a
-  // factor beyond the float domain: the slice then goes to the general kernel, which follows the reference's own walk.)
-  auto need3 = [&](int t0, int (&need)[3], bool &bad) { // indices t0, t0 + 1, t0 + 2 (all within 0 .. 126)
-    bad |= t0 + 2 - p.qm_min > 79;
-    int sy[3], ly[3], sc[3], lc[3], hb[3];
-    bool hnz[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int tq16 = 16 * (t0 + k);
-      const float ry = *(const float *)(tab + entry(tq16, m_y)), rc = *(const float *)(tab + entry(tq16, m_c)),
-                  rh = *(const float *)(tab + entry(tq16, m_h));
-      bits8u(fy, ry, has_y, sy[k], ly[k]);
-      bits8u(fc, rc, has_c, sc[k], lc[k]);
-      const int ebh = (int)__builtin_amdgcn_ubfe(__float_as_uint(__builtin_fmaf(fh, rh, 1.0f)), 23, 8);
-      hb[k] = has_h ? 2 * ebh + min(ebh, 128) - 380 : 0;
-      hnz[k] = has_h && ebh >= 128;
-    }
-    const unsigned long long u_lanes = runsC >= 64 ? ~0ull : ((1ull << runsC) - 1);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int pk1 = ((hc == 0 ? hb[k] : 0) << 16) | sy[k], pk2 = ((hc != 0 ? hb[k] : 0) << 16) | sc[k];
-      const int s1 = wave_incl_scan(pk1, lane), s2 = wave_incl_scan(pk2, lane);
-      const int e1 = s1 - pk1, e2 = s2 - pk2;
-      const int tot_hy = __builtin_amdgcn_readlane(s1, 63) >> 16;
-      const int tot_hu = __builtin_amdgcn_readlane(s2, 47) >> 16, tot_hv = (__builtin_amdgcn_readlane(s2, 63) >> 16) - tot_hu;
-      const int tot_bu = __builtin_amdgcn_readlane(s2, runsC - 1) & 0xFFFF;
-      const int end_yb = tot_hy + (e1 & 0xFFFF) + ly[k], end_yh = (e1 >> 16) + hb[k];
-      const int end_cb = (ccb == 1 ? tot_hu + (e2 & 0xFFFF) : tot_hv + (e2 & 0xFFFF) - tot_bu) + lc[k];
-      const int end_ch = (e2 >> 16) - (hc == 2 ? tot_hu : 0) + hb[k];
-      const unsigned long long b_y = __ballot(ly[k] != 0), h_y = __ballot(hnz[k] && hc == 0);
-      const unsigned long long b_c = __ballot(lc[k] != 0), h_c = __ballot(hnz[k] && hc != 0);
-      int n = comp_bytes(last_of(b_y, h_y, end_yb, end_yh), bad);
-      n += comp_bytes(last_of(b_c & u_lanes, h_c & 0x0000FFFF00000000ull, end_cb, end_ch), bad);
-      n += comp_bytes(last_of(b_c & ~u_lanes, h_c & 0xFFFF000000000000ull, end_cb, end_ch), bad);
-      need[k] = n;
-    }
-  };
-  // the luma error of indices t0, t0 + 1, t0 + 2; over[k]: index t0 + k is outside the float domain (an error if it is used)
-  auto yss3 = [&](int t0, long long (&e)[3], bool (&over)[3]) {
-    long long acc[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      over[k] = t0 + k - p.qm_min > 79;
-      acc[k] = 1ll << 35;
-      const uint4 ty = *(const uint4 *)(tab + entry(16 * (t0 + k), m_y)), th = *(const uint4 *)(tab + entry(16 * (t0 + k), m_h));
-      auto err2 = [&](float f, const uint4 &t) -> long long {
-        const unsigned q = (unsigned)(f * __uint_as_float(t.x));
-        const unsigned r = (__umul24(q, t.y) + __umul24(min(q, 1u), t.z)) >> 2;
-        const int d = (int)f - (int)r;
-        return (long long)__mul24(d, d);
-      };
-      if (has_y) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[k] += err2(fy[i], ty);
-      }
-      if (has_h && hc == 0) acc[k] += err2(fh, th);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int lo = seg_incl_scan<64>((int)(acc[k] & 0xFFFFFF), lane), hi = seg_incl_scan<64>((int)(acc[k] >> 24), lane);
-      e[k] = (long long)__builtin_amdgcn_readlane(lo, 63) + ((long long)__builtin_amdgcn_readlane(hi, 63) << 24) - (64ll << 35);
-    }
-  };
-#endif
-
-  // ---- the search of k_cbr_search_reg: threshold by monotonicity from the predecessor's, the reference's
+  // ---- the search of k_cbr_search_reg, unchanged: threshold by monotonicity from the predecessor's, the reference's
   // smallest trial for the error it would raise, then the refinement by the luma error
   bool bad = __any(out);
   int trial = 63, q = 127, delta = 64;
@@ -255,22 +182,6 @@ __global__ __launch_bounds__(256, VC2_CBR16_WPE) void k_cbr_search16(const CbrPa
     }
   } else if (!bad) {
     int lo = -1, hi = 127, step = 1, lowest = 127; // lo: the largest index known not to fit; hi: the smallest known to fit
-#if VC2_CBR16_MULTI
-    int t = min(max(guess - 1, 0), 124); // measures t, t + 1, t + 2: the predecessor's threshold in the middle
-    for (;;) {
-      int need[3];
-      need3(t, need, bad);
-      bad = __any(bad);
-      if (bad) break;
-      lowest = min(lowest, t);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { if (need[k] <= avail) hi = min(hi, t + k); else lo = max(lo, t + k); }
-      if (hi - lo <= 1) break;
-      if (hi == 127) { if (lo >= 126) break; t = min(124, lo + step); step *= 3; }
-      else if (lo < 0) { if (hi <= 0) break; t = max(0, hi - 2 - step); step *= 3; }
-      else t = min(max(((lo + hi) >> 1) - 1, 0), 124);
-    }
-#else
     int t = min(guess, 126);
     for (;;) {
       const int need = need_bytes(t, bad);
@@ -283,7 +194,6 @@ __global__ __launch_bounds__(256, VC2_CBR16_WPE) void k_cbr_search16(const CbrPa
       else if (lo < 0) { if (hi <= 0) break; t = max(0, hi - step); step *= 2; }
       else t = (lo + hi) >> 1;
     }
-#endif
     q = hi;
     if (!bad) { // the smallest trial of the reference's walk to this threshold
       int rt = 63, rd = 64, rmin = 127, rmax = 0;
@@ -294,28 +204,6 @@ __global__ __launch_bounds__(256, VC2_CBR16_WPE) void k_cbr_search16(const CbrPa
   }
   const int q_fit = q;
   if (!bad) {
-#if VC2_CBR16_MULTI
-    // q = the first index whose successor's error is not smaller (yss(q + 1) - yss(q) >= 0), from q_fit on
-    long long prev = 0;
-    bool first = true;
-    trial = q;
-    for (;;) {
-      long long e[3];
-      bool over[3];
-      yss3(trial, e, over);
-      int k = 0;
-      if (first) { prev = e[0]; bad |= over[0]; k = 1; first = false; }
-      bool done = false;
-      for (; k < 3 && !bad; ++k) { // e[k]: index trial + k, the successor of trial + k - 1
-        if (over[k]) { bad = true; break; }
-        if (e[k] - prev >= 0) { q = trial + k - 1; done = true; break; }
-        prev = e[k];
-      }
-      if (done || bad) break;
-      trial += 3;
-      // (prev = the error of index trial - 1; the next pass's three are all successors)
-    }
-#else
     trial = q;
     long long prev = yss(trial, bad), d;
     do {
@@ -326,7 +214,6 @@ __global__ __launch_bounds__(256, VC2_CBR16_WPE) void k_cbr_search16(const CbrPa
       prev = cur;
     } while (d < 0);
     q = trial - 1;
-#endif
   }
   if (lane == 0) p.qidx[(size_t)pic * p.n_slices + slice] = bad ? VC2_CBR_MARK : q;
   guess = bad ? -1 : q_fit;
