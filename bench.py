@@ -4,7 +4,7 @@
 A "step" = one pass of the hot path (encode_batch_dev then decode_batch_dev) over one batch of
 synthetic pictures that are already resident in HBM.  Workload at every N: BASELINE.json config 2
 (UHD-1 3840x2160 4:2:2 10-bit, HQ_ConstQ, DD97, 4 levels, slices -u 1 -a 2, q 16, scalar 2);
-each rank/GPU owns its own batch of 64 distinct pictures (frames are independent: weak scaling, no collective on the data
+each rank/GPU owns its own batch of 128 distinct pictures (frames are independent: weak scaling, no collective on the data
 path; --streams 2 cuts the batch over two HIP streams: +1.4 % on one MI355X, per-kernel durations then overlap).  Prints ONE JSON line on rank 0:
 
   value            encode+decode, device resident, K timed steps (barrier + synchronize on both sides)
@@ -198,11 +198,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64,
-                    help="pictures per GPU per step (all distinct).  64 since round 5: measured on one box 48 / 64 / 80 / 112 / 128 "
-                         "pictures per step give 105.0 / 107.2 / 104.6 / 104.5 / 104.8 Gpixel/s where 32 gives 100 - 103 (the launch "
-                         "gaps and the tails of sixteen kernels per step are paid once per step; 96+: the streaming kernels' segment plan "
-                         "no longer fills whole rounds of wavefront slots)")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="pictures per GPU per step (all distinct).  128 since round 5's two-level kernels: measured on one box, "
+                         "alternating, 64 / 96 / 128 / 160 / 192 / 256 pictures per step give 110.2 / 109.4 / 112.6 / 110.4 / 111.3 / "
+                         "111.1 Gpixel/s and 32 gives 101 - 103 (the launch gaps, the ramps and the tails of sixteen kernels per step "
+                         "are paid once per step, and every wavefront of the streaming kernels fills and drains its ring once per "
+                         "launch; between the peaks the segment plan does not fill whole rounds of wavefront slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the per-core CPU run (0: one per core)")

@@ -14,7 +14,11 @@ from synth import synth, noise_frame
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rnd = random.Random(seed)
-hip = vc2hip_py.Vc2Hip(0)
+# FUZZ_FLAGS=planes8_always,no_pair ...: context flags by their names in vc2hip_py.FLAGS (round 5: the byte band planes are
+# chosen from the batch before, so a fuzz run that wants them in every case forces them)
+_flags = 0
+for _n in filter(None, os.environ.get("FUZZ_FLAGS", "").split(",")): _flags |= vc2hip_py.FLAGS[_n.strip().upper()]
+hip = vc2hip_py.Vc2Hip(0, flags=_flags)
 oracle = load_oracle()
 bad = both_err = same = 0
 for case in range(count):

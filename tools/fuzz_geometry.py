@@ -19,7 +19,11 @@ wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "tall", "pair")
 pairm = len(sys.argv) > 3 and sys.argv[3] == "pair"   # geometries the two-level kernels take: short filters, depth 2 - 4, every plane from 192 samples wide at the pair's level
 tall = len(sys.argv) > 3 and sys.argv[3] in ("tall", "pair")   # wide planes with MANY slice rows: the streaming / pair kernels' segments (top, middle, bottom walks)
 rnd = random.Random(seed)
-hip = vc2hip_py.Vc2Hip(0)
+# FUZZ_FLAGS=planes8_always,no_pair ...: context flags by their names in vc2hip_py.FLAGS (round 5: the byte band planes are
+# chosen from the batch before, so a fuzz run that wants them in every case forces them)
+_flags = 0
+for _n in filter(None, os.environ.get("FUZZ_FLAGS", "").split(",")): _flags |= vc2hip_py.FLAGS[_n.strip().upper()]
+hip = vc2hip_py.Vc2Hip(0, flags=_flags)
 hip.profile_enable(True)   # (only to count, at the end, which transform kernels the cases went through)
 oracle = load_oracle()
 bad = 0
