@@ -510,3 +510,28 @@ def test_two_level_kernels_are_the_path_taken(variants, oracle):
     assert "dwt_level_first" not in seen["default"]
     assert not any("pair" in k for k in seen["levels"]), seen["levels"]
     assert {"dwt_level_first", "dwt_level", "idwt_level", "idwt_level_final"} <= seen["levels"]
+
+
+def test_band_plane_form_follows_the_batches_and_never_changes_a_result(oracle):
+    """Round 5: the decoder chooses byte or 16-bit band planes from the batch before (payload bits per sample, escape count).
+    A fresh context decodes coarse pictures (-> bytes from its second call: the first look is waited for), then fine noise
+    (many bits per sample -> back to 16-bit planes), then coarse ones again; every picture must be the oracle's, whatever
+    form its call happened to use (the forced forms are the `bytes` / `words` variants of every other case of this file)."""
+    hip = _ctx()
+    w, h = 2048, 128
+    cases = []
+    for seed, q, gen in ((5, 24, synth), (6, 24, synth), (7, 24, synth), (8, 0, noise_frame), (9, 0, noise_frame), (10, 0, noise_frame),
+                         (11, 20, synth), (12, 20, synth), (13, 20, synth)):
+        raw = gen(w, h, "422", 10, seed)
+        p = make_params(w, h, "422", 10, "DD97", 3, 1, 2, q=q, scalar=2)
+        stream = oracle.encode_stream(p, raw, 1)
+        dec, _ = oracle.decode_stream(p, stream, 1)
+        fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", 3, 1, 2, q=q, scalar=2)
+        payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+        assert payload == stream[-13 - len(payload):-13], (seed, "payload")
+        cases.append((seed, payload, fmt, cp, dec))
+    for seed, payload, fmt, cp, dec in cases:
+        assert hip.decode_picture(payload, fmt, cp) == dec, (seed, "decode")
+    # and without a synchronisation between the calls (the look at the batch before is then usually not there yet)
+    pays = [c[1] for c in cases[:3]] * 3
+    assert hip.decode_pictures_pipelined(pays, cases[0][2], cases[0][3]) == [c[4] for c in cases[:3]] * 3

@@ -146,7 +146,7 @@ struct vc2hip_ctx {
   unsigned long long *d_stat = nullptr; // device: [0] pieces with an escape from a byte plane (k_hq_unpack16<true>)
   unsigned long long *h_stat = nullptr; // pinned: [0] that count, [1..] the batch's payload lengths (first 60 pictures)
   hipEvent_t stat_ev = nullptr;
-  bool stat_pending = false, stat_was8 = false;
+  bool stat_pending = false, stat_was8 = false, stat_seen = false;
   int stat_n = 0;                      // lengths copied
   double stat_samples = 0;             // samples per picture of that batch
   int ld_batch = 1;         // pictures of the LD batch being encoded (fill_ld_enc sizes the scratch array with it)
@@ -1668,8 +1668,13 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     // escape count arrive through pinned memory behind an event: no wait here): small coefficients <=> few payload bits per
     // sample.  The planes keep their places and their wide elements: only the bytes of a plane's narrow elements halve.
     if (bp.levels) {
+      // (the context's FIRST look is waited for -- once, at its second batch, while the first is all the GPU has to do
+      // anyway: a caller that never synchronises between batches would otherwise keep the 16-bit planes for as long as it
+      // runs ahead of the GPU; every later look is only taken when it has arrived)
+      if (c->stat_pending && !c->stat_seen) (void)hipEventSynchronize(c->stat_ev);
       if (c->stat_pending && hipEventQuery(c->stat_ev) == hipSuccess) {
         c->stat_pending = false;
+        c->stat_seen = true;
         double bytes = 0;
         for (int k = 0; k < c->stat_n; ++k) bytes += (double)c->h_stat[1 + k];
         const double bits = c->stat_n ? 8.0 * bytes / (c->stat_n * c->stat_samples) : 99.0;

@@ -292,6 +292,9 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
   return v < 0 ? (int)(0u - (unsigned)a) : a;
 }
 
+#ifndef VC2_STREAM_DQ8
+#define VC2_STREAM_DQ8 1 // byte planes: dequantise through a table per band in LDS (k_inv_stream)
+#endif
 // BP8 (round 5): the level's band planes hold ONE BYTE per coefficient (vc2hip_internal.h BandPlanes::bytes8: quantised
 // coefficients are small; -128 is the sentinel, the value then sits in the wide array at the element's index as for the
 // 16-bit sentinel).  This kernel runs at the memory system's pace: its band rows are half of what it reads.
@@ -303,6 +306,20 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   using T = typename VE::T;
   constexpr int RL = RLK<K>;
   __shared__ int qtab[360]; // quant_factor / quant_offset / domain limit by adjusted index (every wavefront of the workgroup writes all of it: the same values)
+  // BP8: the dequantised value of every byte, per band, for the quantiser index all of the wavefront's slices share (the
+  // common case: HQ_ConstQ streams) -- a byte then costs one shift and one LDS read where extraction, range test and
+  // scale() cost seven VALU instructions, and this kernel's time is its VALU instructions.  Private to the
+  // wavefront; rebuilt when the index changes; slices with different indices side by side take the arithmetic.
+  // Measured (same box, alternating): the last inverse level of 32 UHD pictures 0.478 -> 0.418 ms, of 32 HD pictures (LeGall)
+  // 0.147 -> 0.109.  The last level of the short filters only: the instantiation for the levels below it has no registers
+  // to spare (128 with 40 bytes of scratch, 0.132 -> 0.148 ms with the table), DD137 / Daub97 / Fidelity would spill
+  // more than they do (Fidelity, 4 UHD-2 pictures: 0.656 -> 0.667).
+  constexpr bool DQ8 = BP8 && FINAL && VC2_STREAM_DQ8 &&
+                       (K == VC2HIP_DD97 || K == VC2HIP_LEGALL || K == VC2HIP_HAAR0 || K == VC2HIP_HAAR1);
+  __shared__ int dq8[DQ8 ? VC2_STREAM_WG_WAVES * 768 : 1];
+  int *const tab8 = dq8 + (DQ8 ? (int)(threadIdx.x >> 6) * 768 : 0);
+  int tab_q = -1;      // the index the table holds (wave-uniform)
+  bool tab_on = false; // the current slice row reads through the table (wave-uniform)
   const int lane = threadIdx.x & 63;
   int comp, pic;
   VC2_STAMP_BEGIN
@@ -374,12 +391,44 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
       if (aq > 119 && p.dequant && b >= b0) atomicOr(p.err, VC2_DEVERR_QINDEX);
       qf[b] = qtab[min(aq, 119)]; qo[b] = qtab[120 + min(aq, 119)]; ql[b] = qtab[240 + min(aq, 119)];
     }
+    if constexpr (DQ8) {
+      tab_on = false;
+      if (p.dequant && !p.ll_from_store) {
+        const int q0 = __builtin_amdgcn_readfirstlane(q);
+        if (__builtin_amdgcn_ballot_w64(q != q0) == 0ull) { // one index for every slice of the wavefront's strip
+          if (q0 != tab_q) {
+            wave_sync(); // (the last row's reads of the old table are done)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { // entry 256 (b - 1) + byte, b = 1 + i / 4 (the factors are the same in every lane)
+              const int x = (int)(signed char)(64 * (i & 3) + lane);
+              tab8[64 * i + lane] = x == -128 ? (int)0x80000000 : dequant_full(x, qf[1 + i / 4], qo[1 + i / 4]);
+            }
+            wave_sync();
+            tab_q = q0;
+          }
+          tab_on = true;
+        }
+      }
+    }
   };
   // unpack band b of row m (escapes resolved) and dequantise
   // unpack band b of row m (escapes resolved) and dequantise: band by band (the Fidelity kernels)
   auto band4 = [&](int m, int slot, int b) __attribute__((always_inline)) -> int4 {
     const bool from_plane = b == 0 && !p.ll_from_store;
     int v[4];
+    if constexpr (DQ8) {
+      if (b > 0 && tab_on) { // (wave-uniform) through the table: dequantised at once
+        const unsigned w = bq8[slot][b];
+        const int *t = tab8 + 256 * (b - 1);
+        v[0] = t[w & 0xFFu]; v[1] = t[(w >> 8) & 0xFFu]; v[2] = t[(w >> 16) & 0xFFu]; v[3] = t[w >> 24];
+        if (__builtin_expect(min(min(v[0], v[1]), min(v[2], v[3])) == (int)0x80000000, 0)) {
+          const int32_t *wq = wide + rec_at(m, b);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (v[k] == (int)0x80000000) v[k] = dequant_full(wq[k], qf[b], qo[b]);
+        }
+        return make_int4(v[0], v[1], v[2], v[3]);
+      }
+    }
     if (BP8 && b > 0) {
       const unsigned w = bq8[slot][b];
       v[0] = __builtin_amdgcn_sbfe((int)w, 0, 8); v[1] = __builtin_amdgcn_sbfe((int)w, 8, 8); v[2] = __builtin_amdgcn_sbfe((int)w, 16, 8); v[3] = (int)w >> 24;
@@ -422,6 +471,31 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
     if constexpr (BP8) { // LL: 16-bit elements of its plane (sentinel -32768); the bands: bytes (sentinel -128)
       const uint2 w0 = bq[slot][0];
       v[0] = vc2_lo16(w0.x); v[1] = vc2_hi16(w0.x); v[2] = vc2_lo16(w0.y); v[3] = vc2_hi16(w0.y);
+      if constexpr (DQ8) {
+        if (tab_on) { // (wave-uniform) the bands through the table: dequantised at once; LL comes from the level below as it is
+#pragma unroll
+          for (int b = 1; b < 4; ++b) {
+            const unsigned w = bq8[slot][b];
+            const int *t = tab8 + 256 * (b - 1);
+            v[4 * b] = t[w & 0xFFu]; v[4 * b + 1] = t[(w >> 8) & 0xFFu]; v[4 * b + 2] = t[(w >> 16) & 0xFFu]; v[4 * b + 3] = t[w >> 24];
+          }
+          int low0 = min(min(v[0], v[1]), min(v[2], v[3])), low = v[4];
+#pragma unroll
+          for (int k = 5; k < 16; ++k) low = min(low, v[k]);
+          if (__builtin_expect(low0 == VC2_ST_SENTINEL || low == (int)0x80000000, 0)) {
+            const int32_t *wl = llp_w + mul24z(m, ow);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (v[k] == VC2_ST_SENTINEL) v[k] = wl[k];
+#pragma unroll
+            for (int b = 1; b < 4; ++b) {
+              const int32_t *wq = wide + rec_at(m, b);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) if (v[4 * b + k] == (int)0x80000000) v[4 * b + k] = dequant_full(wq[k], qf[b], qo[b]);
+            }
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (int b = 1; b < 4; ++b) {
         const unsigned w = bq8[slot][b];
