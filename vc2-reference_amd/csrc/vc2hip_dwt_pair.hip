@@ -811,8 +811,7 @@ __global__ __launch_bounds__(64, (K == VC2HIP_DD137 || SPL2 ? 2 : VC2_PAIR_WPE_I
       for (int k = 0; k < 4; ++k) {
         const unsigned a = (unsigned)(min(max(s[2 * k], clip_lo), clip_hi) + sample_offset) << sample_shift;
         const unsigned b = (unsigned)(min(max(s[2 * k + 1], clip_lo), clip_hi) + sample_offset) << sample_shift;
-        const unsigned t = (a & 0xFFFFu) | (b << 16);
-        o.w[k] = __builtin_amdgcn_perm(t, t, 0x02030001u); // host order to big-endian 16-bit words
+        o.w[k] = __builtin_amdgcn_perm(b, a, 0x04050001u); // the low halves of a, b as big-endian 16-bit words (pack and swap in one v_perm)
       }
     } else if constexpr (S_::narrow) {
       const int mx = max(max(max(s[0], s[1]), max(s[2], s[3])), max(max(s[4], s[5]), max(s[6], s[7])));

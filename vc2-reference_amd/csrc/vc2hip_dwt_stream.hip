@@ -293,7 +293,7 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
 }
 
 #ifndef VC2_STREAM_DQ8
-#define VC2_STREAM_DQ8 1 // byte planes: dequantise through a table per band in LDS (k_inv_stream)
+#define VC2_STREAM_DQ8 2 // byte planes: dequantise through a table per band in LDS (k_inv_stream); 1: the last level only
 #endif
 // BP8 (round 5): the level's band planes hold ONE BYTE per coefficient (vc2hip_internal.h BandPlanes::bytes8: quantised
 // coefficients are small; -128 is the sentinel, the value then sits in the wide array at the element's index as for the
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   // 0.147 -> 0.109.  The last level of the short filters only: the instantiation for the levels below it has no registers
   // to spare (128 with 40 bytes of scratch, 0.132 -> 0.148 ms with the table), DD137 / Daub97 / Fidelity would spill
   // more than they do (Fidelity, 4 UHD-2 pictures: 0.656 -> 0.667).
-  constexpr bool DQ8 = BP8 && FINAL && VC2_STREAM_DQ8 &&
+  constexpr bool DQ8 = BP8 && (FINAL || VC2_STREAM_DQ8 > 1) && VC2_STREAM_DQ8 &&
                        (K == VC2HIP_DD97 || K == VC2HIP_LEGALL || K == VC2HIP_HAAR0 || K == VC2HIP_HAAR1);
   __shared__ int dq8[DQ8 ? VC2_STREAM_WG_WAVES * 768 : 1];
   int *const tab8 = dq8 + (DQ8 ? (int)(threadIdx.x >> 6) * 768 : 0);
@@ -381,7 +381,16 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
     }
   };
   // quantiser constants of the lane's slice in block row sv, per band
+  // (DQ8: the twelve constants are not kept across the walk -- only the four indices in one register; whoever needs the
+  // constants fetches them from qtab at that moment (q_now): eleven registers for the table path's addresses)
   int qf[4], qo[4], ql[4];
+  unsigned aqp = 0;
+  auto q_now = [&]() __attribute__((always_inline)) {
+    if constexpr (DQ8) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { const int a = (int)((aqp >> (8 * b)) & 0xFFu); qf[b] = qtab[a]; qo[b] = qtab[120 + a]; ql[b] = qtab[240 + a]; }
+    }
+  };
   auto load_q = [&](int sv) __attribute__((always_inline)) {
     const int q = p.dequant ? qidx[sv * p.xs + sx] : 0;
 #pragma unroll
@@ -389,7 +398,8 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
       const int qm = b == 0 ? p.qmatrix[0] : p.qmatrix[p.band + b - 1];
       const int aq = max(q - qm, 0);
       if (aq > 119 && p.dequant && b >= b0) atomicOr(p.err, VC2_DEVERR_QINDEX);
-      qf[b] = qtab[min(aq, 119)]; qo[b] = qtab[120 + min(aq, 119)]; ql[b] = qtab[240 + min(aq, 119)];
+      if constexpr (DQ8) aqp = b == 0 ? (unsigned)min(aq, 119) : aqp | (unsigned)min(aq, 119) << (8 * b);
+      else { qf[b] = qtab[min(aq, 119)]; qo[b] = qtab[120 + min(aq, 119)]; ql[b] = qtab[240 + min(aq, 119)]; }
     }
     if constexpr (DQ8) {
       tab_on = false;
@@ -397,6 +407,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
         const int q0 = __builtin_amdgcn_readfirstlane(q);
         if (__builtin_amdgcn_ballot_w64(q != q0) == 0ull) { // one index for every slice of the wavefront's strip
           if (q0 != tab_q) {
+            q_now();
             wave_sync(); // (the last row's reads of the old table are done)
 #pragma unroll
             for (int i = 0; i < 12; ++i) { // entry 256 (b - 1) + byte, b = 1 + i / 4 (the factors are the same in every lane)
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
         const int *t = tab8 + 256 * (b - 1);
         v[0] = t[w & 0xFFu]; v[1] = t[(w >> 8) & 0xFFu]; v[2] = t[(w >> 16) & 0xFFu]; v[3] = t[w >> 24];
         if (__builtin_expect(min(min(v[0], v[1]), min(v[2], v[3])) == (int)0x80000000, 0)) {
+          q_now();
           const int32_t *wq = wide + rec_at(m, b);
 #pragma unroll
           for (int k = 0; k < 4; ++k) if (v[k] == (int)0x80000000) v[k] = dequant_full(wq[k], qf[b], qo[b]);
@@ -450,6 +462,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
       v[0] = (int)w.x; v[1] = (int)w.y; v[2] = (int)w.z; v[3] = (int)w.w;
     }
     if (p.dequant && !from_plane) {
+      q_now();
       const int mx = max(max(v[0], v[1]), max(v[2], v[3])), mn = min(min(v[0], v[1]), min(v[2], v[3]));
       if (mx <= ql[b] && mn >= -ql[b]) {
 #pragma unroll
@@ -483,6 +496,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
 #pragma unroll
           for (int k = 5; k < 16; ++k) low = min(low, v[k]);
           if (__builtin_expect(low0 == VC2_ST_SENTINEL || low == (int)0x80000000, 0)) {
+            q_now();
             const int32_t *wl = llp_w + mul24z(m, ow);
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (v[k] == VC2_ST_SENTINEL) v[k] = wl[k];
@@ -540,6 +554,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
       }
     }
     if (p.dequant) {
+      q_now();
       const int bf = p.ll_from_store ? 0 : 1; // bands that come from the store
       bool fast = true;
 #pragma unroll
@@ -601,8 +616,7 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
       for (int k = 0; k < 4; ++k) {
         const unsigned a = (unsigned)(min(max(s[2 * k], p.clip_lo), p.clip_hi) + p.sample_offset) << p.sample_shift;
         const unsigned b = (unsigned)(min(max(s[2 * k + 1], p.clip_lo), p.clip_hi) + p.sample_offset) << p.sample_shift;
-        const unsigned t = (a & 0xFFFFu) | (b << 16);
-        o.w[k] = __builtin_amdgcn_perm(t, t, 0x02030001u); // host order to big-endian 16-bit words
+        o.w[k] = __builtin_amdgcn_perm(b, a, 0x04050001u); // the low halves of a, b as big-endian 16-bit words (pack and swap in one v_perm)
       }
     } else if constexpr (S_::narrow) {
       const int mx = max(max(max(s[0], s[1]), max(s[2], s[3])), max(max(s[4], s[5]), max(s[6], s[7])));
