@@ -1720,6 +1720,10 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     }
   }
   int32_t *d_store, *d_ll, *d_q, *d_storew = nullptr, *d_llw = nullptr;
+  {
+    static const int pad = vc2_tune_int("VC2HIP_DEC_STORE_PAD", 0); // (experiment: elements between the pictures' stores; a multiple of 8)
+    if (s16 && pad > 0 && sstride + pad < (1ll << 31)) sstride += pad & ~7;
+  }
   NEED(c, B_STORE, std::max((size_t)n * ns * g.slice_coefs * 4, (size_t)n * (size_t)sstride * 2), d_store); // (16-bit elements: records, band planes and record heads)
   NEED(c, B_LL0, ll_bytes(g, n) + 16, d_ll);
   if (s16) {

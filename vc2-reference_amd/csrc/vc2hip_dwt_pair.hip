@@ -1229,8 +1229,9 @@ size_t vc2_pair_applicable(PairParams &pp, int kernel, bool edge, bool inverse, 
   }
   if (!nseg) return 0;
   {
-    static const int f = vc2_tune_int("VC2HIP_PAIR_NSEG", 0);
+    static const int f = vc2_tune_int("VC2HIP_PAIR_NSEG", 0), fe = vc2_tune_int("VC2HIP_PAIR_NSEG_EDGE", 0);
     if (f > 0) nseg = std::min(f, p.ys);
+    if (fe > 0 && edge) nseg = std::min(fe, p.ys);
   }
   for (int c = 0; c < 3; ++c) if (p.st_strips[c]) p.st_segs[c] = nseg;
   p.st_segmax = nseg;
