@@ -43,6 +43,9 @@ void vc2_upload_tables_pair(const QuantTables &t, hipStream_t s) {
 
 namespace {
 
+#ifndef VC2_PAIR_NT
+#define VC2_PAIR_NT 1 // the slice records leave k_fwd_pair with non-temporal stores (the slice coder reads them gigabytes later)
+#endif
 #include "vc2hip_stream_eng.h"
 
 // Issue priority in turn (prio_turn, vc2hip_stream_eng.h), for kernels with TWO wavefronts per SIMD.  The four-level
@@ -259,6 +262,10 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
   auto flush = [&](const ST *img, int ss, int run0, int run_n, int piece, int sv) __attribute__((always_inline)) {
     const int epp = piece / (int)sizeof(ST), ppr = run_n / epp; // elements per piece, pieces per run
     ST *rec0 = store + mul24z(sv * xs + sp.sx0, slice_coefs) + run0;
+    // Runs that are WHOLE 128-byte lines of the first launch leave non-temporally: the slice coder reads them gigabytes later,
+    // and 128 UHD pictures take 1.93 - 2.0 instead of 2.29 - 2.31 ms.  Not partial lines: their pieces no longer meet in L2 --
+    // the deep levels' launch went from 0.34 to 0.63 ms, the first launch of 32 HD pictures (192-byte runs) from 0.144 to 0.218.
+    const bool nt = FIRST && VC2_PAIR_NT && piece == 16 && (((run0 | run_n | slice_coefs) * (int)sizeof(ST)) & 127) == 0;
     if (ppr <= 64) {
       const int spt = 64 / ppr;                                  // slices per trip
       int ls = (int)((float)lane * (1.0f / (float)ppr));         // lane / ppr (exact: both below 2^7, corrected below)
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
 #pragma unroll 1
       for (int s2 = ls; s2 < sp.nsl; s2 += spt, src += dsrc, dst += ddst) {
         if (ls < spt) {
-          if (piece == 16) *(uint4 *)dst = *(const uint4 *)src;
+          if (piece == 16) { if (nt) st_nt(dst, *(const uint4 *)src); else *(uint4 *)dst = *(const uint4 *)src; }
           else if (piece == 8) *(uint2 *)dst = *(const uint2 *)src;
           else *(unsigned *)dst = *(const unsigned *)src;
         }
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
         ST *dst = rec0 + mul24z(s2, slice_coefs);
 #pragma unroll 1
         for (int q = lane; q < ppr; q += 64) {
-          if (piece == 16) *(uint4 *)(dst + q * epp) = *(const uint4 *)(src + q * epp);
+          if (piece == 16) { if (nt) st_nt(dst + q * epp, *(const uint4 *)(src + q * epp)); else *(uint4 *)(dst + q * epp) = *(const uint4 *)(src + q * epp); }
           else if (piece == 8) *(uint2 *)(dst + q * epp) = *(const uint2 *)(src + q * epp);
           else *(unsigned *)(dst + q * epp) = *(const unsigned *)(src + q * epp);
         }

@@ -292,6 +292,9 @@ __device__ __forceinline__ int dequant_full(int v, int qf, int off) { // scale()
   return v < 0 ? (int)(0u - (unsigned)a) : a;
 }
 
+#ifndef VC2_STREAM_NT_OUT
+#define VC2_STREAM_NT_OUT 1 // the decoded picture's rows leave with non-temporal stores (k_inv_stream FINAL)
+#endif
 #ifndef VC2_STREAM_DQ8
 #define VC2_STREAM_DQ8 2 // byte planes: dequantise through a table per band in LDS (k_inv_stream); 1: the last level only
 #endif
@@ -634,7 +637,13 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
   };
   auto put_out = [&](int y, const Pend &o) __attribute__((always_inline)) {
     if (!own || y >= lim_h) return;
-    if constexpr (FINAL) *(uint4 *)(rawo + mul24z(y, out_w) * 2) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    if constexpr (FINAL) {
+#if VC2_STREAM_NT_OUT
+      st_nt(rawo + mul24z(y, out_w) * 2, make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]));
+#else
+      *(uint4 *)(rawo + mul24z(y, out_w) * 2) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+#endif
+    }
     else if constexpr (S_::narrow) *(uint4 *)(lvl + mul24z(y, out_w)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
     else {
       *(uint4 *)(lvl + mul24z(y, out_w)) = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);

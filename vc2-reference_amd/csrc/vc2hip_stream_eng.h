@@ -36,6 +36,21 @@ template <int NP> __device__ __forceinline__ RowT<NP> vc2_times9(const RowT<NP> 
 template <int CTRL> __device__ __forceinline__ int dppm(int old, int v) {
   return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
 }
+// streaming stores: what these kernels write is read by the NEXT kernel, gigabytes later -- nothing in L2 is worth displacing
+// for it (round 5: the decoded picture's rows written this way take the last inverse level from a placement-dependent
+// 1.75 ms per 128 UHD pictures in most processes to 1.34 - 1.41 in most)
+typedef int vc2_nt4_t __attribute__((ext_vector_type(4)));
+typedef int vc2_nt2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_nt(void *p, uint4 v) {
+  const vc2_nt4_t x = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+  __builtin_nontemporal_store(x, (__attribute__((address_space(1))) vc2_nt4_t *)(size_t)p);
+}
+__device__ __forceinline__ void st_nt(void *p, uint2 v) {
+  const vc2_nt2_t x = {(int)v.x, (int)v.y};
+  __builtin_nontemporal_store(x, (__attribute__((address_space(1))) vc2_nt2_t *)(size_t)p);
+}
+__device__ __forceinline__ void st_nt(void *p, unsigned v) { __builtin_nontemporal_store((int)v, (__attribute__((address_space(1))) int *)(size_t)p); }
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
