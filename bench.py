@@ -200,10 +200,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128,
                     help="pictures per GPU per step (all distinct).  128 since round 5's two-level kernels: measured on one box, "
-                         "alternating, 64 / 96 / 128 / 160 / 192 / 256 pictures per step give 110.2 / 109.4 / 112.6 / 110.4 / 111.3 / "
-                         "111.1 Gpixel/s and 32 gives 101 - 103 (the launch gaps, the ramps and the tails of sixteen kernels per step "
-                         "are paid once per step, and every wavefront of the streaming kernels fills and drains its ring once per "
-                         "launch; between the peaks the segment plan does not fill whole rounds of wavefront slots)")
+                         "alternating, on the round's last sources 32 / 64 / 96 / 128 / 160 / 192 / 256 pictures per step give 110.3 / "
+                         "115.9 / 117.5 / 121.7 / 117.2 / 118.4 / 119.9 Gpixel/s (the launch gaps, the ramps and the tails of sixteen "
+                         "kernels per step are paid once per step, and every wavefront of the streaming kernels fills and drains its "
+                         "ring once per launch; between the peaks the segment plan does not fill whole rounds of wavefront slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the per-core CPU run (0: one per core)")
