@@ -495,6 +495,11 @@ __device__ unsigned long long *g_pack_stamps;
 template <int W, bool MID, class ST, bool GIMG = false>
 __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   constexpr int S = 64 / W;
+  // (the ablation build's switches.  "No code writes" moves the components' limits to bit 0 instead of branching around the
+  // writers: with a branch there -- never taken, the switch being off -- the ablation build of round 4 and 5 lost the leading
+  // luma codes of the second to fourth slice of a four-slice wavefront in ~6 % of 2 x 2-sample slices, different ones in every
+  // run (tools/probe/small_slices_diff.py; bisected to exactly that branch); the release build never had it)
+  const bool skip_codes = VC2_SKIP(p, 1), skip_out = VC2_SKIP(p, 2);
   const int nwv = (int)blockDim.x >> 6; // wavefronts per workgroup: 4, fewer when four slice images do not fit in LDS
   extern __shared__ unsigned lds_u[];
   __shared__ unsigned long long s_base; // byte offset of this tile inside the picture payload
@@ -585,8 +590,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         const int count = seg_max<W>(c.last_end ? incl - c.sum + c.last_end : 0);
         bytes[0] = comp_len(count);
         PACK_STAMP(7);
-        if (!__any(c.sum > 64)) { if (!VC2_SKIP(p, 1)) write8_short(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c); }
-        else write8(img, 8 * (base + 1) + incl - c.sum, 8 * (base + 1 + bytes[0]), c, VC2_SKIP(p, 1));
+        const int lim_y = skip_codes ? 0 : 8 * (base + 1 + bytes[0]);
+        if (!__any(c.sum > 64)) write8_short(img, 8 * (base + 1) + incl - c.sum, lim_y, c);
+        else write8(img, 8 * (base + 1) + incl - c.sum, lim_y, c);
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[0] / p.scalar));
         base += 1 + bytes[0];
       }
@@ -604,8 +610,9 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
         bytes[1] = comp_len(__shfl(cnt, seg * W));
         bytes[2] = cbr_v(comp_len(__shfl(cnt, seg * W + W / 2)));
         const int base_c = half ? base + 1 + bytes[1] : base;
-        if (!__any(c.sum > 64)) { if (!VC2_SKIP(p, 1)) write8_short(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c); }
-        else write8(img, 8 * (base_c + 1) + rel, 8 * (base_c + 1 + bytes[cc]), c, VC2_SKIP(p, 1));
+        const int lim_c = skip_codes ? 0 : 8 * (base_c + 1 + bytes[cc]);
+        if (!__any(c.sum > 64)) write8_short(img, 8 * (base_c + 1) + rel, lim_c, c);
+        else write8(img, 8 * (base_c + 1) + rel, lim_c, c);
         if (sl == 0) put_byte(img, base, (unsigned)(bytes[1] / p.scalar));
         if (sl == W / 2) put_byte(img, base_c, (unsigned)(bytes[2] / p.scalar));
       }
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
     }
     __syncthreads();
   }
-  if (!active || VC2_SKIP(p, 2)) return;
+  if (!active || skip_out) return;
 
   if (p.lookback) {
     unsigned long long off = s_base;
