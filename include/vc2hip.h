@@ -231,7 +231,14 @@ int vc2hip_decode_picture_end(vc2hip_ctx *ctx, int ticket);
  * (first call sizes the workspace).  The kernels run on the ctx stream (vc2hip_create makes its own,
  * vc2hip_create_on_stream takes the caller's): buffers that another stream has written -- a framework's
  * fill or gather kernel, a copy -- must be complete before the call, and the results are complete after
- * vc2hip_sync (or an event the caller records on the ctx stream). */
+ * vc2hip_sync (or an event the caller records on the ctx stream).
+ * One exception, HQ decode on a context made by vc2hip_create / _with_flags without a PLANES8 flag: the form of the
+ * decoder's band planes (16-bit or byte elements: same results, different speed) follows the batch before; that batch's
+ * payload lengths and escape count come back through pinned memory behind an event.  The context's SECOND decode call
+ * waits for that event once (hipEventSynchronize: the first batch must have run); every later call only queries it.
+ * On a caller's stream (vc2hip_create_on_stream) the call never waits, and while that stream is being captured into a
+ * graph it records nothing.  Callers that need the same kernels launched whatever the host's timing (graph capture,
+ * running far ahead of the GPU) create the context with VC2HIP_FLAG_PLANES8_ALWAYS or _NEVER. */
 /* Cut every device-resident batch into k contiguous sub-batches, each on its own HIP stream and workspace,
  * forked from and joined to the context's stream (k = 1: off, the default).  The launches of the sub-batches
  * overlap on the GPU; results are identical.  Extension, no counterpart in the reference. */
@@ -242,6 +249,11 @@ int vc2hip_encode_batch_dev(vc2hip_ctx *ctx, const void *d_raw, int n,
 int vc2hip_decode_batch_dev(vc2hip_ctx *ctx, const void *d_payload, size_t payload_stride,
                             const uint64_t *d_lens, int n, const vc2hip_picture_format *fmt,
                             const vc2hip_coding_params *cp, void *d_raw_out);
+
+/* Which form the band planes of the context's most recent HQ decode call had: 0 = none (the slice records only), 16 = 16-bit
+ * elements, 8 = byte elements (see above: the adaptive choice, or the PLANES8 flags).  Introspection for tests and
+ * measurements -- the results never depend on it.  Extension, no counterpart in the reference. */
+int vc2hip_band_plane_bits(const vc2hip_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * measurement: per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg)

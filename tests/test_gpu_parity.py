@@ -344,6 +344,59 @@ def test_cfg2_uhd_batch_device_resident(hip, oracle):
     assert hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest() == g["decoded"]["sha256"]
 
 
+@pytest.mark.parametrize("flags,forms", [("", (16, 8)), ("PLANES8_ALWAYS", (8, 8)), ("PLANES8_NEVER", (16, 16))])
+def test_cfg2_timed_path_at_full_size_in_every_plane_form(oracle, flags, forms):
+    """The configuration bench.py times, pinned here: cfg 2 at full size through vc2hip_encode_batch_dev /
+    vc2hip_decode_batch_dev, 4 pictures per call, TWICE on a context of its own -- with default flags the second call has
+    taken the look at the first and decodes through BYTE band planes (the dequantiser table and the non-temporal stores ride
+    on that instantiation), with the PLANES8 flags the form is fixed from the first call.  vc2hip_band_plane_bits says which
+    form each call used, the library's own launch profile which kernels ran; payloads and decoded pictures against the
+    reference's digests after BOTH calls."""
+    import torch
+    import vc2hip_py
+    g = GOLD["cfg2"]
+    hip = vc2hip_py.Vc2Hip(flags=sum(vc2hip_py.FLAGS[f] for f in flags.split(",") if f))
+    raw2 = synth(3840, 2160, "422", 10, 1234, frames=2)
+    n = 4
+    raw = raw2 * 2                      # slots 2, 3 = slots 0, 1 again
+    fmt, cp = _fmt_cp(hip, 3840, 2160, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    p = make_params(3840, 2160, "422", 10, "DD97", 4, 1, 2, q=16, scalar=2)
+    stream = oracle.encode_stream(p, raw2, 2)
+    assert hashlib.sha256(stream).hexdigest() == g["stream"]["sha256"]
+    for call in range(2):
+        d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        hip.profile_reset(); hip.profile_enable(True)
+        hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+        hip.sync()
+        hip.profile_enable(False)
+        assert hip.band_plane_bits() == forms[call], (flags, call)
+        seen = {k for k, v in hip.profile().items() if v[0] > 0}
+        assert {"dwt_pair_first", "dwt_pair", "hq_pack", "slice_compact", "slice_index_tables", "hq_unpack", "idwt_pair", "idwt_level",
+                "idwt_level_final"} <= seen, seen
+        lens = d_len.cpu().tolist()
+        pay = d_pay.cpu().numpy()
+        assert lens[2:] == lens[:2]
+        for half in range(2):
+            pos = len(stream) - 13
+            for k in reversed(range(2)):
+                slot = 2 * half + k
+                body = bytes(pay[slot * stride:slot * stride + lens[slot]])
+                assert stream[pos - lens[slot]:pos] == body, (flags, call, slot)
+                pos -= lens[slot]
+                pos = stream.rfind(b"BBCD", 0, pos)
+            out = d_out[2 * half * rb:2 * (half + 1) * rb].cpu().numpy().tobytes()
+            assert hashlib.sha256(out).hexdigest() == g["decoded"]["sha256"], (flags, call, half)
+    hip.close()
+
+
 def test_cfg3_uhd_cbr_reference_digests(hip, oracle):
     """BASELINE config 3 (UHD-1 HQ_CBR, -s 8294400 -S 2) at full size: per-slice quantiser search + CBR
     packing on the GPU; stream and decoded picture digests of reference output."""

@@ -97,6 +97,18 @@ def test_store16_escapes_both_directions(variants, oracle):
     assert hit is not None, "no quantiser index puts quantised values between 32768 and 65534"
 
 
+@pytest.mark.parametrize("q", [116, 118, 119])
+def test_byte_planes_high_and_mixed_indices(variants, oracle, q):
+    """the byte planes' dequantiser table at the top of the quantiser table.  With q = 116 ... 119 and matrix entries
+    of 0 the adjusted indices reach 116 ... 119, where quant_factor wraps in 32 bits (Quantisation.cpp:40-58 as the reference
+    computes it); 16-bit noise keeps some quantised values non-zero, so the table's entries for those factors are read.
+    Every variant (the `bytes` one forces the byte planes) against the oracle; slices with DIFFERENT indices side by side on
+    the byte planes are test_wide_cbr's `bytes` variant."""
+    w, h, depth = 1024, 64, 2
+    raw = noise_frame(w, h, "422", 16, seed=300 + q)
+    _check(variants, oracle, raw, w, h, "422", 16, "LeGall", depth, 2, 4, q=q, scalar=8)
+
+
 @pytest.mark.parametrize("cf", ["422", "444"])
 def test_deep_level_shapes_with_escapes(variants, oracle, cf):
     """The deep levels of the UHD slice geometry (32 x 16 slices, depth 4: blocks of 2 x 1 and 1 x 1 coefficients with LL

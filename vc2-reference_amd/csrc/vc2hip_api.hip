@@ -148,6 +148,8 @@ struct vc2hip_ctx {
   hipEvent_t stat_ev = nullptr;
   bool stat_pending = false, stat_was8 = false, stat_seen = false;
   int stat_n = 0;                      // lengths copied
+  int stat_n_total = 0;                // pictures of that batch (the escape count is over all of them)
+  int last_plane_bits = 0;             // vc2hip_band_plane_bits: the most recent HQ decode call's band planes (0 none, 16, 8)
   double stat_samples = 0;             // samples per picture of that batch
   int ld_batch = 1;         // pictures of the LD batch being encoded (fill_ld_enc sizes the scratch array with it)
   bool allow_heads = true;  // record heads for the levels below them (A/B and test switch VC2HIP_NO_HEADS)
@@ -540,9 +542,7 @@ static int need(vc2hip_ctx *c, int which, size_t bytes, void **out) {
     HIPCHK(c, hipMalloc(&b.p, cap));
     b.cap = cap;
 #ifdef VC2HIP_ABLATE
-#ifdef VC2HIP_ABLATE
     if (getenv("VC2HIP_DEBUG_ALLOC")) fprintf(stderr, "vc2hip alloc: buffer %d at %p, %zu bytes\n", which, b.p, cap);
-#endif
 #endif
   }
   *out = b.p;
@@ -1670,15 +1670,18 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     if (bp.levels) {
       // (the context's FIRST look is waited for -- once, at its second batch, while the first is all the GPU has to do
       // anyway: a caller that never synchronises between batches would otherwise keep the 16-bit planes for as long as it
-      // runs ahead of the GPU; every later look is only taken when it has arrived)
-      if (c->stat_pending && !c->stat_seen) (void)hipEventSynchronize(c->stat_ev);
+      // runs ahead of the GPU; every later look is only taken when it has arrived.  Never on a caller's stream
+      // (vc2hip_create_on_stream): that caller may be capturing a graph or deliberately running ahead of the GPU -- there
+      // the look is only ever queried, and VC2HIP_FLAG_PLANES8_ALWAYS / _NEVER make the choice deterministic: include/vc2hip.h)
+      if (c->stat_pending && !c->stat_seen && c->own_stream) (void)hipEventSynchronize(c->stat_ev);
       if (c->stat_pending && hipEventQuery(c->stat_ev) == hipSuccess) {
         c->stat_pending = false;
         c->stat_seen = true;
         double bytes = 0;
         for (int k = 0; k < c->stat_n; ++k) bytes += (double)c->h_stat[1 + k];
         const double bits = c->stat_n ? 8.0 * bytes / (c->stat_n * c->stat_samples) : 99.0;
-        const double esc = (double)c->h_stat[0] * 8.0 / (std::max(1, c->stat_n) * c->stat_samples); // (pieces of eight coefficients)
+        // (pieces of eight coefficients; counted over ALL pictures of the batch, not only the stat_n whose lengths were copied)
+        const double esc = (double)c->h_stat[0] * 8.0 / (std::max(1, c->stat_n_total) * c->stat_samples);
 #ifdef VC2HIP_ABLATE
         if (getenv("VC2HIP_PLANES8_DEBUG")) fprintf(stderr, "planes8: previous batch %d pictures, %.2f payload bits per sample, %s planes, escape pieces %.4f%%\n", c->stat_n, bits, c->stat_was8 ? "byte" : "16-bit", 100 * esc);
 #endif
@@ -1763,12 +1766,21 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
     fill_comp_arrays(g, p.comp_n, p.comp_off, n0);
     p.prefix = cp->prefix; p.scalar = cp->scalar; p.err = c->d_err;
     p.bp = bp; p.hs = hs; p.xs = g.xs;
+    c->last_plane_bits = bp.levels ? (bp.bytes8 ? 8 : 16) : 0;
     p.stats = c->d_stat;
-    const bool track = bp.levels && c->planes8_mode == 0 && !c->stat_pending;
+    // (no look while the caller's stream is being captured into a graph: the copies and the event would become graph nodes
+    // and the event could never be queried)
+    bool capturing = false;
+    if (!c->own_stream) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      capturing = hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    }
+    const bool track = bp.levels && c->planes8_mode == 0 && !c->stat_pending && !capturing;
     if (track) HIPCHK(c, hipMemsetAsync(c->d_stat, 0, 8, c->stream));
     vc2_launch_unpack(c->L, p, n, c->stream);
     if (track) { // this batch's escape count and payload lengths for the next call's choice
       c->stat_n = std::min(n, 60);
+      c->stat_n_total = n;
       c->stat_samples = 0;
       for (int k = 0; k < 3; ++k) c->stat_samples += (double)g.c[k].h * g.c[k].w;
       c->stat_was8 = bp.bytes8 != 0;
@@ -1824,6 +1836,8 @@ static int decode_batch_common(vc2hip_ctx *c, const void *d_payload, size_t payl
   return run_inverse(c, g, cp->kernel, n, d_store, d_q, qm, true, ld, ll, dst, ds, true, f, s16, d_storew, &bp, sstride, nullptr,
                      hs.n[0] ? &hs : nullptr, head_level);
 }
+
+extern "C" int vc2hip_band_plane_bits(const vc2hip_ctx *c) { return c ? c->last_plane_bits : 0; }
 
 extern "C" int vc2hip_decode_batch_dev(vc2hip_ctx *c, const void *d_payload, size_t payload_stride, const uint64_t *d_lens,
                                        int n, const vc2hip_picture_format *f, const vc2hip_coding_params *cp, void *d_raw_out) {

@@ -413,6 +413,10 @@ __global__ __launch_bounds__(64 * VC2_STREAM_WG_WAVES, (stream_wpe<K, TAIL>())) 
             q_now();
             wave_sync(); // (the last row's reads of the old table are done)
 #pragma unroll
+            // The marker 0x80000000 is no value of scale(): dequant_full ends in `a /= 4` on an int, so every result --
+            // the wrapped factors of indices 116..119 included -- lies within +-2^29.  A prefetched row holds raw bytes
+            // only and is dequantised where it is used, behind the load_q of ITS slice row: no row ever reads a table
+            // built for another row's index (tests/test_gpu_wide.py::test_byte_planes_high_and_mixed_indices).
             for (int i = 0; i < 12; ++i) { // entry 256 (b - 1) + byte, b = 1 + i / 4 (the factors are the same in every lane)
               const int x = (int)(signed char)(64 * (i & 3) + lane);
               tab8[64 * i + lane] = x == -128 ? (int)0x80000000 : dequant_full(x, qf[1 + i / 4], qo[1 + i / 4]);

@@ -148,6 +148,32 @@ __device__ __forceinline__ void p16_group(const uint4 w, const float f, const un
   L = S;
 }
 
+#ifdef VC2_PRICE8 // PRICING ONLY: eight coefficients that are already quantised bytes (no division, the byte is the table index)
+__device__ __forceinline__ void p16_group8(const uint2 w, const unsigned *lut, unsigned long long &G, int &L, int &last) {
+  const unsigned ww[2] = {w.x, w.y};
+  unsigned pr[4];
+  int pl[4];
+  int S = 0;
+  last = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const unsigned x = ww[d >> 1] >> (16 * (d & 1));
+    const unsigned e0 = lut[x & 0xFFu], e1 = lut[(x >> 8) & 0xFFu];
+    const int l0 = (int)(e0 >> 24), l1 = (int)(e1 >> 24);
+    S += l0;
+    const int c0 = S & (int)(signed char)(e0 >> 16);
+    S += l1;
+    const int c1 = S & (int)(signed char)(e1 >> 16);
+    last = max(last, max(c0, c1));
+    pr[d] = ((e0 & 0xFFFFu) << l1) | (e1 & 0xFFFFu);
+    pl[d] = l0 + l1;
+  }
+  const unsigned long long q0 = ((unsigned long long)pr[0] << pl[1]) | pr[1], q1 = ((unsigned long long)pr[2] << pl[3]) | pr[3];
+  G = (q0 << (pl[2] + pl[3])) | q1;
+  L = S;
+}
+#endif
+
 // OR the first `keep` of the n <= 63 right-aligned bits of G into the image at bit position pos (0 <= keep <= n; what a
 // bounded write drops beyond the component's length are the '1's of trailing zeros, VLC.cpp:151-156).  No special cases
 // and no branch: with keep == 0 the value is zero and the three words it is OR-ed into may lie up to ~70 bytes behind the
@@ -217,7 +243,11 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   const int16_t *rec = (const int16_t *)p.store + rec_at;
   uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
   int hv = 0;
+#ifdef VC2_PRICE8
+  if (active && has_body) w0 = *(const uint4 *)((const char *)p.store + (rec_at + coff + head_n + 16 * cl));
+#else
   if (active && has_body) { const int16_t *b = rec + coff + head_n + 16 * cl; w0 = *(const uint4 *)b; w1 = *(const uint4 *)(b + 8); }
+#endif
   if (active && has_head) hv = rec[coff + cl];
   const int32_t *hwide = p.store_wide + rec_at + coff + cl; // the head coefficient's place in the wide array (an escape of the 16-bit store)
   const int q = p.qidx[(size_t)pic * p.n_slices + (active ? slice : 0)]; // (a scalar load: requested before the barrier, used behind it)
@@ -236,10 +266,17 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   unsigned long long G0, G1;
   int L0, L1, last0, last1;
   float maxf = 0.f;
+#ifdef VC2_PRICE8
+  p16_group8(make_uint2(w0.x, w0.y), lut, G0, L0, last0);
+  p16_group8(make_uint2(w0.z, w0.w), lut, G1, L1, last1);
+  int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
+  bool slow = (w0.x & w0.y & w0.z & w0.w) == 0x80808080u && fb == 3.f && maxf > 0.f; // (a test of the same shape; never true)
+#else
   p16_group(w0, fb, lut, G0, L0, last0, maxf);
   p16_group(w1, fb, lut, G1, L1, last1, maxf);
   int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
   bool slow = maxf >= 32768.f /* an escape of the store */ || maxf * fb >= (float)(P16_MAXQ + 1) || max(L0, L1) > 63;
+#endif
   if (!has_body) { body_bits = 0; body_last = 0; slow = false; }
   // ---- head: one coefficient, code by arithmetic
   unsigned hcode = 0;

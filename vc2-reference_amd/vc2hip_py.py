@@ -57,7 +57,7 @@ EXPORTS = [
     "vc2hip_decode_picture_ld", "vc2hip_encode_batch_dev", "vc2hip_decode_batch_dev",
     "vc2hip_profile_enable", "vc2hip_profile_only", "vc2hip_profile_count", "vc2hip_profile_get", "vc2hip_profile_reset",
     "vc2hip_host_alloc", "vc2hip_host_free", "vc2hip_encode_picture_begin", "vc2hip_encode_picture_end",
-    "vc2hip_decode_picture_begin", "vc2hip_decode_picture_end",
+    "vc2hip_decode_picture_begin", "vc2hip_decode_picture_end", "vc2hip_band_plane_bits",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library():
     lib.vc2hip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_double)]
     lib.vc2hip_profile_reset.argtypes = [vp]
+    lib.vc2hip_band_plane_bits.argtypes = [vp]
     lib.vc2hip_host_alloc.argtypes = [C.c_size_t]
     lib.vc2hip_host_alloc.restype = vp
     lib.vc2hip_host_free.argtypes = [vp]
@@ -154,6 +155,8 @@ class Vc2Hip:
     def __init__(self, device=0, stream=None, flags=0):
         self.lib = load_library()
         h = C.c_void_p()
+        if stream is not None and flags:
+            raise ValueError("vc2hip_create_on_stream takes no flags: give either a stream or flags")
         if stream is None and flags:
             rc = self.lib.vc2hip_create_with_flags(device, C.c_uint(flags), C.byref(h))
         elif stream is None:
@@ -413,6 +416,10 @@ class Vc2Hip:
 
     def profile_reset(self):
         self.lib.vc2hip_profile_reset(self.h)
+
+    def band_plane_bits(self):
+        """0 / 16 / 8: the band planes of this context's most recent HQ decode call (vc2hip_band_plane_bits)"""
+        return int(self.lib.vc2hip_band_plane_bits(self.h))
 
     def profile(self):
         out = {}
