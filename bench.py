@@ -634,14 +634,19 @@ def main():
 
 
 OTHER_CFGS = {
-    # name: geometry and coding parameters of BASELINE.json configs[0], [2], [3], [4]; B pictures per step
-    "cfg1": dict(w=1920, h=1080, cf="422", bits=10, wb=2, k="LeGall", d=2, u=2, a=4, B=16, kw=dict(q=12, scalar=1),
+    # name: geometry and coding parameters of BASELINE.json configs[0], [2], [3], [4]; B pictures per step.
+    # B from the round-6 sweep (tools/batch_sweep.sh, one box, encode+decode Gpixel/s; VERDICT r5 item 7b -- rounds 1 - 5 ran these
+    # lines at 16 (cfg 4: 4) pictures per step while the headline ran 128):
+    #   cfg1  16 / 32 / 64 / 128: 51.6 / 62.0 / 69.1 / 73.3      cfg3  16 / 32 / 64 / 128: 73.7 / 82.6 / 88.3 / 93.5
+    #   cfg4  4 / 8 / 16 / 32:    45.7 / 50.6 / 53.9 / 55.4      cfg5 (encode+decode there) 16 ... 256: 7.8 / 9.2 / 9.9 / 10.3 / 10.5
+    # (the step amortises its ~16 launches, their ramps and tails; cfg 3 takes as many of the headline's pictures as exist)
+    "cfg1": dict(w=1920, h=1080, cf="422", bits=10, wb=2, k="LeGall", d=2, u=2, a=4, B=128, kw=dict(q=12, scalar=1),
                  workload="BASELINE cfg1: 1920x1080 4:2:2 10-bit HQ_ConstQ LeGall depth 2, -u 2 -a 4 -q 12"),
-    "cfg3": dict(w=3840, h=2160, cf="422", bits=10, wb=2, k="DD97", d=4, u=1, a=2, B=16, kw=dict(mode="HQ_CBR", s=8294400, scalar=2),
+    "cfg3": dict(w=3840, h=2160, cf="422", bits=10, wb=2, k="DD97", d=4, u=1, a=2, B=128, kw=dict(mode="HQ_CBR", s=8294400, scalar=2),
                  workload="BASELINE cfg3: UHD-1 3840x2160 4:2:2 10-bit HQ_CBR DD97 depth 4, -u 1 -a 2 -s 8294400 -S 2"),
-    "cfg4": dict(w=7680, h=4320, cf="444", bits=12, wb=2, k="Fidelity", d=5, u=1, a=1, B=4, kw=dict(q=40, scalar=8),
-                 workload="BASELINE cfg4: UHD-2 7680x4320 4:4:4 12-bit HQ_ConstQ Fidelity depth 5, -u 1 -a 1 -q 40 -S 8 (4 pictures on ONE GPU)"),
-    "cfg5": dict(w=1920, h=1080, cf="422", bits=8, wb=1, k="LeGall", d=3, u=1, a=2, B=16, kw=dict(mode="LD", s=1036800),
+    "cfg4": dict(w=7680, h=4320, cf="444", bits=12, wb=2, k="Fidelity", d=5, u=1, a=1, B=16, kw=dict(q=40, scalar=8),
+                 workload="BASELINE cfg4: UHD-2 7680x4320 4:4:4 12-bit HQ_ConstQ Fidelity depth 5, -u 1 -a 1 -q 40 -S 8 (16 pictures on ONE GPU)"),
+    "cfg5": dict(w=1920, h=1080, cf="422", bits=8, wb=1, k="LeGall", d=3, u=1, a=2, B=128, kw=dict(mode="LD", s=1036800),
                  workload="BASELINE cfg5: 1920x1080 4:2:2 8-bit LD LeGall depth 3, -u 1 -a 2 -s 1036800, DECODE only"),
 }
 

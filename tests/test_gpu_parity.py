@@ -397,6 +397,45 @@ def test_cfg2_timed_path_at_full_size_in_every_plane_form(oracle, flags, forms):
     hip.close()
 
 
+@pytest.mark.parametrize("n", [3, 5])
+def test_shared_slots_hold_whole_tiles(oracle, n):
+    """HD-size slices (16 x 8 luma samples, LeGall depth 2): the slice coder puts sixteen slices of a workgroup into one shared
+    slot, so a picture's slots are WHOLE tiles.  1920 x 72 has 1080 slices = 67.5 tiles: rounds 3 - 5 sized the slot buffer by
+    the slice count, every picture's tiles started 8 slots further into it than the allocation assumed, and the last pictures
+    of a batch ran off its end -- hidden by the allocator's rounding until 136 pictures of 1080p faulted in the compaction
+    (round 6).  Noise at a low index makes every slice long, so the last tile's bytes reach far into its slots; a fresh context
+    (its buffers are sized by this batch alone); every slot against the oracle."""
+    import torch
+    import vc2hip_py
+    hip = vc2hip_py.Vc2Hip()
+    w, h = 1920, 72
+    raw = noise_frame(w, h, "422", 10, seed=4100 + n)
+    p = make_params(w, h, "422", 10, "LeGall", 2, 2, 4, q=6, scalar=2)
+    stream = oracle.encode_stream(p, raw, 1)
+    dec, _ = oracle.decode_stream(p, stream, 1)
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "LeGall", 2, 2, 4, q=6, scalar=2)
+    assert (cp.y_slices * cp.x_slices) % 16 == 8
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(raw * n), dtype=torch.uint8).to(dev)
+    d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+    hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+    hip.sync()
+    lens = d_len.cpu().tolist()
+    pay = d_pay.cpu().numpy()
+    out = d_out.cpu().numpy().tobytes()
+    for k in range(n):
+        body = bytes(pay[k * stride:k * stride + lens[k]])
+        assert body == stream[-13 - len(body):-13], k
+        assert out[k * rb:(k + 1) * rb] == dec, k
+    hip.close()
+
+
 def test_cfg3_uhd_cbr_reference_digests(hip, oracle):
     """BASELINE config 3 (UHD-1 HQ_CBR, -s 8294400 -S 2) at full size: per-slice quantiser search + CBR
     packing on the GPU; stream and decoded picture digests of reference output."""

@@ -3,7 +3,7 @@
 HQ_CBR -- the decoder's byte-budget short cut and its fall-back -- and LD).  Both must
 either refuse the payload or return the same picture.
 
-  python tools/fuzz_decode.py <seed> <cases>"""
+  python tools/fuzz_decode.py <seed> <cases>        (FUZZ_BIG=1: pictures of 1000 - 7000 slices, payloads of many index chunks)"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vc2-reference_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -30,6 +30,8 @@ for case in range(count):
     a = rnd.choice([1, 2, 4]) * (1 if cf == "444" else 2)
     wide = rnd.random() < 0.3
     ys, xs = rnd.choice([1, 2, 4]), (rnd.choice([32, 64]) if wide else rnd.choice([1, 3, 8]))
+    if os.environ.get("FUZZ_BIG"):   # payloads of many index chunks (round 6: the recorded walks of the slice index): 1000 - 7000 slices
+        ys, xs = rnd.choice([16, 33, 56]), rnd.choice([64, 120])
     h, w = ys * u * unit, xs * a * unit
     scalar, prefix, q = rnd.choice([1, 2, 4]), rnd.choice([0, 0, 2]), rnd.choice([0, 8, 20])
     raw = (noise_frame if rnd.random() < 0.3 else synth)(w, h, cf, 10, rnd.randrange(1 << 30))
@@ -56,7 +58,7 @@ for case in range(count):
     head = stream[:len(stream) - 13 - len(payload0)]
     for m in range(4):
         pay = bytearray(payload0)
-        for _ in range(rnd.choice([1, 1, 2, 5])):
+        for _ in range(rnd.choice([1, 1, 2, 5]) * (8 if os.environ.get("FUZZ_BIG") else 1)):
             pay[rnd.randrange(len(pay))] = rnd.choice([0, 0xFF, rnd.randrange(256)])
         pay = bytes(pay)
         try:

@@ -5,7 +5,9 @@ chroma formats, bit depths, kernels, depths, slice sizes, modes.  Prints the fai
 
 wide: planes of 512 ... 2560 samples across and a few slice rows, so that levels go through the streaming transform
 kernels and the decoder's band planes (the default sizes stay below them), mixed with tile-kernel levels underneath.
-tall: such planes with 3 ... 33 slice rows (round 5: the segments of the streaming and the two-level kernels)."""
+tall: such planes with 3 ... 33 slice rows (round 5: the segments of the streaming and the two-level kernels).
+FUZZ_BATCH=1 (round 6): every case through vc2hip_encode_batch_dev / vc2hip_decode_batch_dev with 2 ... 8 pictures on a context of
+its own."""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vc2-reference_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -88,10 +90,35 @@ while done < count:
         dec, _ = oracle.decode_stream(p, stream, 1)
         fmt = vc2hip_py.picture_format(w, h, cf, bits, wb)
         cp = vc2hip_py.coding_params(hip.lib, fmt, kernel, depth, u, a, **kw)
-        payload, _ = hip.encode_picture_hq(raw, fmt, cp)
-        ok_e = stream[:-13].endswith(payload)
-        out = hip.decode_picture(payload, fmt, cp)
-        ok_d = out == dec
+        if os.environ.get("FUZZ_BATCH"):
+            # round 6: the device-resident BATCH path on a context of its own (its workspaces are sized by this case alone, so a
+            # buffer that is a few slots short runs off its end instead of into the slack of an earlier, larger case): n copies
+            # of the picture, every slot against the oracle
+            import torch
+            nb = rnd.choice([2, 3, 5, 8])
+            hb = vc2hip_py.Vc2Hip(0, flags=_flags)
+            rb = hb.raw_picture_bytes(fmt)
+            assert rb == len(raw)
+            stride = (hb.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+            dev = torch.device("cuda:0")
+            rpad = (-rb) % 16   # (pictures of a batch are packed back to back; the buffers must be 16-byte aligned as a whole)
+            d_raw = torch.frombuffer(bytearray(raw * nb + bytes(rpad)), dtype=torch.uint8).to(dev)
+            d_pay = torch.zeros(nb * stride, dtype=torch.uint8, device=dev); d_len = torch.zeros(nb, dtype=torch.int64, device=dev)
+            d_out = torch.zeros(nb * rb + rpad, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            hb.encode_batch_dev(d_raw.data_ptr(), nb, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+            hb.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), nb, fmt, cp, d_out.data_ptr())
+            hb.sync()
+            lens = d_len.cpu().tolist(); pay = d_pay.cpu().numpy(); outs = d_out.cpu().numpy().tobytes()
+            ok_e = all(stream[:-13].endswith(bytes(pay[k * stride:k * stride + lens[k]])) and lens[k] > 0 for k in range(nb))
+            ok_d = all(outs[k * rb:(k + 1) * rb] == dec for k in range(nb))
+            hb.close()
+            del d_raw, d_pay, d_len, d_out
+        else:
+            payload, _ = hip.encode_picture_hq(raw, fmt, cp)
+            ok_e = stream[:-13].endswith(payload)
+            out = hip.decode_picture(payload, fmt, cp)
+            ok_d = out == dec
         if not (ok_e and ok_d):
             bad += 1
             print("MISMATCH", "enc" if not ok_e else "", "dec" if not ok_d else "", desc)

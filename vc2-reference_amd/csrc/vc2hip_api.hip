@@ -104,6 +104,18 @@ void vc2_prof_end(Launcher &L, hipStream_t s) {
   if (le != hipSuccess && L.launch_error.empty())
     L.launch_error = std::string("kernel launch failed (") + (L.last_name ? L.last_name : "?") + "): " + hipGetErrorString(le);
   L.cur_entry = -1;
+#ifdef VC2HIP_ABLATE // VC2HIP_DEBUG_SYNC=1 (tools/probe/fault_bisect.py): wait for every stage and name it -- the last name printed before a fault is the stage at fault
+  {
+    static const bool dbg_sync = getenv("VC2HIP_DEBUG_SYNC") != nullptr;
+    if (dbg_sync) {
+      fprintf(stderr, "vc2hip stage %s ...", L.last_name ? L.last_name : "?");
+      fflush(stderr);
+      const hipError_t e = hipStreamSynchronize(s);
+      fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+      fflush(stderr);
+    }
+  }
+#endif
 }
 void vc2_prof_break(Launcher &L) { (void)L; }
 
@@ -1004,7 +1016,13 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const void *store, cons
   // (images kept in the slots themselves: room for the two guard words of an image)
   const int slot = (int)((max_slice_bytes(prefix, scalar) + (gimg ? 8 : 0) + 15) & ~(size_t)15);
   uint8_t *slots; uint32_t *sizes, *offs;
-  NEED(c, B_SLOTS, (size_t)n * ns * slot + 32, slots); // (+32: the compaction reads whole 16-byte pieces and the dword behind them)
+  // Shared slots (below) hold WHOLE tiles: a picture's last tile has room for all its spt slices even when fewer exist
+  // (1080p: 16200 slices in 1013 tiles of 16 = room for 16208).  Rounds 3 - 5 sized the buffer by the slice count; the
+  // 2 MiB rounding of large workspaces hid the n * 8 slots that were missing until a batch of 136 HD pictures ran the
+  // compaction off the end of it (round 6: tools/probe/fault_bisect.py, tests/test_gpu_parity.py::test_shared_slots_hold_whole_tiles)
+  const int spt_room = (gimg || d_cbr_bytes) ? 0 : vc2_pack_slices_per_tile(p);
+  const size_t slot_count = spt_room ? (size_t)((ns + spt_room - 1) / spt_room) * spt_room : (size_t)ns;
+  NEED(c, B_SLOTS, (size_t)n * slot_count * slot + 32, slots); // (+32: the compaction reads whole 16-byte pieces and the dword behind them)
   NEED(c, B_SIZES, (size_t)n * ns * 4, sizes);
   NEED(c, B_OFFS, (size_t)n * ns * 4, offs);
   p.slots = slots; p.slot_bytes = slot; p.sizes = sizes;
