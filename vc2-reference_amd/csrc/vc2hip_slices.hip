@@ -2434,10 +2434,6 @@ __device__ __forceinline__ int slice_len_lds(const uint8_t *b, int pos, int pref
   return q - pos;
 }
 
-#ifndef VC2_IDX_STAGE
-#define VC2_IDX_STAGE 0 // 1: every thread's requests go out before the first of them is used (round 6: measured)
-#endif
-#if !VC2_IDX_STAGE
 __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long plen,
                             unsigned long long c0, int nbytes) {
   // nbytes is a multiple of 16; payload slots and chunk starts are 16-byte aligned
@@ -2453,49 +2449,6 @@ __device__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long
     *(uint4 *)(lds + i) = v;
   }
 }
-#else
-// (round 6: every thread's requests go out before the first of them is used -- up to four 16-byte pieces per thread; the loop
-// that loaded and stored piece by piece paid the trip to memory once per piece: "chunk in 1.9 us" of a workgroup's ~8 us)
-__device__ __forceinline__ void stage_chunk(uint8_t *lds, const uint8_t *pay, unsigned long long plen,
-                                            unsigned long long c0, int nbytes) {
-  // nbytes is a multiple of 16; payload slots and chunk starts are 16-byte aligned
-  constexpr int MAXP = 4;
-  const int nt16 = (int)blockDim.x * 16;
-  for (int i0 = threadIdx.x * 16; i0 < nbytes; i0 += MAXP * nt16) {
-    uint4 v[MAXP];
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-      const int i = i0 + k * nt16;
-      v[k] = make_uint4(0, 0, 0, 0);
-      if (i < nbytes && c0 + i + 16 <= plen) v[k] = *(const uint4 *)(pay + c0 + i);
-    }
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-      const int i = i0 + k * nt16;
-      if (i >= nbytes) continue;
-      const unsigned long long a = c0 + i;
-      if (a + 16 > plen && a < plen) { // the piece the payload ends in
-        unsigned w[4] = {0, 0, 0, 0};
-        for (int b = 0; b < 16; ++b) if (a + b < plen) w[b >> 2] |= (unsigned)pay[a + b] << (8 * (b & 3));
-        v[k] = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-      *(uint4 *)(lds + i) = v[k];
-    }
-  }
-}
-#endif
-
-// The recorded walk (round 6).  The table kernel's walks from the landing positions visit slice starts; the true chain
-// through the chunk is one of them, and the others run into it sooner or later (a walk that ever stands on a true slice
-// start stays on the chain).  The walk from the landing position MOST entries arrive at -- every true slice start of the
-// entry region arrives at the true chain's -- leaves its positions behind (chunk-relative, ascending, up to IDX_PATH_HOPS).
-// The emit kernel, once the chunk's entry is known, walks through memory only until it stands ON a recorded position --
-// from there on the two walks are the same walk -- copies the rest, and walks on from the last recorded position itself,
-// so that whatever the serial walk does at a chunk's or the payload's end it still does.  A recorded walk it never meets
-// (the popular landing was not the chain's and the two do not merge inside the chunk) costs it nothing but the
-// comparisons: it is then the serial walk of rounds 2 - 5.
-//   per chunk: [0] positions recorded, [8 ...] the positions (16-bit words)
-constexpr int IDX_PATH_HOPS = 248, IDX_PATH_STRIDE = 8 + IDX_PATH_HOPS;
 
 static constexpr int IDX_MAX_E = 32767;  // beyond: serial walk (k_index_serial)
 constexpr int idx_threads(int CH, int GS = 0) { return (CH >> GS) <= 8192 ? 512 : 1024; } // by the chunk's candidate positions (GS: k_index_tables_nx)
@@ -2520,7 +2473,7 @@ template <int CH, int GS>
 __global__ __launch_bounds__(idx_threads(CH, GS)) void k_index_tables_nx(const uint8_t *payload, long long stride,
                                                                  const unsigned long long *lens, unsigned *tables,
                                                                  int n_chunks, int E, int prefix, int scalar, unsigned *err, const unsigned *skip,
-                                                                 int merge, unsigned short *paths) {
+                                                                 int merge) {
   constexpr int NT = idx_threads(CH, GS), NP = CH >> GS; // candidate positions of a chunk
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_b[];
@@ -2557,9 +2510,7 @@ __global__ __launch_bounds__(idx_threads(CH, GS)) void k_index_tables_nx(const u
   }
   __syncthreads();
   unsigned *tab = tables + ((size_t)pic * n_chunks + chunk) * EU;
-  unsigned short *pth = paths ? paths + ((size_t)pic * n_chunks + chunk) * IDX_PATH_STRIDE : nullptr;
   if (!merge) {
-    if (pth && threadIdx.x == 0) pth[0] = 0; // no recorded walk: the emit kernel walks through memory
     for (int e = threadIdx.x; e < EU; e += NT) {
       int pos = e << GS, cnt = 0;
       if (pos >= lim) pos = CH; // starts behind the payload end: no slice
@@ -2576,10 +2527,9 @@ __global__ __launch_bounds__(idx_threads(CH, GS)) void k_index_tables_nx(const u
   unsigned *W = (unsigned *)(nx + NP);               // per candidate position of [E, 2E): the result of a walk from it (exit offset << 16 | slices)
   unsigned *need = W + EU;                           // one bit per candidate position of [E, 2E): some walk landed here
   unsigned short *list = (unsigned short *)(need + (EU + 31) / 32);  // the landing positions, dense
-  __shared__ unsigned s_count, s_best;
+  __shared__ unsigned s_count;
   for (int t = threadIdx.x; t < (EU + 31) / 32; t += NT) need[t] = 0;
-  if (pth) for (int t = threadIdx.x; t < EU; t += NT) W[t] = 0; // (until the landing walks write their results: arrivals per landing position)
-  if (threadIdx.x == 0) { s_count = 0; s_best = 0; }
+  if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   constexpr int EPT = 4096 / NT; // entries per thread (the launcher merges only entry regions of up to 4096 offsets)
   int la[EPT], ca[EPT];
@@ -2594,26 +2544,14 @@ __global__ __launch_bounds__(idx_threads(CH, GS)) void k_index_tables_nx(const u
       if (pos < CH) {
         const int t = (pos - E) >> GS;
         if (!(atomicOr(&need[t >> 5], 1u << (t & 31)) >> (t & 31) & 1u)) list[atomicAdd(&s_count, 1u)] = (unsigned short)t;
-        if (pth) atomicAdd(&W[t], 1u);
       }
     }
   }
   __syncthreads();
-  if (pth) { // the landing position most entries arrive at (ties: any)
-    for (int i = threadIdx.x; i < (int)s_count; i += NT) atomicMax(&s_best, (min(W[list[i]], 0xFFFFu) << 16) | (unsigned)i);
-    __syncthreads();
-    if (s_count == 0 && threadIdx.x == 0) pth[0] = 0;
-  }
-  const int best = pth ? (int)(s_best & 0xFFFFu) : -1;
   for (int i = threadIdx.x; i < (int)s_count; i += NT) {
     const int t = list[i];
     int pos = E + (t << GS), cnt = 0;
-    if (i == best) { // the same walk, leaving its positions behind
-      while (pos < CH) { if (cnt < IDX_PATH_HOPS) pth[8 + cnt] = (unsigned short)pos; pos = nx[pos >> GS]; ++cnt; }
-      pth[0] = (unsigned short)min(cnt, IDX_PATH_HOPS);
-    } else {
-      while (pos < CH) { pos = nx[pos >> GS]; ++cnt; }
-    }
+    while (pos < CH) { pos = nx[pos >> GS]; ++cnt; }
     W[t] = (unsigned)(pos - CH) << 16 | (unsigned)cnt;
   }
   __syncthreads();
@@ -2762,17 +2700,14 @@ __global__ __launch_bounds__(1024) void k_index_chain(const unsigned long long *
 }
 
 // One lane per chunk walks from the chunk's (now known) entry and writes the offsets: three dependent byte loads per
-// slice, served by L2 or beyond -- ~110 slices of a 16 KiB chunk of UHD pictures, 0.21 ms per 128 pictures at one
-// wavefront per SIMD, all of it waiting.  Round 6: with the table kernel's recorded walk (IDX_PATH_*, above) the lane
-// walks through memory only until it stands on a recorded position, copies the rest of that walk, and walks on from
-// its last position: the chunk's end, the payload's end and the error of a payload that ends too early are the serial
-// walk's own code.
+// slice, served by L2 -- a chunk's lane needs ~60 of its 8192 bytes, and all chunks of the batch walk at the same time
+// (round 2 staged every chunk whole into LDS for one walking lane: eight chunks per CU at a time, 0.047 ms).
 __global__ __launch_bounds__(64) void k_index_emit(const uint8_t *payload, long long stride,
                                                    const unsigned long long *lens, const uint2 *entries,
                                                    uint32_t *offsets, int n_chunks, int E, int n_slices,
-                                                   int prefix, int scalar, unsigned *err, int IDX_CH, const unsigned *skip,
-                                                   const unsigned short *paths, int gsh) {
+                                                   int prefix, int scalar, unsigned *err, int IDX_CH, const unsigned *skip) {
   if (skip && *skip == 0) return; // the HQ_CBR short cut found every slice where the byte budgets put it (k_cbr_index_check)
+  (void)E;
   const int chunk = blockIdx.x * 64 + threadIdx.x, pic = blockIdx.y;
   if (chunk >= n_chunks) return;
   const unsigned long long plen = min(lens[pic], (unsigned long long)stride), c0 = (unsigned long long)chunk * IDX_CH;
@@ -2780,71 +2715,17 @@ __global__ __launch_bounds__(64) void k_index_emit(const uint8_t *payload, long 
   const uint2 en = entries[(size_t)pic * n_chunks + chunk];
   if ((int)en.y >= n_slices || (int)en.x >= IDX_CH) return;
   const uint8_t *pay = payload + (size_t)pic * stride;
-  uint32_t *offs = offsets + (size_t)pic * n_slices;
   unsigned long long pos = c0 + en.x;
   const unsigned long long end = c0 + IDX_CH;
   int k = (int)en.y;
-  bool dead = false;
-  auto walk = [&](unsigned long long stop) __attribute__((always_inline)) {
-    while (pos < stop && k < n_slices) {
-      offs[k] = (uint32_t)pos;
-      if (pos >= plen) { atomicOr(err, VC2_DEVERR_STREAM); dead = true; break; } // (what follows starts behind the payload too)
-      unsigned long long q = pos + prefix + 1;
-      for (int c = 0; c < 3; ++c) q += 1 + (q < plen ? (unsigned long long)pay[q] * scalar : 0ull);
-      pos = q;
-      ++k;
-    }
-  };
-  if (paths) {
-    const unsigned short *pth = paths + ((size_t)pic * n_chunks + chunk) * IDX_PATH_STRIDE;
-    const int nh = (int)pth[0];
-    const unsigned short *hp = pth + 8;
-    if (nh > 0) {
-      // the serial walk, until it stands on a recorded position (both walks ascend: one pass over the recorded ones)
-      int i = 0;
-      unsigned nextp = hp[0];
-      bool met = false;
-      while (pos < end && k < n_slices) {
-        const unsigned rel = (unsigned)(pos - c0);
-        while (nextp < rel && i + 1 < nh) nextp = hp[++i];
-        if (nextp == rel) { met = true; break; }
-        if (nextp < rel) break; // beyond the last recorded position: the serial walk finishes the chunk
-        offs[k] = (uint32_t)pos;
-        if (pos >= plen) { atomicOr(err, VC2_DEVERR_STREAM); dead = true; break; }
-        unsigned long long q = pos + prefix + 1;
-        for (int c = 0; c < 3; ++c) q += 1 + (q < plen ? (unsigned long long)pay[q] * scalar : 0ull);
-        pos = q;
-        ++k;
-      }
-      if (met) {
-        // positions i .. nh - 2 are copied; the walk goes on FROM position nh - 1 (it writes that one itself)
-        const int m = min(nh - 1 - i, n_slices - k);
-        const unsigned c032 = (unsigned)c0;
-        // (16-byte loads of eight positions where the recorded walk's alignment allows: a loop of 2-byte loads is a chain of
-        // ~100 trips to L2)
-        int j = 0;
-        for (; j < m && ((i + j) & 7); ++j) offs[k + j] = c032 + hp[i + j];
-        for (; j + 16 <= m; j += 16) {
-          const uint4 a = *(const uint4 *)(hp + i + j), b = *(const uint4 *)(hp + i + j + 8);
-          uint32_t *o = offs + k + j;
-          o[0] = c032 + (a.x & 0xFFFFu); o[1] = c032 + (a.x >> 16); o[2] = c032 + (a.y & 0xFFFFu); o[3] = c032 + (a.y >> 16);
-          o[4] = c032 + (a.z & 0xFFFFu); o[5] = c032 + (a.z >> 16); o[6] = c032 + (a.w & 0xFFFFu); o[7] = c032 + (a.w >> 16);
-          o[8] = c032 + (b.x & 0xFFFFu); o[9] = c032 + (b.x >> 16); o[10] = c032 + (b.y & 0xFFFFu); o[11] = c032 + (b.y >> 16);
-          o[12] = c032 + (b.z & 0xFFFFu); o[13] = c032 + (b.z >> 16); o[14] = c032 + (b.w & 0xFFFFu); o[15] = c032 + (b.w >> 16);
-        }
-        for (; j + 8 <= m; j += 8) {
-          const uint4 a = *(const uint4 *)(hp + i + j);
-          uint32_t *o = offs + k + j;
-          o[0] = c032 + (a.x & 0xFFFFu); o[1] = c032 + (a.x >> 16); o[2] = c032 + (a.y & 0xFFFFu); o[3] = c032 + (a.y >> 16);
-          o[4] = c032 + (a.z & 0xFFFFu); o[5] = c032 + (a.z >> 16); o[6] = c032 + (a.w & 0xFFFFu); o[7] = c032 + (a.w >> 16);
-        }
-        for (; j < m; ++j) offs[k + j] = c032 + hp[i + j];
-        k += m;
-        if (m == nh - 1 - i) pos = c0 + hp[nh - 1];
-      }
-    }
+  while (pos < end && k < n_slices) {
+    offsets[(size_t)pic * n_slices + k] = (uint32_t)pos;
+    if (pos >= plen) { atomicOr(err, VC2_DEVERR_STREAM); break; } // (what follows starts behind the payload too)
+    unsigned long long q = pos + prefix + 1;
+    for (int c = 0; c < 3; ++c) q += 1 + (q < plen ? (unsigned long long)pay[q] * scalar : 0ull);
+    pos = q;
+    ++k;
   }
-  if (!dead) walk(end);
 }
 
 static int idx_entries(int prefix, int scalar) { return prefix + 4 + 3 * 255 * scalar; }
@@ -2927,8 +2808,7 @@ size_t vc2_slice_index_workspace(int n_pictures, size_t max_payload, int prefix,
   if (n_chunks > (size_t)1024 * 16) return 256; // serial walk (see vc2_launch_slice_index)
   const size_t n_groups = (n_chunks + IDX_GROUP - 1) / IDX_GROUP;
   const size_t n_supers = (n_groups + IDX_GROUP - 1) / IDX_GROUP;
-  return (size_t)n_pictures * (n_chunks * E * sizeof(unsigned) + (n_chunks + (n_groups + n_supers) * E) * sizeof(uint2) +
-                               n_chunks * (size_t)IDX_PATH_STRIDE * sizeof(unsigned short)) + 1024;
+  return (size_t)n_pictures * (n_chunks * E * sizeof(unsigned) + (n_chunks + (n_groups + n_supers) * E) * sizeof(uint2)) + 512;
 }
 
 void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long payload_stride,
@@ -2957,11 +2837,6 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   unsigned *tables = (unsigned *)workspace;
   uint2 *entries = (uint2 *)(((size_t)(tables + (size_t)n_pictures * n_chunks * EU) + 15) & ~(size_t)15);
   const size_t stage_bytes = (size_t)((ch + E + 16 + 15) & ~15);
-  // (the arrays behind the chunk entries, as laid out further down; the recorded walks -- IDX_PATH_* -- behind them all)
-  const int n_groups_ws = (n_chunks + IDX_GROUP - 1) / IDX_GROUP, n_supers_ws = (n_groups_ws + IDX_GROUP - 1) / IDX_GROUP;
-  unsigned short *paths = (unsigned short *)(((size_t)(entries + (size_t)n_pictures * n_chunks + (size_t)n_pictures * (n_groups_ws + n_supers_ws) * EU) + 15) & ~(size_t)15);
-  static const bool no_paths = vc2_tune_int("VC2HIP_IDX_NO_PATHS", 0) != 0; // (ablation build: the serial emit walk of rounds 3 - 5)
-  if (no_paths) paths = nullptr;
   vc2_prof_begin(L, "slice_index_tables", s);
   {
     // merged walks (see the kernel): entry regions of up to 4096 offsets whose landing region lies inside the chunk
@@ -2972,7 +2847,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   do {                                                                                                                        \
     vc2_allow_lds((const void *)k_index_tables_nx<CH, GS>, lds);                                                                  \
     VC2_LAUNCH(L, (k_index_tables_nx<CH, GS>), dim3(n_chunks, n_pictures), dim3(idx_threads(CH, GS)), lds, s, payload, payload_stride, \
-               lens, tables, n_chunks, E, prefix, scalar, err, skip, merge, paths);                                           \
+               lens, tables, n_chunks, E, prefix, scalar, err, skip, merge);                                                  \
   } while (0)
 #define VC2_IDX_TABLES_G(CH) do { if (gsh == 0) VC2_IDX_TABLES(CH, 0); else if (gsh == 1) VC2_IDX_TABLES(CH, 1); else VC2_IDX_TABLES(CH, 2); } while (0)
     if (ch == 8192) VC2_IDX_TABLES_G(8192);
@@ -3002,8 +2877,7 @@ void vc2_launch_slice_index(Launcher &L, const uint8_t *payload, long long paylo
   vc2_prof_end(L, s);
   vc2_prof_begin(L, "slice_index_emit", s);
   VC2_LAUNCH(L, k_index_emit, dim3((n_chunks + 63) / 64, n_pictures), dim3(64), 0, s, payload,
-                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch, skip,
-                     (const unsigned short *)paths, gsh);
+                     payload_stride, lens, entries, offsets, n_chunks, E, n_slices, prefix, scalar, err, ch, skip);
   vc2_prof_end(L, s);
 }
 
