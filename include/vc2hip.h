@@ -64,11 +64,12 @@ int vc2hip_create(int device, vc2hip_ctx **out);
 #define VC2HIP_FLAG_NO_HEADS        0x010u /* no side-by-side record heads for the deep levels */
 #define VC2HIP_FLAG_NO_CBR_INDEX    0x020u /* HQ_CBR decode always through the general slice index */
 #define VC2HIP_FLAG_GENERIC_DWT     0x040u /* generic transform kernels only */
-#define VC2HIP_FLAG_SINGLE_PASS_VBR 0x080u /* VBR packing with decoupled look-back instead of slots + scan + compaction */
+#define VC2HIP_FLAG_SINGLE_PASS_VBR 0x080u /* VBR packing with decoupled look-back instead of slots + scan + compaction, whatever the batch (default: from 112 pictures per call on, where the round-4 slice coder applies) */
 #define VC2HIP_FLAG_CBR_GENERAL     0x100u /* HQ_CBR quantiser search without the register kernels */
 #define VC2HIP_FLAG_LD_DIAGONALS    0x200u /* LD index search: one launch per slice anti-diagonal instead of one launch */
 #define VC2HIP_FLAG_PLANES8_ALWAYS  0x400u /* decoder: one byte per band-plane coefficient from the first picture (default: once a batch has shown small coefficients) */
 #define VC2HIP_FLAG_PLANES8_NEVER   0x800u /* decoder: 16-bit band planes only */
+#define VC2HIP_FLAG_TWO_PASS_VBR    0x1000u /* VBR packing through slots + scan + compaction also where the one-pass slice coder is the default */
 int vc2hip_create_with_flags(int device, unsigned flags, vc2hip_ctx **out);
 /* same, but launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int vc2hip_create_on_stream(int device, void *hip_stream, vc2hip_ctx **out);

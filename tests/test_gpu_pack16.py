@@ -141,3 +141,53 @@ for (w, h, cf, bits, k, d, u, a, q, sc, noise) in (({W}, {H}, "422", 10, "DD97",
     assert w1 == 1024 and g1 > 900 and big1 > 900   # noise, q = 0: quotients beyond the table nearly everywhere
     assert w2 == 3 * 1024 and g2 == 0               # large slices, 12-bit Fidelity: heads beyond 2^20 stay on the table path
     assert w3 == 3 * 1024 and g3 > 2500
+
+
+@pytest.mark.parametrize("n,flags", [(113, ""), (3, "SINGLE_PASS_VBR"), (113, "TWO_PASS_VBR")])
+def test_one_pass_coder_is_the_default_from_112_pictures_on(oracle, n, flags):
+    """Round 6: k_hq_pack16 in its look-back form writes every slice where it belongs in the payload -- no slots, no scan of
+    the sizes, no compaction.  The library takes it by itself from 112 pictures per call on (the grid puts the same tile of
+    all pictures side by side; with fewer the predecessor tile is too close), with VC2HIP_FLAG_SINGLE_PASS_VBR for any batch,
+    never with VC2HIP_FLAG_TWO_PASS_VBR.  2176 x 272: 68 x 17 slices (the 16-bit store's kernels take widths that are multiples of
+    128 samples, so a picture's slices always fill whole tiles of four: tools/probe/pack16_geoms.py); five different pictures in turn -- smooth, noise (the general coder: quotients
+    beyond the table), half and half -- so that neighbouring pictures' slices differ in length; every payload, every length
+    and every decoded picture against the oracle, and the library's launch profile says which path ran."""
+    import torch
+    import vc2hip_py
+    hip = vc2hip_py.Vc2Hip(flags=sum(vc2hip_py.FLAGS[f] for f in flags.split(",") if f))
+    w, h = 2176, 272
+    kinds = [synth(w, h, "422", 10, 91), noise_frame(w, h, "422", 10, seed=92), _half_noise(w, h, "422", 10, 93),
+             synth(w, h, "422", 10, 94), _half_noise(w, h, "422", 10, 95)]
+    p = make_params(w, h, "422", 10, "DD97", 4, 1, 2, q=9, scalar=8)
+    want = []
+    for raw in kinds:
+        stream = oracle.encode_stream(p, raw, 1)
+        dec, _ = oracle.decode_stream(p, stream, 1)
+        want.append((stream, dec))
+    fmt, cp = _fmt_cp(hip, w, h, "422", 10, "DD97", 4, 1, 2, q=9, scalar=8)
+    rb = hip.raw_picture_bytes(fmt)
+    stride = (hip.max_payload_bytes(fmt, cp) + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    d_raw = torch.frombuffer(bytearray(b"".join(kinds[k % 5] for k in range(n))), dtype=torch.uint8).to(dev)
+    for call in range(2):   # (twice: the status words of the first call must not leak into the second)
+        d_pay = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_out = torch.zeros(n * rb, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        hip.profile_reset(); hip.profile_enable(True)
+        hip.encode_batch_dev(d_raw.data_ptr(), n, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
+        hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), n, fmt, cp, d_out.data_ptr())
+        hip.sync()
+        hip.profile_enable(False)
+        seen = {k for k, v in hip.profile().items() if v[0] > 0}
+        one_pass = flags == "SINGLE_PASS_VBR" or (flags == "" and n >= 112)
+        assert "hq_pack" in seen and ("slice_compact" in seen) == (not one_pass), (seen, n, flags)
+        lens = d_len.cpu().tolist()
+        pay = d_pay.cpu().numpy()
+        out = d_out.cpu().numpy()
+        for k in range(n):
+            stream, dec = want[k % 5]
+            body = bytes(pay[k * stride:k * stride + lens[k]])
+            assert body == stream[-13 - len(body):-13] and len(body) > 1000, (k, call)
+            assert out[k * rb:(k + 1) * rb].tobytes() == dec, (k, call)
+    hip.close()

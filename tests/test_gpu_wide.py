@@ -24,7 +24,7 @@ def variants():
     """default = everything on (two-level kernels, streaming kernels, 16-bit store, band planes, record heads); the others
     each take ONE of them away, so that every alternative path runs the same cases"""
     return {"default": _ctx(), "store32": _ctx("STORE32"), "tiles": _ctx("NO_STREAM"), "records": _ctx("NO_BANDPLANES"),
-            "levels": _ctx("NO_PAIR"), "bytes": _ctx("PLANES8_ALWAYS"), "words": _ctx("PLANES8_NEVER")}
+            "levels": _ctx("NO_PAIR"), "bytes": _ctx("PLANES8_ALWAYS"), "words": _ctx("PLANES8_NEVER"), "onepass": _ctx("SINGLE_PASS_VBR")}
 
 
 def _fmt_cp(hip, w, h, cf, bits, kernel, depth, u, a, **kw):

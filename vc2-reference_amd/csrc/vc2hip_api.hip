@@ -146,7 +146,13 @@ struct vc2hip_ctx {
   // VC2HIP_SINGLE_PASS_VBR=1: decoupled look-back inside the pack kernel -- measured 2x SLOWER on
   // MI355X when it was measured (1.28 vs 0.62 + 0.20 ms per 16 UHD pictures: the look-back sits on every workgroup's
   // critical path and the kernel is latency-bound), kept as a tested alternative.
+  // Round 6: where k_hq_pack16 codes the slices AND a launch holds enough pictures the look-back IS the default (its grid
+  // puts the same tile of all pictures side by side: vc2hip_pack16.h); VC2HIP_FLAG_TWO_PASS_VBR keeps the slots there too.
   bool two_pass_vbr = true;
+  bool force_two_pass_vbr = false;
+#ifndef VC2_ONE_PASS_MIN_PICTURES
+#define VC2_ONE_PASS_MIN_PICTURES 112
+#endif
   bool force_generic = false; // VC2HIP_GENERIC_DWT=1: always use the generic level kernels (tests)
   bool allow_store16 = true;  // VC2HIP_STORE32=1: keep the int32 coefficient store on the batch path too (tests, A/B)
   bool allow_planes = true; // decode: band planes for the streaming levels (A/B and test switch VC2HIP_NO_BANDPLANES)
@@ -343,7 +349,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
       {"VC2HIP_STORE32", VC2HIP_FLAG_STORE32}, {"VC2HIP_NO_STREAM", VC2HIP_FLAG_NO_STREAM}, {"VC2HIP_NO_PAIR", VC2HIP_FLAG_NO_PAIR},
       {"VC2HIP_NO_BANDPLANES", VC2HIP_FLAG_NO_BANDPLANES}, {"VC2HIP_NO_HEADS", VC2HIP_FLAG_NO_HEADS},
       {"VC2HIP_NO_CBR_INDEX", VC2HIP_FLAG_NO_CBR_INDEX}, {"VC2HIP_GENERIC_DWT", VC2HIP_FLAG_GENERIC_DWT},
-      {"VC2HIP_SINGLE_PASS_VBR", VC2HIP_FLAG_SINGLE_PASS_VBR}, {"VC2HIP_CBR_GENERAL", VC2HIP_FLAG_CBR_GENERAL},
+      {"VC2HIP_SINGLE_PASS_VBR", VC2HIP_FLAG_SINGLE_PASS_VBR}, {"VC2HIP_TWO_PASS_VBR", VC2HIP_FLAG_TWO_PASS_VBR}, {"VC2HIP_CBR_GENERAL", VC2HIP_FLAG_CBR_GENERAL},
       {"VC2HIP_PLANES8_ALWAYS", VC2HIP_FLAG_PLANES8_ALWAYS}, {"VC2HIP_PLANES8_NEVER", VC2HIP_FLAG_PLANES8_NEVER}};
     for (const auto &e : env) { const char *v = getenv(e.name); if (v && v[0] == '1') flags |= e.flag; }
     { const char *v = getenv("VC2HIP_LD_ROWS"); if (v && v[0] == '0') flags |= VC2HIP_FLAG_LD_DIAGONALS; }
@@ -359,6 +365,7 @@ static int create_common(int device, hipStream_t stream, bool own, vc2hip_ctx **
   c->allow_heads = !(flags & VC2HIP_FLAG_NO_HEADS);
   c->allow_cbr_index = !(flags & VC2HIP_FLAG_NO_CBR_INDEX);
   c->two_pass_vbr = !(flags & VC2HIP_FLAG_SINGLE_PASS_VBR);
+  c->force_two_pass_vbr = (flags & VC2HIP_FLAG_TWO_PASS_VBR) != 0;
   c->cbr_general = (flags & VC2HIP_FLAG_CBR_GENERAL) != 0;
   c->ld_diagonals = (flags & VC2HIP_FLAG_LD_DIAGONALS) != 0;
   c->flags = flags;
@@ -1003,7 +1010,14 @@ static int run_pack(vc2hip_ctx *c, const Geom &g, int n, const void *store, cons
     vc2_launch_fill_u64(c->L, d_lens, cbr_total, (size_t)n, c->stream);
     return VC2HIP_OK;
   }
-  if (!c->two_pass_vbr && !gimg && !d_cbr_bytes) { // single pass: slice offsets by decoupled look-back inside the pack kernel
+  // single pass: slice offsets by decoupled look-back inside the pack kernel -- the default where k_hq_pack16 codes the
+  // slices (round 6), everywhere with VC2HIP_FLAG_SINGLE_PASS_VBR, nowhere with VC2HIP_FLAG_TWO_PASS_VBR
+  // (the look-back pays from ~100 pictures per launch on: the grid puts the same tile of ALL pictures side by side, and a
+  // picture's tile t - 1 is only that many workgroups ahead of tile t.  128 UHD pictures: 1.69 ms against 1.47 + 0.51 for
+  // slots and compaction; 96: 1.46 = 1.46; 64: 1.15 against 0.75 + 0.25)
+  const bool one_pass = !gimg && !d_cbr_bytes &&
+                        (!c->two_pass_vbr || (!c->force_two_pass_vbr && n >= VC2_ONE_PASS_MIN_PICTURES && vc2_pack_one_pass_default(p)));
+  if (one_pass) {
     const long long lb_stride = (long long)((ns + 3) / 4) + 8;
     unsigned long long *lb;
     NEED(c, B_SIZES, (size_t)n * lb_stride * 8, lb);

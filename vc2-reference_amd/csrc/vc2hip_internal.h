@@ -294,6 +294,7 @@ size_t vc2_level_lds_bytes(int kernel, const LevelParams &p);
 
 void vc2_launch_pack(Launcher &L, const PackParams &p, int n_pictures, hipStream_t s);
 int vc2_pack_slices_per_tile(const PackParams &p);
+bool vc2_pack_one_pass_default(const PackParams &p); // VBR slices coded by k_hq_pack16: look-back, no slots
 void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets,
                            unsigned long long *totals, int n_slices, int n_pictures, hipStream_t s);
 void vc2_launch_compact(Launcher &L, const uint8_t *slots, int slot_bytes, const uint32_t *sizes,

@@ -83,7 +83,8 @@ static void vc2_upload_vlc_lut_s(hipStream_t s) {
 //   lane16[64 + c] = head[c],  lane16[67 + c] = body lanes of component c
 // (the offsets of a lane's coefficients follow from those six numbers by arithmetic: no load in front of the record loads)
 static bool pack16_plan(const PackParams &p, unsigned *lane16) {
-  if (!p.store16 || !p.quantise || p.lookback || p.tile_slices) return false;
+  if (!p.store16 || !p.quantise || p.tile_slices) return false;
+  if (p.lookback && (p.cbr_bytes || (p.n_slices + 3) / 4 > 65535)) return false; // (one pass: VBR only; the tiles are the grid's y)
   if ((p.slice_coefs & 7) || (p.store_stride & 7)) return false; // every record on a 16-byte boundary (the uint4 loads)
   const int lo[3] = {0, 32, 48}, width[3] = {32, 16, 16};
   for (int l = 0; l < 128; ++l) lane16[l] = 0;
@@ -215,12 +216,27 @@ __device__ __forceinline__ int p16_general(const int16_t *src, const int32_t *sr
   return count;
 }
 
-template <bool CBR>
-__global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
+// MODE 0: VBR through slots (scan + compaction behind the kernel), 1: HQ_CBR (every slice at its budget's offset),
+// 2: VBR in ONE pass (round 6) -- the slice offsets by decoupled look-back over the workgroups' byte counts, every slice
+// written where it belongs in the payload: no slots, no scan, no compaction (1.25 GB written and 2.5 GB moved again per 128
+// UHD pictures).  One 8-byte status word per tile of four slices: flag << 62 | bytes (flag 1: the tile's own count, 2: the
+// count of everything up to and including it).  The grid of mode 2 is (pictures, tiles): consecutive workgroups are the
+// SAME tile of consecutive pictures, so a picture's tile t - 1 started a whole row of workgroups before tile t and the
+// chains of all pictures advance side by side (round 1's form in k_hq_pack -- tiles numbered by a ticket per picture, one
+// picture's 4050 tiles in flight at a time -- took twice the time of the slots).  Workgroups start in the order of their
+// linear index (x fastest), so a predecessor is running or done: no ticket.
+constexpr int P16_SLOTS = 0, P16_CBR = 1, P16_LOOKBACK = 2;
+#ifndef VC2_P16LB_WPE
+#define VC2_P16LB_WPE 8 // mode 2: wavefronts per SIMD the register allocator is held to (64 registers and 12 bytes of spill; left alone it takes 66: 1.72 against 1.69 ms)
+#endif
+template <int MODE>
+__global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pack16(const PackParams p) {
+  constexpr bool CBR = MODE == P16_CBR, LB = MODE == P16_LOOKBACK;
   extern __shared__ unsigned lds_u[];
+  __shared__ int s_tot[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pic = blockIdx.y;
-  const int slice = blockIdx.x * 4 + wave;
+  const int pic = LB ? blockIdx.x : blockIdx.y, tile = LB ? blockIdx.y : blockIdx.x;
+  const int slice = tile * 4 + wave;
   const bool active = slice < p.n_slices; // wave-uniform
   const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
   unsigned *lut = lds_u;                   // at LDS address 0: a look-up's address is the quotient's low byte times four
@@ -255,7 +271,14 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
   if (threadIdx.x < 128) qt[threadIdx.x] = qt_e;
   for (int i = lane; i < img_q; i += 64) ((uint4 *)img)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  if (!active) return;
+  if (!active) {
+    if constexpr (LB) { // (a picture's last tile: the wavefronts without a slice count as zero bytes and keep the barriers' company)
+      if (lane == 0) s_tot[wave] = 0;
+      __syncthreads();
+      __syncthreads();
+    }
+    return;
+  }
 
   const int aqb = max(q - (int)(lt & 0xFFu), 0), aqh = max(q - (int)((lt >> 8) & 0xFFu), 0);
   if ((has_body && aqb > 119) || (has_head && aqh > 119)) atomicOr(p.err, VC2_DEVERR_QINDEX);
@@ -313,21 +336,60 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
 
   P16_STAT(0, true); P16_STAT(1, has_body && maxf >= 32768.f); P16_STAT(2, has_body && maxf * fb >= (float)(P16_MAXQ + 1));
   P16_STAT(3, has_body && max(L0, L1) > 63); P16_STAT(4, slow);
-  if (__builtin_expect(__any(slow), 0)) {
+  // mode 2: a slice's byte count is known BEFORE its codes go into the image.  The four counts meet over a barrier; from then
+  // on the workgroup's four slices share ONE image, back to back as they will lie in the payload (`wimg`, byte base `wb`:
+  // the codes of neighbouring slices meet in a word through the LDS atomics that write them anyway), so that what leaves
+  // the workgroup is one run of ~2.3 KB with one alignment.  One wavefront -- the LEADER, a different one from tile to
+  // tile -- publishes the tile's count and requests the status words of the 64 tiles before this one; the answer travels
+  // while all four write their codes
+  unsigned long long lb_first = 0;
+  bool lb_have = false;
+  unsigned *wimg = img;
+  int wb = 0;
+  const int leader = LB ? (tile == (p.n_slices + 3) / 4 - 1 ? 0 : (tile & 3)) : 0; // (the last tile's later wavefronts may have no slice)
+  auto lb_publish = [&](int total_bytes) {
+    if (lane == 0) s_tot[wave] = total_bytes;
+    __syncthreads();
+    wimg = lds_u + P16_LUT_N + 4 * 128;
+    { // (straight-line and through readfirstlane: as a loop over `wave` the base became a vector value and every address built
+      // on it cost the kernel twenty registers -- two wavefronts per SIMD)
+      const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2];
+      wb = __builtin_amdgcn_readfirstlane((wave > 0 ? t0 : 0) + (wave > 1 ? t1 : 0) + (wave > 2 ? t2 : 0));
+    }
+    if (wave == leader && tile > 0) {
+      unsigned long long *st = p.lookback + (size_t)pic * p.lookback_stride + 1;
+      if (lane == 0) __hip_atomic_store(&st[tile], (1ull << 62) | (unsigned long long)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef VC2_P16LB_NOEARLY
+      const int t = tile - 1 - lane;
+      lb_first = t >= 0 ? __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+      lb_have = true;
+#endif
+    }
+  };
+  const bool slow_any = __any(slow);
+  if (__builtin_expect(slow_any, 0)) {
     // the general coder, component by component: measure, then write (the image is still all zeros)
     const int32_t *recw = p.store_wide + rec_at;
+    if constexpr (LB) { // (the slice's place in the tile's image follows from all three lengths: measure first)
+#pragma unroll 1
+      for (int cc = 0; cc < 3; ++cc)
+        bytes[cc] = comp_len(p16_general<false>(rec + p.comp_off[cc], recw + p.comp_off[cc], p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, nullptr, 0, 0, p.err));
+      lb_publish(p.prefix + 4 + bytes[0] + bytes[1] + bytes[2]);
+    }
     int base = p.prefix + 1;
     for (int cc = 0; cc < 3; ++cc) {
       const int16_t *src = rec + p.comp_off[cc];
       const int32_t *srcw = recw + p.comp_off[cc];
-      const int count = p16_general<false>(src, srcw, p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, nullptr, 0, 0, p.err);
-      bytes[cc] = comp_len(count);
-      if (cc == 2) bytes[2] = cbr_v(bytes[2]);
-      p16_general<true>(src, srcw, p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, img, 8 * (base + 1), 8 * bytes[cc], p.err);
-      if (lane == 0) put_byte(img, base, (unsigned)(bytes[cc] / p.scalar));
+      if constexpr (!LB) {
+        const int count = p16_general<false>(src, srcw, p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, nullptr, 0, 0, p.err);
+        bytes[cc] = comp_len(count);
+        if (cc == 2) bytes[2] = cbr_v(bytes[2]);
+      }
+      p16_general<true>(src, srcw, p.comp_n[cc], p.comp_n0[cc], q, p.qmatrix, lane, wimg, 8 * (wb + base + 1), 8 * bytes[cc], p.err);
+      if (lane == 0) put_byte(wimg, wb + base, (unsigned)(bytes[cc] / p.scalar));
       base += 1 + bytes[cc];
     }
-    if (lane == 0) put_byte(img, p.prefix, (unsigned)q & 0xFFu);
+    if (lane == 0) put_byte(wimg, wb + p.prefix, (unsigned)q & 0xFFu);
   } else {
     // ---- positions: one scan over (head bits << 16 | body bits), segments = components (rows 0-1, row 2, row 3)
     const int pk = (hbits << 16) | body_bits;
@@ -358,33 +420,108 @@ __global__ __launch_bounds__(256) void k_hq_pack16(const PackParams p) {
     bytes[0] = __builtin_amdgcn_readlane(len, 0);
     bytes[1] = __builtin_amdgcn_readlane(len, 1);
     bytes[2] = cbr_v(__builtin_amdgcn_readlane(len, 2));
+    if constexpr (LB) lb_publish(p.prefix + 4 + bytes[0] + bytes[1] + bytes[2]);
     // data of component c starts one byte (its length byte) behind the previous component's end
     const int at_u = p.prefix + 2 + bytes[0], at_v = at_u + 1 + bytes[1]; // the length bytes of U and V
-    const int bit0 = 8 * ((comp == 0 ? p.prefix + 1 : (comp == 1 ? at_u : at_v)) + 1);
+    const int bit0 = 8 * (wb + (comp == 0 ? p.prefix + 1 : (comp == 1 ? at_u : at_v)) + 1);
     const int room = 8 * (comp == 0 ? bytes[0] : (comp == 1 ? bytes[1] : bytes[2])); // bits of the component's data
     // a head code is inside the length or wholly beyond it (beyond the last non-zero coefficient every code is one bit)
     if (hbits && hpos + hbits <= room) {
       const unsigned v = hcode << (32 - hbits);
-      unsigned *at = img + ((bit0 + hpos) >> 5);
+      unsigned *at = wimg + ((bit0 + hpos) >> 5);
       const unsigned bo = (unsigned)(bit0 + hpos);
       atomicOr(at, __builtin_amdgcn_alignbit(0u, v, bo));
       atomicOr(at + 1, __builtin_amdgcn_alignbit(v, 0u, bo));
     }
     if (has_body) {
       const int keep = min(max(room - bpos, 0), body_bits), k0 = min(keep, L0);
-      p16_put(img, bit0 + bpos, G0, L0, k0);
-      p16_put(img, bit0 + bpos + L0, G1, L1, keep - k0);
+      p16_put(wimg, bit0 + bpos, G0, L0, k0);
+      p16_put(wimg, bit0 + bpos + L0, G1, L1, keep - k0);
     }
     if (lane < 4) { // the quantiser index and the three length bytes
       const int at = lane == 0 ? p.prefix : (lane == 1 ? p.prefix + 1 : (lane == 2 ? at_u : at_v));
       const int lb = lane == 1 ? bytes[0] : (lane == 2 ? bytes[1] : bytes[2]);
       const unsigned val = lane == 0 ? ((unsigned)q & 0xFFu) : (unsigned)((float)lb * p.inv_scalar);
-      put_byte(img, at, val);
+      put_byte(wimg, wb + at, val);
     }
   }
   const int total = p.prefix + 4 + bytes[0] + bytes[1] + bytes[2];
   wave_lds_sync();
-  if (CBR) {
+  if constexpr (LB) {
+    __syncthreads(); // the tile's image is complete
+    // Only the LEADER waits for the look-back and moves the tile: the other three wavefronts are done and give their places to
+    // the next workgroups' (with all four waiting the kernel took 1.88 ms per 128 UHD pictures against 1.45 + 0.51 for slots and
+    // compaction: the wait -- a trip of the 64 status words to memory and back -- held four wavefront places per workgroup
+    // for a third of their lives)
+    if (wave != leader) return;
+    unsigned long long *st = p.lookback + (size_t)pic * p.lookback_stride + 1;
+    const unsigned long long M62 = (1ull << 62) - 1;
+    unsigned long long run = 0;
+    if (tile > 0) {
+      unsigned long long v = lb_first;
+      bool have = lb_have;
+      int spins = 0;
+      for (int base = tile - 1;;) {
+        const int t = base - lane;
+        // tiles before the first one count as an inclusive prefix of zero
+        if (!have) v = t >= 0 ? __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+        have = false;
+        const unsigned flag = (unsigned)(v >> 62);
+        const unsigned long long m2 = __ballot(flag == 2), m0 = __ballot(flag == 0);
+        const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;
+        const unsigned long long need = first2 >= 63 ? ~0ull : ((2ull << first2) - 1);
+#ifdef VC2_P16LB_NOWAIT // (pricing only, wrong offsets: what the kernel takes when nothing is ever waited for)
+        if (true) {
+#else
+        if ((m0 & need) == 0) { // every tile up to the first inclusive prefix has published
+#endif
+          run += (unsigned long long)wave_sum64((long long)(lane <= first2 ? (v & M62) : 0ull));
+          if (first2 < 64) break;
+#ifdef VC2_P16LB_NOWAIT
+          break;
+#endif
+          base -= 64;
+          spins = 0;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_STREAM); break; } // (never: see the grid's order)
+      }
+    }
+    const int tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    if (lane == 0) {
+      const unsigned long long incl = run + (unsigned long long)tot;
+      __hip_atomic_store(&st[tile], (2ull << 62) | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tile == (p.n_slices + 3) / 4 - 1) p.lens[pic] = incl;
+    }
+    // bytes of the image in stream order: byte i = img[i >> 2] >> (24 - 8 * (i & 3)).  Byte stores for the ragged head and
+    // tail of the destination, sixteen bytes per lane for its dword-aligned middle: destination dword w = stream bytes
+    // head + 4 w ..., i. e. image words w and w + 1 shifted by `head` bytes (k_compact's arithmetic, from LDS)
+    uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + run;
+    const unsigned *im = wimg;
+    const int head = min((int)((4 - ((size_t)dst & 3)) & 3), tot);
+    const int nw = (tot - head) >> 2, tail0 = head + 4 * nw;
+    if (lane < head) dst[lane] = (uint8_t)(im[lane >> 2] >> (24 - 8 * (lane & 3)));
+    if (lane < tot - tail0) { const int i = tail0 + lane; dst[i] = (uint8_t)(im[i >> 2] >> (24 - 8 * (i & 3))); }
+    unsigned *d4 = (unsigned *)(dst + head);
+    const unsigned h = (unsigned)head;
+    for (int q4 = 4 * lane; q4 < nw; q4 += 256) {
+      const uint4 v = *(const uint4 *)(im + q4);
+      const unsigned nx = im[q4 + 4]; // (behind a tile of the greatest length: the images' guard words)
+      const unsigned b0 = __builtin_bswap32(v.x), b1 = __builtin_bswap32(v.y), b2 = __builtin_bswap32(v.z), b3 = __builtin_bswap32(v.w), b4 = __builtin_bswap32(nx);
+      Dword4 o;
+      o.x = __builtin_amdgcn_alignbyte(b1, b0, h);
+      o.y = __builtin_amdgcn_alignbyte(b2, b1, h);
+      o.z = __builtin_amdgcn_alignbyte(b3, b2, h);
+      o.w = __builtin_amdgcn_alignbyte(b4, b3, h);
+      if (q4 + 4 <= nw) *(Dword4 *)(d4 + q4) = o;
+      else {
+        d4[q4] = o.x;
+        if (q4 + 1 < nw) d4[q4 + 1] = o.y;
+        if (q4 + 2 < nw) d4[q4 + 2] = o.z;
+      }
+    }
+  } else if (CBR) {
     if (bad_cbr) return;
     uint8_t *dst = p.payload + (size_t)pic * p.payload_stride + p.cbr_offsets[slice];
     // dword stores for the 4-byte aligned middle of the destination (the budgets put a slice at any byte), byte stores for

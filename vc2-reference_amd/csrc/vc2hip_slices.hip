@@ -799,6 +799,7 @@ __global__ __launch_bounds__(256) void k_hq_pack(const PackParams p) {
   PACK_STAMP(5);
 }
 
+struct __attribute__((aligned(4))) Dword4 { unsigned x, y, z, w; }; // four dwords at any dword-aligned address
 #include "vc2hip_pack16.h"
 
 size_t vc2_pack_lds_bytes(int prefix, int scalar);
@@ -846,6 +847,17 @@ static void p16_print_stats(hipStream_t s) {
 #else
 static void p16_print_stats(hipStream_t) {}
 #endif
+// VBR pictures whose slices k_hq_pack16 codes are packed in ONE pass by default (look-back, no slots): the caller asks
+// before it allocates slots or look-back words
+bool vc2_pack_one_pass_default(const PackParams &p0) {
+  static const int use16 = vc2_tune_int("VC2HIP_PACK16", 1);
+  if (!use16 || p0.cbr_bytes || vc2_pack_image_mode(p0.prefix, p0.scalar) != 0) return false;
+  PackParams p = p0;
+  static unsigned long long dummy;
+  p.lookback = &dummy;
+  p.tile_slices = 0;
+  return pack16_plan(p, p.lane16);
+}
 void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStream_t s) {
   PackParams p = p0;
 #ifdef VC2HIP_ABLATE
@@ -860,11 +872,14 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
     const dim3 grid((p.n_slices + 3) / 4, n_pictures);
     vc2_prof_begin(L, "hq_pack", s);
     if (p.cbr_bytes) {
-      vc2_allow_lds((const void *)k_hq_pack16<true>, 144 * 1024);
-      VC2_LAUNCH(L, k_hq_pack16<true>, grid, dim3(256), lds, s, p);
+      vc2_allow_lds((const void *)k_hq_pack16<P16_CBR>, 144 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16<P16_CBR>, grid, dim3(256), lds, s, p);
+    } else if (p.lookback) { // one pass: (pictures, tiles) -- see the kernel
+      vc2_allow_lds((const void *)k_hq_pack16<P16_LOOKBACK>, 144 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16<P16_LOOKBACK>, dim3(n_pictures, (p.n_slices + 3) / 4), dim3(256), lds, s, p);
     } else {
-      vc2_allow_lds((const void *)k_hq_pack16<false>, 144 * 1024);
-      VC2_LAUNCH(L, k_hq_pack16<false>, grid, dim3(256), lds, s, p);
+      vc2_allow_lds((const void *)k_hq_pack16<P16_SLOTS>, 144 * 1024);
+      VC2_LAUNCH(L, k_hq_pack16<P16_SLOTS>, grid, dim3(256), lds, s, p);
     }
     vc2_prof_end(L, s);
     p16_print_stats(s);
@@ -1016,7 +1031,6 @@ void vc2_launch_scan_sizes(Launcher &L, const uint32_t *sizes, uint32_t *offsets
   vc2_prof_end(L, s);
 }
 
-struct __attribute__((aligned(4))) Dword4 { unsigned x, y, z, w; }; // four dwords at any dword-aligned address
 // W lanes copy one slice: 64, or 32 / 16 when slices are short (at most 4 * W dwords per trip would leave lanes idle)
 template <int W>
 __global__ __launch_bounds__(256) void k_compact(const uint8_t *slots, int slot_bytes,

@@ -16,7 +16,7 @@ u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 # vc2hip_create_with_flags (include/vc2hip.h: each flag selects the slower / more general of two correct paths)
 FLAGS = {"STORE32": 0x001, "NO_STREAM": 0x002, "NO_PAIR": 0x004, "NO_BANDPLANES": 0x008, "NO_HEADS": 0x010, "NO_CBR_INDEX": 0x020,
          "GENERIC_DWT": 0x040, "SINGLE_PASS_VBR": 0x080, "CBR_GENERAL": 0x100, "LD_DIAGONALS": 0x200,
-         "PLANES8_ALWAYS": 0x400, "PLANES8_NEVER": 0x800}
+         "PLANES8_ALWAYS": 0x400, "PLANES8_NEVER": 0x800, "TWO_PASS_VBR": 0x1000}
 
 KERNELS = {"DD97": 0, "LeGall": 1, "DD137": 2, "Haar0": 3, "Haar1": 4, "Fidelity": 5, "Daub97": 6}
 CF = {"444": 0, "422": 1, "420": 2}
