@@ -12,7 +12,10 @@ from vc2lib import load_oracle, make_params, KERNELS
 
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
-hip = vc2hip_py.Vc2Hip(0); oracle = load_oracle()
+# FUZZ_FLAGS=single_pass_vbr,...: context flags by their names in vc2hip_py.FLAGS (round 6: the one-pass form of the coder)
+_flags = 0
+for _n in filter(None, os.environ.get("FUZZ_FLAGS", "").split(",")): _flags |= vc2hip_py.FLAGS[_n.strip().upper()]
+hip = vc2hip_py.Vc2Hip(0, flags=_flags); oracle = load_oracle()
 bad = refused = 0
 for case in range(cases):
     wide = rng.random() < 0.35

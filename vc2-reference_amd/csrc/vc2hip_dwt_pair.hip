@@ -266,37 +266,6 @@ __global__ __launch_bounds__(64, (pair_wpe<K>())) void k_fwd_pair(const PairPara
     // and 128 UHD pictures take 1.93 - 2.0 instead of 2.29 - 2.31 ms.  Not partial lines: their pieces no longer meet in L2 --
     // the deep levels' launch went from 0.34 to 0.63 ms, the first launch of 32 HD pictures (192-byte runs) from 0.144 to 0.218.
     const bool nt = FIRST && VC2_PAIR_NT && piece == 16 && (((run0 | run_n | slice_coefs) * (int)sizeof(ST)) & 127) == 0;
-#ifdef VC2_PRICE8 // PRICING ONLY (wrong results): what byte records would cost -- every 16-byte piece of the first launch leaves as
-                  // 8 bytes (values >> 4, low bytes) at half its byte offset from the picture's store
-    if constexpr (FIRST && S_::narrow) {
-      if (piece == 16 && ppr <= 64) {
-        const bool nt8 = VC2_PAIR_NT && (((run0 | run_n | slice_coefs)) & 127) == 0;
-        const int spt = 64 / ppr;
-        int ls = (int)((float)lane * (1.0f / (float)ppr));
-        ls -= ls * ppr > lane ? 1 : 0;
-        ls += (ls + 1) * ppr <= lane ? 1 : 0;
-        const int e = (lane - ls * ppr) * epp;
-        const ST *src = img + ls * ss + e;
-        ST *dst = rec0 + mul24z(ls, slice_coefs) + e;
-        const int dsrc = spt * ss;
-        const size_t ddst = mul24z(spt, slice_coefs);
-        typedef short s2v __attribute__((ext_vector_type(2)));
-#pragma unroll 1
-        for (int s2 = ls; s2 < sp.nsl; s2 += spt, src += dsrc, dst += ddst) {
-          if (ls < spt) {
-            uint4 x = *(const uint4 *)src;
-            unsigned xs4[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s2v t = __builtin_bit_cast(s2v, xs4[k]); t = t >> (short)4; xs4[k] = __builtin_bit_cast(unsigned, t); }
-            const uint2 o = make_uint2(__builtin_amdgcn_perm(xs4[1], xs4[0], 0x06040200u), __builtin_amdgcn_perm(xs4[3], xs4[2], 0x06040200u));
-            char *d8 = (char *)store + ((size_t)((const char *)dst - (const char *)store) >> 1);
-            if (nt8) st_nt(d8, o); else *(uint2 *)d8 = o;
-          }
-        }
-        return;
-      }
-    }
-#endif
     if (ppr <= 64) {
       const int spt = 64 / ppr;                                  // slices per trip
       int ls = (int)((float)lane * (1.0f / (float)ppr));         // lane / ppr (exact: both below 2^7, corrected below)

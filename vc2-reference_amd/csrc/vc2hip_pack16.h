@@ -82,9 +82,13 @@ static void vc2_upload_vlc_lut_s(hipStream_t s) {
 //   lane16[lane]   = quantisation-matrix entry of the lane's body run | of its head coefficient << 8
 //   lane16[64 + c] = head[c],  lane16[67 + c] = body lanes of component c
 // (the offsets of a lane's coefficients follow from those six numbers by arithmetic: no load in front of the record loads)
+#ifndef VC2_P16LB_WAVES
+#define VC2_P16LB_WAVES 4 // slices (= wavefronts) of a look-back tile
+#endif
+constexpr int P16LB_WAVES = VC2_P16LB_WAVES;
 static bool pack16_plan(const PackParams &p, unsigned *lane16) {
   if (!p.store16 || !p.quantise || p.tile_slices) return false;
-  if (p.lookback && (p.cbr_bytes || (p.n_slices + 3) / 4 > 65535)) return false; // (one pass: VBR only; the tiles are the grid's y)
+  if (p.lookback && (p.cbr_bytes || (p.n_slices + P16LB_WAVES - 1) / P16LB_WAVES > 65535)) return false; // (one pass: VBR only; the tiles are the grid's y)
   if ((p.slice_coefs & 7) || (p.store_stride & 7)) return false; // every record on a 16-byte boundary (the uint4 loads)
   const int lo[3] = {0, 32, 48}, width[3] = {32, 16, 16};
   for (int l = 0; l < 128; ++l) lane16[l] = 0;
@@ -149,31 +153,6 @@ __device__ __forceinline__ void p16_group(const uint4 w, const float f, const un
   L = S;
 }
 
-#ifdef VC2_PRICE8 // PRICING ONLY: eight coefficients that are already quantised bytes (no division, the byte is the table index)
-__device__ __forceinline__ void p16_group8(const uint2 w, const unsigned *lut, unsigned long long &G, int &L, int &last) {
-  const unsigned ww[2] = {w.x, w.y};
-  unsigned pr[4];
-  int pl[4];
-  int S = 0;
-  last = 0;
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    const unsigned x = ww[d >> 1] >> (16 * (d & 1));
-    const unsigned e0 = lut[x & 0xFFu], e1 = lut[(x >> 8) & 0xFFu];
-    const int l0 = (int)(e0 >> 24), l1 = (int)(e1 >> 24);
-    S += l0;
-    const int c0 = S & (int)(signed char)(e0 >> 16);
-    S += l1;
-    const int c1 = S & (int)(signed char)(e1 >> 16);
-    last = max(last, max(c0, c1));
-    pr[d] = ((e0 & 0xFFFFu) << l1) | (e1 & 0xFFFFu);
-    pl[d] = l0 + l1;
-  }
-  const unsigned long long q0 = ((unsigned long long)pr[0] << pl[1]) | pr[1], q1 = ((unsigned long long)pr[2] << pl[3]) | pr[3];
-  G = (q0 << (pl[2] + pl[3])) | q1;
-  L = S;
-}
-#endif
 
 // OR the first `keep` of the n <= 63 right-aligned bits of G into the image at bit position pos (0 <= keep <= n; what a
 // bounded write drops beyond the component's length are the '1's of trailing zeros, VLC.cpp:151-156).  No special cases
@@ -230,13 +209,14 @@ constexpr int P16_SLOTS = 0, P16_CBR = 1, P16_LOOKBACK = 2;
 #define VC2_P16LB_WPE 8 // mode 2: wavefronts per SIMD the register allocator is held to (64 registers and 12 bytes of spill; left alone it takes 66: 1.72 against 1.69 ms)
 #endif
 template <int MODE>
-__global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pack16(const PackParams p) {
+__global__ __launch_bounds__((MODE == 2 ? 64 * P16LB_WAVES : 256), (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pack16(const PackParams p) {
   constexpr bool CBR = MODE == P16_CBR, LB = MODE == P16_LOOKBACK;
   extern __shared__ unsigned lds_u[];
-  __shared__ int s_tot[4];
+  constexpr int NW = MODE == 2 ? P16LB_WAVES : 4; // slices of a workgroup
+  __shared__ int s_tot[NW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pic = LB ? blockIdx.x : blockIdx.y, tile = LB ? blockIdx.y : blockIdx.x;
-  const int slice = tile * 4 + wave;
+  const int slice = tile * NW + wave;
   const bool active = slice < p.n_slices; // wave-uniform
   const int img_q = ((p.prefix + 4 + 3 * 255 * p.scalar + 3) / 4 + 2 + 3) / 4; // image size in 16-byte pieces
   unsigned *lut = lds_u;                   // at LDS address 0: a look-up's address is the quotient's low byte times four
@@ -259,11 +239,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pac
   const int16_t *rec = (const int16_t *)p.store + rec_at;
   uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
   int hv = 0;
-#ifdef VC2_PRICE8
-  if (active && has_body) w0 = *(const uint4 *)((const char *)p.store + (rec_at + coff + head_n + 16 * cl));
-#else
   if (active && has_body) { const int16_t *b = rec + coff + head_n + 16 * cl; w0 = *(const uint4 *)b; w1 = *(const uint4 *)(b + 8); }
-#endif
   if (active && has_head) hv = rec[coff + cl];
   const int32_t *hwide = p.store_wide + rec_at + coff + cl; // the head coefficient's place in the wide array (an escape of the 16-bit store)
   const int q = p.qidx[(size_t)pic * p.n_slices + (active ? slice : 0)]; // (a scalar load: requested before the barrier, used behind it)
@@ -289,17 +265,10 @@ __global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pac
   unsigned long long G0, G1;
   int L0, L1, last0, last1;
   float maxf = 0.f;
-#ifdef VC2_PRICE8
-  p16_group8(make_uint2(w0.x, w0.y), lut, G0, L0, last0);
-  p16_group8(make_uint2(w0.z, w0.w), lut, G1, L1, last1);
-  int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
-  bool slow = (w0.x & w0.y & w0.z & w0.w) == 0x80808080u && fb == 3.f && maxf > 0.f; // (a test of the same shape; never true)
-#else
   p16_group(w0, fb, lut, G0, L0, last0, maxf);
   p16_group(w1, fb, lut, G1, L1, last1, maxf);
   int body_bits = L0 + L1, body_last = last1 ? L0 + last1 : last0;
   bool slow = maxf >= 32768.f /* an escape of the store */ || maxf * fb >= (float)(P16_MAXQ + 1) || max(L0, L1) > 63;
-#endif
   if (!has_body) { body_bits = 0; body_last = 0; slow = false; }
   // ---- head: one coefficient, code by arithmetic
   unsigned hcode = 0;
@@ -346,24 +315,27 @@ __global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pac
   bool lb_have = false;
   unsigned *wimg = img;
   int wb = 0;
-  const int leader = LB ? (tile == (p.n_slices + 3) / 4 - 1 ? 0 : (tile & 3)) : 0; // (the last tile's later wavefronts may have no slice)
+  const int leader = LB ? (tile == (p.n_slices + NW - 1) / NW - 1 ? 0 : (tile & (NW - 1))) : 0; // (the last tile's later wavefronts may have no slice)
   auto lb_publish = [&](int total_bytes) {
     if (lane == 0) s_tot[wave] = total_bytes;
     __syncthreads();
     wimg = lds_u + P16_LUT_N + 4 * 128;
     { // (straight-line and through readfirstlane: as a loop over `wave` the base became a vector value and every address built
       // on it cost the kernel twenty registers -- two wavefronts per SIMD)
-      const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2];
-      wb = __builtin_amdgcn_readfirstlane((wave > 0 ? t0 : 0) + (wave > 1 ? t1 : 0) + (wave > 2 ? t2 : 0));
+      int b = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < NW - 1; ++w2) b += wave > w2 ? s_tot[w2] : 0;
+      wb = __builtin_amdgcn_readfirstlane(b);
     }
     if (wave == leader && tile > 0) {
       unsigned long long *st = p.lookback + (size_t)pic * p.lookback_stride + 1;
-      if (lane == 0) __hip_atomic_store(&st[tile], (1ull << 62) | (unsigned long long)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef VC2_P16LB_NOEARLY
+      int agg = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) agg += s_tot[w2];
+      if (lane == 0) __hip_atomic_store(&st[tile], (1ull << 62) | (unsigned long long)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int t = tile - 1 - lane;
       lb_first = t >= 0 ? __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
       lb_have = true;
-#endif
     }
   };
   const bool slow_any = __any(slow);
@@ -470,16 +442,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pac
         const unsigned long long m2 = __ballot(flag == 2), m0 = __ballot(flag == 0);
         const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;
         const unsigned long long need = first2 >= 63 ? ~0ull : ((2ull << first2) - 1);
-#ifdef VC2_P16LB_NOWAIT // (pricing only, wrong offsets: what the kernel takes when nothing is ever waited for)
-        if (true) {
-#else
         if ((m0 & need) == 0) { // every tile up to the first inclusive prefix has published
-#endif
           run += (unsigned long long)wave_sum64((long long)(lane <= first2 ? (v & M62) : 0ull));
           if (first2 < 64) break;
-#ifdef VC2_P16LB_NOWAIT
-          break;
-#endif
           base -= 64;
           spins = 0;
           continue;
@@ -488,11 +453,13 @@ __global__ __launch_bounds__(256, (MODE == 2 ? VC2_P16LB_WPE : 1)) void k_hq_pac
         if (++spins > (1 << 22)) { if (lane == 0) atomicOr(p.err, VC2_DEVERR_STREAM); break; } // (never: see the grid's order)
       }
     }
-    const int tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    int tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) tot += s_tot[w2];
     if (lane == 0) {
       const unsigned long long incl = run + (unsigned long long)tot;
       __hip_atomic_store(&st[tile], (2ull << 62) | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tile == (p.n_slices + 3) / 4 - 1) p.lens[pic] = incl;
+      if (tile == (p.n_slices + NW - 1) / NW - 1) p.lens[pic] = incl;
     }
     // bytes of the image in stream order: byte i = img[i >> 2] >> (24 - 8 * (i & 3)).  Byte stores for the ragged head and
     // tail of the destination, sixteen bytes per lane for its dword-aligned middle: destination dword w = stream bytes
@@ -734,7 +701,7 @@ static size_t pack16w_lds(int prefix, int scalar) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
   return img_q * 16 + P16_LUT_N * 4 + 128 * 16 + P16_GUARD_BYTES;
 }
-static size_t pack16_lds(int prefix, int scalar) {
+static size_t pack16_lds(int prefix, int scalar, int waves = 4) {
   const size_t img_q = (((size_t)prefix + 4 + 3 * 255 * (size_t)scalar + 3) / 4 + 2 + 3) / 4;
-  return 4 * img_q * 16 + P16_LUT_N * 4 + 128 * 16 + P16_GUARD_BYTES;
+  return (size_t)waves * img_q * 16 + P16_LUT_N * 4 + 128 * 16 + P16_GUARD_BYTES;
 }

@@ -876,7 +876,8 @@ void vc2_launch_pack(Launcher &L, const PackParams &p0, int n_pictures, hipStrea
       VC2_LAUNCH(L, k_hq_pack16<P16_CBR>, grid, dim3(256), lds, s, p);
     } else if (p.lookback) { // one pass: (pictures, tiles) -- see the kernel
       vc2_allow_lds((const void *)k_hq_pack16<P16_LOOKBACK>, 144 * 1024);
-      VC2_LAUNCH(L, k_hq_pack16<P16_LOOKBACK>, dim3(n_pictures, (p.n_slices + 3) / 4), dim3(256), lds, s, p);
+      VC2_LAUNCH(L, k_hq_pack16<P16_LOOKBACK>, dim3(n_pictures, (p.n_slices + P16LB_WAVES - 1) / P16LB_WAVES), dim3(64 * P16LB_WAVES),
+                 pack16_lds(p.prefix, p.scalar, P16LB_WAVES), s, p);
     } else {
       vc2_allow_lds((const void *)k_hq_pack16<P16_SLOTS>, 144 * 1024);
       VC2_LAUNCH(L, k_hq_pack16<P16_SLOTS>, grid, dim3(256), lds, s, p);
