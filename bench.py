@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the per-core CPU run (0: one per core)")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-batch32", action="store_true",
+                    help="skip `value_at_32_pictures_per_step` (the rocprofv3 passes: every launch of a kernel is then of the full batch, "
+                         "and the per-kernel averages in profiles/ are those of the timed step)")
     ap.add_argument("--no-rank-oracle", action="store_true",
                     help="N > 1: skip the oracle's coding of every rank's slots 2..5 (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -438,11 +441,13 @@ def main():
     def step32():
         hip.encode_batch_dev(d_raw.data_ptr(), B32, fmt, cp, d_pay.data_ptr(), stride, d_len.data_ptr())
         hip.decode_batch_dev(d_pay.data_ptr(), stride, d_len.data_ptr(), B32, fmt, cp, d_out.data_ptr())
-    step32()
-    dt_32 = timed(step32, args.steps)
-    step()   # (the buffers hold the whole batch's results again for the parity check below)
-    hip.sync()
-    tmax = torch.tensor([dt_noev, dt_enc, dt_dec, dt_32], dtype=torch.float64, device=red_dev)
+    dt_32 = None
+    if not args.no_batch32:
+        step32()
+        dt_32 = timed(step32, args.steps)
+        step()   # (the buffers hold the whole batch's results again for the parity check below)
+        hip.sync()
+    tmax = torch.tensor([dt_noev, dt_enc, dt_dec, dt_32 or 0.0], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_noev, dt_enc, dt_dec, dt_32 = tmax.tolist()
@@ -615,9 +620,10 @@ def main():
                               "min": round(total_px / max(region_dt) / 1e6, 1), "max": round(total_px / min(region_dt) / 1e6, 1),
                               "note": f"three timed regions of {args.steps} steps each, every one between barrier + synchronize, each decoding into "
                                       "its own separately allocated output buffer; `value` / `ms_per_step` are the MEDIAN region's"},
-            "value_at_32_pictures_per_step": {"value": round(pixels * B32 * world * args.steps / dt_32 / 1e6, 1), "unit": "Mpixels/s",
-                                              "ms_per_step": round(dt_32 / args.steps * 1e3, 4),
-                                              "note": "the unit rounds 1 - 4 quoted; the same buffers, the first 32 pictures per step"},
+            "value_at_32_pictures_per_step": (None if not dt_32 else
+                                              {"value": round(pixels * B32 * world * args.steps / dt_32 / 1e6, 1), "unit": "Mpixels/s",
+                                               "ms_per_step": round(dt_32 / args.steps * 1e3, 4),
+                                               "note": "the unit rounds 1 - 4 quoted; the same buffers, the first 32 pictures per step"}),
             "value_without_kernel_events": round(total_px / dt_noev / 1e6, 1),
             "parity_checked": parity,
             "e2e": e2e,

@@ -49,17 +49,19 @@ def main(tag):
             if r['Counter_Name'] != name:
                 continue
             sn = short(r['Kernel_Name'])
-            if sn:   # several instantiations (and launch sizes) can share a short name: average over all their launches
-                a = acc.setdefault(sn, [0, 0.0])
-                a[0] += 1
-                a[1] += float(r['Counter_Value'])
-        for sn, (cnt, tot) in acc.items():
-            out.setdefault(sn, {})[name + '_KiB'] = tot / cnt
-            out[sn]['launches_sampled'] = cnt
+            if sn:   # several instantiations can share a short name: average over their launches
+                acc.setdefault(sn, []).append(float(r['Counter_Value']))
+        for sn, vals in acc.items():
+            # (round 6: bench.py also runs a few steps of 32 pictures -- `value_at_32_pictures_per_step`; a launch that moved
+            # less than half of the name's largest launch is one of those, or of a smaller instantiation, and stays out of
+            # the per-launch average of the full batch.  Names that only occur in those steps keep what they have.)
+            full = [v for v in vals if v >= 0.5 * max(vals)]
+            out.setdefault(sn, {})[name + '_KiB'] = sum(full) / len(full)
+            out[sn]['launches_sampled'] = len(full)
     cfg = json.loads(open(f'{d}/bench_under_rocprof.json').read().strip().splitlines()[-1])["config"]   # the same command line as the PMC passes
     per_launch = cfg["pictures_per_gpu_per_step"] // max(1, cfg["streams"])
     res = {"_comment": "rocprofv3 PMC, two separate passes (--kernel-trace --pmc FETCH_SIZE ; --kernel-trace --pmc WRITE_SIZE) of "
-                       f"`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs` ({cfg['pictures_per_gpu_per_step']} UHD cfg-2 pictures per step on {cfg['streams']} stream(s): {per_launch} per launch), averages "
+                       f"`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs --no-batch32` ({cfg['pictures_per_gpu_per_step']} UHD cfg-2 pictures per step on {cfg['streams']} stream(s): {per_launch} per launch), averages "
                        "per launch. FETCH_SIZE/WRITE_SIZE are in KiB. hbm_bytes_per_launch applies the gfx950 correction of "
                        "MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads): 2*FETCH + WRITE -- an upper bound for "
                        "kernels whose reads are narrower than 16 bytes per lane. Names with several launches per step (dwt_level, "
