@@ -23,7 +23,8 @@
 //     escape of the 16-bit store -- sends the WHOLE slice (wave-uniform) through component_bits, the general two-pass
 //     coder of this file: correct for every input, about three times slower for that slice.
 // The launcher (vc2_launch_pack) chooses this kernel when pack16_plan() accepts the geometry; every other geometry, the
-// int32 store, unquantised input, look-back VBR and images beyond LDS keep k_hq_pack.
+// int32 store, unquantised input and images beyond LDS keep k_hq_pack.  Round 6: MODE 2 of the kernel packs VBR pictures in
+// ONE pass (look-back over the tiles' byte counts: see the comment in front of the kernel).
 #pragma once
 
 #ifdef VC2HIP_ABLATE // why wavefronts leave the table path (tools/probe: VC2HIP_P16_STATS=1 prints the counters after every launch)
