@@ -87,7 +87,7 @@ static void vc2_upload_vlc_lut_s(hipStream_t s) {
 #define VC2_P16LB_WAVES 4 // slices (= wavefronts) of a look-back tile
 #endif
 constexpr int P16LB_WAVES = VC2_P16LB_WAVES;
-static_assert(P16LB_WAVES >= 2 && P16LB_WAVES <= 16 && (P16LB_WAVES & (P16LB_WAVES - 1)) == 0, "the leader of a tile is tile & (waves - 1)");
+static_assert(P16LB_WAVES >= 4 && P16LB_WAVES <= 16 && (P16LB_WAVES & (P16LB_WAVES - 1)) == 0, "the leader of a tile is tile & (waves - 1); the tables are filled by 256 threads");
 static bool pack16_plan(const PackParams &p, unsigned *lane16) {
   if (!p.store16 || !p.quantise || p.tile_slices) return false;
   if (p.lookback && (p.cbr_bytes || (p.n_slices + P16LB_WAVES - 1) / P16LB_WAVES > 65535)) return false; // (one pass: VBR only; the tiles are the grid's y)
